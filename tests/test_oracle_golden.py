@@ -1,0 +1,180 @@
+"""The oracle against the golden vectors taken from the reference (CPU only).
+
+The vectors in tests/golden/ were produced by tools/make_golden.py from the real
+reference; these tests pin oracle/ to them so that the GPU parity tests (which
+compare the HIP path with the oracle) inherit the pin."""
+import glob
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import envs as oenv
+from oracle import policy as opol
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(pat):
+    files = sorted(glob.glob(os.path.join(G, pat)))
+    assert files, pat
+    return [(os.path.basename(f), np.load(f, allow_pickle=False)) for f in files]
+
+
+@pytest.mark.parametrize("name,z", _load("instances_*.npz"))
+def test_instances_rng_order(name, z):
+    env = oenv.OracleEnv(int(z["kind"]), int(z["N"]), int(z["B"]), int(z["num_draw"]),
+                         int(z["seed"]))
+    assert np.array_equal(env.draw_idxs, z["draw_idxs"])
+    for r in range(3):
+        assert np.array_equal(env.pos, z[f"pos{r}"])
+        assert np.array_equal(env.depots, z[f"depots{r}"])
+        assert np.array_equal(env.demands, z[f"demands{r}"])
+        if r < 2:
+            env.reset()
+
+
+@pytest.mark.parametrize("name,z", _load("envtrace_*.npz"))
+def test_env_trace_bit_exact(name, z):
+    kind, B, N = int(z["kind"]), int(z["B"]), int(z["N"])
+    env = oenv.OracleEnv(kind, N, B, 1, int(z["seed"]))
+    assert np.array_equal(env.pos, z["pos"])
+    st = env.get_state()
+    m = (st[0] if kind == oenv.IRP else st)[:, :, -1]
+    assert np.array_equal(m.astype(np.uint8), z["mask_init"])
+    assert np.array_equal(env.visited.astype(np.uint8), z["visited_init"])
+    for t in range(int(z["T"])):
+        st, r, done, _ = env.step(z["actions"][t][:, None])
+        m = (st[0] if kind == oenv.IRP else st)[:, :, -1]
+        assert np.array_equal(m.astype(np.uint8), z["mask"][t]), t
+        assert np.array_equal(env.visited.astype(np.uint8), z["visited"][t]), t
+        assert np.array_equal(env.current_location[:, 0], z["cur"][t])
+        assert done == bool(z["done"][t])
+        assert np.max(np.abs(r - z["reward"][t])) <= 2.3e-16
+        assert np.array_equal(r.astype(np.float32), z["reward"][t].astype(np.float32))
+        if kind == oenv.IRP:
+            assert np.array_equal(env.load, z["load"][t])
+    assert done
+
+
+def test_weight_init_hashes():
+    import hashlib
+    z = np.load(os.path.join(G, "weights.npz"))
+    for kind in (0, 1, 2):
+        sd, tsd = opol.init_state_dicts(kind, 69)
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode())
+            h.update(v.contiguous().numpy().tobytes())
+        assert h.hexdigest()[:16] == str(z[f"sha_k{kind}"])
+        assert list(sd.keys()) == list(z[f"keys_k{kind}"])
+        n = sum(v.numel() for k, v in sd.items()
+                if "running" not in k and "num_batches" not in k)
+        assert n == int(z[f"nparam_k{kind}"])
+
+
+@pytest.mark.parametrize("name,z", _load("encoder_*.npz"))
+def test_encoder(name, z):
+    kind = int(z["kind"])
+    x = torch.tensor(z["x"])
+    dm = None if kind == 0 else torch.tensor(z["depot_mask"])
+    for mode in ("eval", "train"):
+        sd, _ = opol.init_state_dicts(kind, 69)
+        emb = opol.encoder_forward(sd, x, dm, train=(mode == "train"))
+        assert (emb - torch.tensor(z[f"emb_{mode}"])).abs().max().item() < 1e-5
+        if mode == "train":
+            for k in z.files:
+                if k.startswith("bn_"):
+                    got = sd["encoder." + k[3:]].float()
+                    assert (got - torch.tensor(z[k]).float()).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,z", _load("decoder_*.npz"))
+def test_decoder_teacher_forced(name, z):
+    kind = int(z["kind"])
+    sd, _ = opol.init_state_dicts(kind, 69)
+    emb = torch.tensor(z["emb"])
+    ep = opol.DecoderEpisode(sd, emb)
+    for t in range(z["mask"].shape[0]):
+        mask = torch.tensor(z["mask"][t])
+        load = torch.tensor(z["load"][t]) if kind == 2 else None
+        greedy = t % 2 == 0
+        u = ep.logits(mask, load)
+        fin = np.isfinite(z["u"][t])
+        assert np.array_equal(fin, torch.isfinite(u).numpy())
+        assert np.max(np.abs(u.numpy()[fin] - z["u"][t][fin])) < 1e-5
+        idx, logp = ep.choose(u, greedy, None if greedy else torch.tensor(z["noise"][t]))
+        assert np.array_equal(idx.numpy(), z["idx"][t])
+        assert np.max(np.abs(logp.numpy() - z["logp"][t])) < 1e-5
+        ep.advance(idx)
+
+
+@pytest.mark.parametrize("name,z", _load("rollout_*.npz"))
+def test_rollout(name, z):
+    kind, B, N, greedy = int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"])
+    sd, _ = opol.init_state_dicts(kind, 69)
+    env = oenv.OracleEnv(kind, N, B, 1, 69)
+    torch.manual_seed(int(z["torch_seed"]))
+    trace = []
+    with torch.no_grad():
+        loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, trace=trace)
+    acts = np.array([t["idx"].numpy() for t in trace])
+    exempt = np.zeros(B, bool)
+    if acts.shape != z["actions"].shape or not np.array_equal(acts, z["actions"]):
+        for b in range(B):
+            for t in range(min(len(acts), len(z["actions"]))):
+                if acts[t, b] != z["actions"][t, b]:
+                    srt = torch.sort(trace[t]["u"][b], descending=True).values
+                    assert (srt[0] - srt[1]).item() < 1e-4
+                    exempt[b] = True
+                    break
+        torch.manual_seed(int(z["torch_seed"]))
+        with torch.no_grad():
+            loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, forced=z["actions"])
+    assert T == int(z["T"])
+    assert np.max(np.abs(loss.numpy() - z["acc_loss"])) < 1e-5
+    assert np.max(np.abs(logp.numpy() - z["acc_logp"])) < 1e-5
+    assert exempt.sum() <= max(1, B // 32)
+
+
+def test_reference_kats():
+    """The reference's own known answers: tests/test_agent.py:69,84,99,114 and the
+    BASELINE config-1 pin."""
+    want = {0: -1.5130789279937744, 1: -1.952601671218872, 2: -2.9770922660827637}
+    for kind, v in want.items():
+        env = oenv.OracleEnv(kind, 4, 2, 1)
+        sd, _ = opol.init_state_dicts(kind, 69)
+        env.reset()
+        with torch.no_grad():
+            loss, _, _ = opol.rollout(sd, env, True, train=True)
+        assert np.isclose(loss.mean().item(), v)
+    env = oenv.OracleEnv(1, 8, 2, 1)
+    np.random.seed(69)
+    acc, _ = opol.random_rollout(env)
+    assert np.isclose(acc.mean().item(), -5.585874557495117)
+    env = oenv.OracleEnv(0, 20, 64, 6, 69)
+    np.random.seed(69)
+    acc, T = opol.random_rollout(env)
+    assert T == 19 and np.isclose(-acc.mean().item(), 9.624367713928223)
+
+
+def test_reference_env_kats():
+    """tests/test_env.py:44-60 and tests/test_graph.py:26-42 restated on the oracle:
+    two equilateral triangles (side 1 and 4), actions [[2],[2]] -> reward [-1, 0]."""
+    env = oenv.OracleEnv(oenv.VRP, 3, 2, 2, 69)
+    assert env.depots[:, 0].tolist() == [1, 2]
+    y = np.sqrt(3) / 2
+    env.pos[0] = [[0, 0], [1, 0], [0.5, y]]
+    env.pos[1] = [[0, 0], [4, 0], [2, 4 * y]]
+    st = env.get_state()
+    assert st.shape == (2, 3, 4) and st[:, :, 2].sum() == 2
+    st, r, _, _ = env.step(np.array([2, 2])[:, None])
+    assert np.allclose(r, [-1, 0])
+    assert st[0, 2, 3] == 1 and st[1, 2, 3] == 1
+    e2 = oenv.OracleEnv(oenv.TSP, 2, 1, 1, 69)
+    e2.pos[0] = [[2, -1], [-2, 2]]
+    e2.current_location = np.array([[0]])
+    _, r, _, _ = e2.step(np.array([[1]]))
+    assert r[0] == -5
