@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched env.step() + attention-policy rollout.
+
+Metric (BASELINE.json): env-steps/sec in node-steps (batch x nodes x steps / s) on
+TSP-20, batch 512 per GPU, greedy rollout of the untrained seed-69 attention agent
+(configs[1]).  One bench "step" = one complete rollout of one batch: encoder + T
+fused decode/env steps, instances already resident in HBM.  Weak scaling: every
+rank runs its own 512-graph batch; the value is the whole-job aggregate.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline            decode_step kernel of the benched workload vs HBM peak
+  roofline_north_star the same kernel at 8192 x 40 (the north-star target shape)
+  cpu_baseline        the CPU oracle (oracle/, a port of the reference) on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vrp-gym_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.3 TB/s achievable
+
+WORKLOADS = {
+    # name: (kind, nodes, batch per GPU, greedy)
+    "tsp20_b512": (0, 20, 512, True),       # BASELINE configs[1] (the metric's config)
+    "tsp40_b8192": (0, 40, 8192, True),     # north-star shape
+    "vrp40_b2048": (1, 40, 2048, True),
+    "vrp100_b2048": (1, 100, 2048, False),  # configs[4] per-GPU shard, sampling
+}
+
+
+def algorithmic_bytes_per_step(B, N):
+    """bytes(B,N) = B*(523*N + 72) per decode+env step."""
+    return B * (523 * N + 72)
+
+
+def make(kind, N, B, seed, device):
+    import agents
+    from gym_vrp.envs import IRPEnv, TSPEnv, VRPEnv
+    Env = (TSPEnv, VRPEnv, IRPEnv)[kind]
+    Agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
+    env = Env(num_nodes=N, batch_size=B, num_draw=1, seed=seed, device=device)
+    agent = Agent(seed=69)
+    agent.model.eval()
+    return env, agent
+
+
+def rewind(env):
+    """Start-of-episode state on the SAME resident instances (device memsets only)."""
+    env._visited.zero_()
+    env._cur.copy_(env._depot)
+    env._load.fill_(1.0)
+    env._parity = 0
+    env._mask_fresh = False
+    env._step_count = 0
+    env._last_rollout = None
+
+
+def timed_rollouts(env, agent, greedy, steps, warmup, dist):
+    from agents import runtime
+    res = None
+    with torch.no_grad():
+        for _ in range(warmup):
+            rewind(env)
+            res = runtime.rollout(agent.model, env, greedy)
+        T = res.T if res is not None else None
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rewind(env)
+            res = runtime.rollout(agent.model, env, greedy)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return dt, res.T, float(-res.acc_loss.mean().item())
+
+
+def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
+    """Average duration of ONE decode_step launch, HIP events on the launch stream
+    around every launch (the stream the library launches on is torch's current one)."""
+    import ctypes as C
+    import vrpgym_hip as hip
+    from agents import runtime
+    env, agent = make(kind, N, B, 69, device)
+    lib = hip.lib()
+    model = agent.model
+    with torch.no_grad():
+        res = runtime.rollout(model, env, greedy, trace=False)  # fills emb + tables
+        T = res.T
+    max_steps = res.max_steps
+    ew, dw = runtime.encoder_struct(model.encoder), runtime.decoder_struct(model.decoder)
+    derived = runtime.decoder_derived(model.decoder, kind)
+    dec_ws = runtime._buf("dec", device, 0)
+    io = hip.RolloutIO()
+    io.acc_loss, io.acc_logp = res.acc_loss.data_ptr(), res.acc_logp.data_ptr()
+    io.notdone = res.notdone.data_ptr()
+    noise = None
+    if not greedy:
+        noise = torch.empty((max_steps, B, N), device=device).exponential_(1)
+        io.noise = noise.data_ptr()
+    stream = hip.current_stream(device)
+    durs = []
+    for _ in range(reps):
+        rewind(env)
+        cenv = env._cenv()
+        hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(T)]
+        for t in range(T):
+            evs[t][0].record()
+            hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
+                                          res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
+                                          max_steps, 0 if greedy else 1, stream))
+            evs[t][1].record()
+        torch.cuda.synchronize()
+        durs += [a.elapsed_time(b) * 1e-3 for a, b in evs]
+    avg = float(np.mean(durs))
+    byts = algorithmic_bytes_per_step(B, N)
+    achieved = byts / avg / 1e9
+    return {"bound": "hbm", "kernel": "decode_step_kernel", "workload": f"kind{kind}_N{N}_B{B}",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
+            "launches_timed": len(durs)}
+
+
+def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
+    """The CPU oracle (a port of the reference's algorithm: vectorised numpy env +
+    torch-CPU fp32 policy) on this host's cores, same workload, bounded sample."""
+    from oracle import envs as oenv
+    from oracle import policy as opol
+    sd, _ = opol.init_state_dicts(kind, 69)
+    env = oenv.OracleEnv(kind, N, B, 1, 69)
+    from copy import deepcopy
+    n, node_steps, t0 = 0, 0, time.perf_counter()
+    with torch.no_grad():
+        opol.rollout(sd, deepcopy(env), greedy)  # warm
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            _, _, T = opol.rollout(sd, deepcopy(env), greedy)
+            node_steps += B * N * T
+            n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(node_steps / dt, 1), "unit": "node-steps/s",
+            "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{n} greedy rollouts of kind{kind} N={N} B={B} in {dt:.1f}s "
+                      f"(oracle/: numpy env + torch-CPU fp32 policy)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="tsp20_b512", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    kind, N, B, greedy = WORKLOADS[a.workload]
+    env, agent = make(kind, N, B, 69 + rank, device)  # each rank its own instance stream
+    dt, T, cost = timed_rollouts(env, agent, greedy, a.steps, a.warmup, dist)
+    tmax = torch.tensor([dt], device=device)
+    costs = torch.tensor([cost], device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(costs, op=dist.ReduceOp.SUM)
+    tmax, cost = float(tmax.item()), float(costs.item()) / world
+    node_steps = world * a.steps * B * N * T
+    out = {
+        "metric": "env-steps/sec (batch x nodes), greedy attention rollout",
+        "value": round(node_steps / tmax, 1), "unit": "node-steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(tmax / a.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{'TSP VRP IRP'.split()[kind]}Env num_nodes={N} "
+                               f"batch_size={B} per GPU, attention agent "
+                               f"{'greedy' if greedy else 'sampling'} rollout "
+                               f"(encoder + {T} fused decode/env steps), untrained seed-69 weights",
+                   "name": a.workload, "global_batch": B * world, "num_nodes": N,
+                   "steps_per_rollout": T, "parallelism": f"dp{world} (independent shards, no "
+                   "collective on the rollout path)"},
+        "graph_steps_per_s": round(world * a.steps * B * T / tmax, 1),
+        "mean_tour_cost": round(cost, 6),
+    }
+    if rank == 0:
+        out["roofline"] = step_kernel_roofline(kind, N, B, greedy, device)
+        if not a.no_north_star and world == 1 and a.workload != "tsp40_b8192":
+            out["roofline_north_star"] = step_kernel_roofline(0, 40, 8192, True, device)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, N, B, greedy)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+/*
+ * vrpgym_hip.h — C ABI of libvrpgym_hip.so (gfx950 / MI355X).
+ *
+ * The reference (kevin-schumann/VRP-GYM) has no FFI: its hot path is Python
+ * (numpy/networkx environments + torch modules).  This header is the boundary a
+ * maintainer would bind with ctypes from the reference's own classes; every entry
+ * point names the reference code it replaces (paths relative to the reference
+ * repository root).  The binding shipped here is vrp-gym_amd/vrpgym_hip/_lib.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - no ownership is transferred, nothing is allocated or freed by the library;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     synchronises, and is safe to capture into a hipGraph;
+ *   - return value 0 = ok, non-zero = error; vrp_last_error() returns a
+ *     thread-local description of the last failure;
+ *   - kind: 0 = TSP, 1 = VRP, 2 = IRP  (gym_vrp/envs/{tsp,vrp,irp}.py).
+ */
+#ifndef VRPGYM_HIP_H
+#define VRPGYM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRP_KIND_TSP 0
+#define VRP_KIND_VRP 1
+#define VRP_KIND_IRP 2
+
+#define VRP_EMB 128      /* embedding width the kernels are built for            */
+#define VRP_HEADS 8      /* decoder heads (agents/graph_tsp_agent.py:53-55)      */
+#define VRP_MAX_NODES 128
+
+/* ---- environment state (replaces the numpy attributes of TSPEnv/IRPEnv) ------ */
+typedef struct vrp_env {
+  int32_t kind, B, N, reserved;
+  const double *pos;     /* (B,N,2) fp64 coordinates   vrp_graph.py:28-31          */
+  const double *demand;  /* (B,N)   fp64, IRP only     vrp_graph.py:41-43          */
+  const int32_t *depot;  /* (B)                        vrp_graph.py:34             */
+  uint8_t *visited;      /* (B,N)  TSPEnv.visited      tsp.py:86,131-148           */
+  uint8_t *mask;         /* (2,B,N) ping-pong copies of the state's mask column;   */
+                         /*   buffer `p` is read by decode step with parity p and  */
+                         /*   buffer p^1 written by the env step that follows it   */
+  int32_t *cur;          /* (B)    TSPEnv.current_location                         */
+  double *load;          /* (B)    IRPEnv.load (fp64), unused otherwise            */
+} vrp_env;
+
+/* E7/E8  TSPEnv.generate_mask tsp.py:131-148 / vrp.py:13-37 / irp.py:126-155.
+ * Applies the depot fix-ups to `visited` in place and writes mask buffer `parity`. */
+int vrp_env_mask(const vrp_env *env, int parity, void *stream);
+
+/* E4-E8  TSPEnv.step tsp.py:60-101 / IRPEnv.step irp.py:49-99 for host-driven callers
+ * (RandomAgent, user code).  actions (B) int64.  Writes reward_f64 (B) = -distance,
+ * *notdone += number of graphs whose visited row is not all ones (evaluated before
+ * the fix-ups, tsp.py:95); the caller zeroes *notdone first; done <=> *notdone == 0.
+ * Writes mask buffer `parity_out`. */
+int vrp_env_step(const vrp_env *env, const int64_t *actions, int parity_out,
+                 double *reward_f64, int32_t *notdone, void *stream);
+
+/* E3  TSPEnv.get_state tsp.py:106-129 / IRPEnv.get_state irp.py:101-124 as fp32
+ * network inputs: x (B,N,3) = [x, y, demand-or-0], is_depot (B,N) u8. */
+int vrp_env_features(const vrp_env *env, float *x, uint8_t *is_depot, void *stream);
+
+/* ---- policy weights (views of the torch parameters; same names as state_dict) -- */
+typedef struct vrp_encoder_layer {
+  const float *in_proj_weight, *in_proj_bias;    /* (384,128) (384) */
+  const float *out_proj_weight, *out_proj_bias;  /* (128,128) (128) */
+  const float *bn1_weight, *bn1_bias;
+  float *bn1_running_mean, *bn1_running_var;
+  int64_t *bn1_num_batches_tracked;
+  const float *ff0_weight, *ff0_bias;            /* (512,128) (512) */
+  const float *ff2_weight, *ff2_bias;            /* (128,512) (128) */
+  const float *bn2_weight, *bn2_bias;
+  float *bn2_running_mean, *bn2_running_var;
+  int64_t *bn2_num_batches_tracked;
+} vrp_encoder_layer;
+
+typedef struct vrp_encoder_weights {
+  int32_t node_dim, depot_dim, hidden, num_layers;     /* 2|3, 2|0, 512, <=8 */
+  const float *node_embed_weight, *node_embed_bias;    /* (128,node_dim) */
+  const float *depot_embed_weight, *depot_embed_bias;  /* (128,2) or NULL */
+  vrp_encoder_layer layer[8];
+} vrp_encoder_weights;
+
+typedef struct vrp_decoder_weights {
+  const float *first_node, *last_node;            /* (128) placeholders       */
+  const float *q_proj_weight;                     /* (384,384)                */
+  const float *k_proj_weight, *v_proj_weight;     /* (384,128)                */
+  const float *in_proj_bias;                      /* (1152) = bq|bk|bv        */
+  const float *out_proj_weight, *out_proj_bias;   /* (384,384) (384)          */
+  const float *kp_weight;                         /* (128,128)                */
+  const float *att_output_weight;                 /* (128,384)                */
+  const float *context_proj_weight;               /* (384,257) IRP only       */
+} vrp_decoder_weights;
+
+/* Scratch sizes (bytes) the caller must provide; pure functions of the shape. */
+int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden);
+int64_t vrp_decoder_workspace_bytes(int kind, int B, int N);
+int64_t vrp_decoder_derived_bytes(void);
+
+/* N1-N3  GraphEncoder.forward agents/graph_encoder.py:41-58, GraphDemandEncoder
+ * .forward :95-138, MultiHeadAttentionLayer.forward :183-198, BatchNorm :141-154.
+ * x (B,N,3) fp32 [x,y,demand], depot_mask (B,N) u8 or NULL (TSP), emb (B,N,128).
+ * train != 0: batch statistics + running-stat update (momentum 0.1). */
+int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int B, int N,
+                        const float *x, const uint8_t *depot_mask, float *emb,
+                        void *workspace, void *stream);
+
+/* D1  Folds the decoder parameters into the matrices the step kernel consumes
+ * (agents/graph_decoder.py:29-44 parameters; algebra in DESIGN.md).  Must be
+ * re-run whenever the parameters change. */
+int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
+                        void *stream);
+
+/* Per-episode decoder state + outputs. */
+typedef struct vrp_rollout_io {
+  float *acc_loss;        /* (B) fp32 sum of -distance, step order  graph_tsp_agent.py:85 */
+  float *acc_logp;        /* (B) fp32 sum of log-prob               graph_tsp_agent.py:86 */
+  int32_t *notdone;       /* (max_steps+1) per-step count of unfinished graphs;          */
+                          /*   notdone[t]==0 <=> env.step t returned done (tsp.py:95)    */
+  int64_t *actions;       /* (max_steps,B) chosen nodes, or NULL                         */
+  const int64_t *forced;  /* (max_steps,B) teacher-forced actions, or NULL               */
+  const float *noise;     /* (max_steps,B,N) Exp(1) noise for sampling, or NULL=greedy   */
+  float *logits;          /* (max_steps,B,N) masked logits u, or NULL (debug/tests)      */
+  float *step_logp;       /* (max_steps,B) per-step log-prob, or NULL                    */
+} vrp_rollout_io;
+
+/* D2  Per-episode constants of GraphDecoder.forward (agents/graph_decoder.py:75-83):
+ * graph embedding, hoisted K projection and the per-node glimpse score tables. */
+int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
+                        void *workspace, void *stream);
+
+/* D2-D6 + E4-E8 fused: one GraphDecoder.forward call (agents/graph_decoder.py:51-115)
+ * followed by env.step on its actions (tsp.py:60-101 / irp.py:49-99), i.e. one
+ * iteration of the loop in TSPModel.forward agents/graph_tsp_agent.py:78-88.
+ * `t` is the step index; the kernel is a no-op once notdone[t-1]==0.
+ * flags: VRP_STEP_SAMPLE = sample with io->noise instead of argmax;
+ *        VRP_STEP_DECODE_ONLY = GraphDecoder.forward alone: no env.step, no
+ *        accumulation (only env->{B,N,mask,load} are read; results go to
+ *        io->actions / io->step_logp / io->logits). */
+#define VRP_STEP_SAMPLE 1
+#define VRP_STEP_DECODE_ONLY 2
+int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
+                    const vrp_env *env, const float *emb, void *workspace,
+                    const vrp_rollout_io *io, int t, int max_steps, int flags,
+                    void *stream);
+
+/* R1  TSPModel/VRPModel/IRPModel.forward (agents/graph_tsp_agent.py:61-92,
+ * graph_vrp_agent.py:52-83, graph_irp_agent.py:54-105): mask init, features,
+ * encoder, prologue and max_steps decode+env steps, all on `stream`.
+ * emb (B,N,128) receives the node embeddings.  max_steps >= 2(N-1) (N-1 for TSP). */
+int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
+                void *derived, const vrp_env *env, int train, int sample,
+                float *emb, void *enc_workspace, void *dec_workspace,
+                const vrp_rollout_io *io, int max_steps, void *stream);
+
+/* Only the T-step decode+env loop of vrp_rollout (emb and prologue already done). */
+int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,
+                      const vrp_env *env, const float *emb, void *dec_workspace,
+                      const vrp_rollout_io *io, int max_steps, int flags, void *stream);
+
+/* Building blocks exported for tests and profiling. */
+int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
+                const float *residual, int ldr, float *C, int ldc, int M, int N, int K,
+                int relu, void *stream);
+
+const char *vrp_last_error(void);
+int vrp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRPGYM_HIP_H */

@@ -1,0 +1,155 @@
+"""CPU-only tests of the product's host side: instance RNG order, weight containers,
+C-ABI exports, sharding and the gradient bucket (gloo, world_size 2)."""
+import glob
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_instances_match_reference_rng_order():
+    from gym_vrp.graph.instances import draw_instances
+    for f in sorted(glob.glob(os.path.join(G, "instances_*.npz"))):
+        z = np.load(f)
+        B, N = int(z["B"]), int(z["N"])
+        np.random.seed(int(z["seed"]))
+        idx = np.random.choice(B, int(z["num_draw"]), replace=False)
+        assert np.array_equal(idx, z["draw_idxs"])
+        for r in range(3):
+            pos, dep, dem = draw_instances(B, N, 1)
+            assert np.array_equal(pos, z[f"pos{r}"])
+            assert np.array_equal(dep, z[f"depots{r}"])
+            assert np.array_equal(dem, z[f"demands{r}"])
+
+
+def test_shard_bounds_partition():
+    from gym_vrp.graph.instances import shard_bounds
+    spans = [shard_bounds(8192, r, 8) for r in range(8)]
+    assert spans[0] == (0, 1024) and spans[-1] == (7168, 8192)
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    with pytest.raises(AssertionError):
+        shard_bounds(10, 0, 3)
+
+
+def test_agent_weight_init_matches_reference():
+    """Same construction order => same initial weights as the reference for a seed
+    (hashes taken from the reference, tests/golden/weights.npz)."""
+    import agents
+    z = np.load(os.path.join(G, "weights.npz"))
+    for kind, cls in enumerate((agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)):
+        a = cls(seed=69)
+        sd = a.model.state_dict()
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+        assert h.hexdigest()[:16] == str(z[f"sha_k{kind}"])
+        assert list(sd.keys()) == list(z[f"keys_k{kind}"])
+        assert [str(tuple(v.shape)) for v in sd.values()] == list(z[f"shapes_k{kind}"])
+        assert sum(p.numel() for p in a.model.parameters()) == int(z[f"nparam_k{kind}"])
+        assert not a.target_model.training and a.model.training
+        for (k1, v1), (k2, v2) in zip(sd.items(), a.target_model.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads and exports every function include/vrpgym_hip.h
+    declares (no compute call: there is no GPU here)."""
+    import vrpgym_hip
+    lib = vrpgym_hip.lib()
+    header = open(os.path.join(ROOT, "include", "vrpgym_hip.h")).read()
+    names = set(re.findall(r"\b(vrp_[a-z_0-9]+)\s*\(", header))
+    assert len(names) >= 15
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert lib.vrp_abi_version() == 1
+    assert lib.vrp_decoder_derived_bytes() > 0
+    assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
+    assert lib.vrp_decoder_workspace_bytes(0, 512, 20) > 2 * 512 * 20 * 8 * 20 * 4
+    # the structs mirrored in Python have the C sizes
+    import ctypes
+    assert ctypes.sizeof(vrpgym_hip.Env) == 16 + 7 * 8
+    assert ctypes.sizeof(vrpgym_hip.DecoderWeights) == 11 * 8
+    assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 8 * 8
+    assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 16 + 4 * 8 + 8 * 18 * 8
+
+
+def test_product_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gym_vrp.envs import TSPEnv
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TSPEnv(num_nodes=5, batch_size=2, num_draw=1)
+    import agents
+    a = agents.TSPAgent()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        a.model.encoder(torch.zeros(2, 5, 2))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vrp-gym_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(sys.argv[1], "vrp-gym_amd"))
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2],
+                        rank=int(sys.argv[3]), world_size=2)
+import agents
+from agents import distributed as D
+rank = dist.get_rank()
+a = agents.TSPAgent(seed=69)
+torch.manual_seed(100 + rank)
+for n, p in a.model.named_parameters():
+    if "_context_proj" in n:      # never receives a gradient for TSP (SURVEY 8e)
+        continue
+    p.grad = torch.randn_like(p)
+params = D.grad_parameters(a.model)
+assert sum(p.numel() for p in params) == 1154432 - 98688
+mine = D.flatten_grads(params).clone()
+D.allreduce_gradients(a.model)
+got = D.flatten_grads(params)
+other = [torch.empty_like(mine) for _ in range(2)]
+dist.all_gather(other, mine)
+want = (other[0] + other[1]) / 2
+assert torch.allclose(got, want, atol=1e-6), (got - want).abs().max()
+c, b = D.gather_costs(torch.full((4,), float(rank)), torch.full((4,), 10.0 + rank))
+assert c.tolist() == [0.0] * 4 + [1.0] * 4 and b.tolist() == [10.0] * 4 + [11.0] * 4
+if rank == 1:
+    with torch.no_grad():
+        for p in a.model.parameters():
+            p.add_(1.0)
+D.broadcast_model(a.model)
+chk = torch.stack([p.detach().sum() for p in a.model.parameters()]).sum()
+both = [torch.empty_like(chk) for _ in range(2)]
+dist.all_gather(both, chk)
+assert torch.equal(both[0], both[1])
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"ok {r}" in o

@@ -1,0 +1,333 @@
+"""Host-side plumbing between the torch parameter containers and libvrpgym_hip.so.
+
+Nothing in here computes: it builds the pointer structs of include/vrpgym_hip.h
+from the modules' parameters, owns the device scratch buffers, draws the sampling
+noise and launches the library on torch's current stream.  There is no CPU path.
+"""
+import ctypes as C
+import weakref
+
+import torch
+
+import vrpgym_hip as hip
+
+EMB, HEADS = 128, 8
+
+_struct_cache = weakref.WeakKeyDictionary()  # module -> (struct, keepalive tensors)
+_derived_cache = weakref.WeakKeyDictionary()  # decoder -> (version key, device buffer)
+_buffers = {}         # (tag, device) -> scratch tensor
+
+
+def check_supported_dims(emb_dim, num_heads, hidden_dim, decoder=False):
+    """The kernels are specialised for the reference's architecture (emb 128, 8 heads,
+    hidden a multiple of 128).  Other sizes can be constructed (state_dict
+    compatibility) but not run."""
+    return emb_dim == EMB and num_heads == HEADS and (hidden_dim is None or hidden_dim % 128 == 0)
+
+
+def invalidate(module):
+    _struct_cache.pop(module, None)
+    _derived_cache.pop(module, None)
+
+
+def _dev(module):
+    return next(module.parameters()).device
+
+
+def _require_cuda(module):
+    dev = _dev(module)
+    if dev.type != "cuda":
+        raise RuntimeError(
+            "this model lives on %s: the MI355X-native path has no CPU fallback "
+            "(move the model to the GPU; a GPU-less run cannot execute it)" % dev)
+    hip.require_gpu()
+    return dev
+
+
+def _buf(tag, device, nbytes):
+    key = (tag, str(device))
+    t = _buffers.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _buffers[key] = t
+    return t
+
+
+# ------------------------------------------------------------------ weight structs
+def encoder_struct(enc):
+    hit = _struct_cache.get(enc)
+    if hit is not None:
+        return hit[0]
+    node_dim, emb, hidden, heads = enc._dims
+    if not check_supported_dims(emb, heads, hidden):
+        raise NotImplementedError(
+            f"HIP encoder is built for emb_dim=128, num_heads=8, hidden%128==0 "
+            f"(got {emb}, {heads}, {hidden})")
+    w = hip.EncoderWeights()
+    w.node_dim, w.hidden, w.num_layers = node_dim, hidden, len(enc.attention_layers)
+    if w.num_layers > 8:
+        raise NotImplementedError("at most 8 attention layers")
+    keep = []
+
+    def P(t):
+        assert t.dtype in (torch.float32, torch.int64) and t.is_contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    w.node_embed_weight, w.node_embed_bias = P(enc.node_embed.weight), P(enc.node_embed.bias)
+    dep = getattr(enc, "depot_embed", None)
+    if dep is not None:
+        w.depot_dim = dep.weight.shape[1]
+        w.depot_embed_weight, w.depot_embed_bias = P(dep.weight), P(dep.bias)
+    for i, layer in enumerate(enc.attention_layers):
+        L, att = w.layer[i], layer.attention_layer
+        L.in_proj_weight, L.in_proj_bias = P(att.in_proj_weight), P(att.in_proj_bias)
+        L.out_proj_weight, L.out_proj_bias = P(att.out_proj.weight), P(att.out_proj.bias)
+        for tag, bn in (("bn1", layer.bn1.norm), ("bn2", layer.bn2.norm)):
+            setattr(L, tag + "_weight", P(bn.weight))
+            setattr(L, tag + "_bias", P(bn.bias))
+            setattr(L, tag + "_running_mean", P(bn.running_mean))
+            setattr(L, tag + "_running_var", P(bn.running_var))
+            setattr(L, tag + "_num_batches_tracked", P(bn.num_batches_tracked))
+        L.ff0_weight, L.ff0_bias = P(layer.ff[0].weight), P(layer.ff[0].bias)
+        L.ff2_weight, L.ff2_bias = P(layer.ff[2].weight), P(layer.ff[2].bias)
+    _struct_cache[enc] = (w, keep)
+    return w
+
+
+def decoder_struct(dec):
+    hit = _struct_cache.get(dec)
+    if hit is not None:
+        return hit[0]
+    att = dec.attention
+    if att.embed_dim != 3 * EMB or att.num_heads != HEADS:
+        raise NotImplementedError("HIP decoder is built for emb_dim=128 and 8 heads")
+    w = hip.DecoderWeights()
+    keep = []
+
+    def P(t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    w.first_node, w.last_node = P(dec._first_node), P(dec._last_node)
+    w.q_proj_weight, w.k_proj_weight = P(att.q_proj_weight), P(att.k_proj_weight)
+    w.v_proj_weight, w.in_proj_bias = P(att.v_proj_weight), P(att.in_proj_bias)
+    w.out_proj_weight, w.out_proj_bias = P(att.out_proj.weight), P(att.out_proj.bias)
+    w.kp_weight, w.att_output_weight = P(dec._kp.weight), P(dec._att_output.weight)
+    w.context_proj_weight = P(dec._context_proj.weight)
+    _struct_cache[dec] = (w, keep)
+    return w
+
+
+def _decoder_version(dec):
+    return tuple(p._version for p in dec.parameters())
+
+
+def decoder_derived(dec, kind):
+    """Folded decoder matrices on the device; refreshed when a parameter changed
+    (optimizer step, load_state_dict) or the env kind differs."""
+    dev = _require_cuda(dec)
+    lib = hip.lib()
+    state = _derived_cache.get(dec)
+    ver = (kind, _decoder_version(dec), str(dev), dec.attention.q_proj_weight.data_ptr())
+    if state is None or state[0] != ver:
+        buf = torch.empty(int(lib.vrp_decoder_derived_bytes()), dtype=torch.uint8, device=dev)
+        w = decoder_struct(dec)
+        hip.check(lib.vrp_decoder_prepare(kind, C.byref(w), buf.data_ptr(),
+                                          hip.current_stream(dev)))
+        state = (ver, buf)
+        _derived_cache[dec] = state
+    return state[1]
+
+
+# ------------------------------------------------------------------ stand-alone encoder
+def encoder_forward(enc, x, depot_mask, train):
+    """GraphEncoder/GraphDemandEncoder.forward on arbitrary input tensors."""
+    dev = _require_cuda(enc)
+    lib = hip.lib()
+    w = encoder_struct(enc)
+    x = x.detach().to(device=dev, dtype=torch.float32)
+    B, N, F = x.shape
+    x3 = torch.zeros((B, N, 3), dtype=torch.float32, device=dev)
+    x3[:, :, :min(F, 3)] = x[:, :, :3]
+    dm = None
+    if depot_mask is not None:
+        dm = depot_mask.detach().to(device=dev).to(torch.uint8).contiguous()
+    emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
+    ws = _buf("enc", dev, lib.vrp_encoder_workspace_bytes(B, N, w.hidden))
+    hip.check(lib.vrp_encoder_forward(C.byref(w), int(bool(train)), B, N, x3.data_ptr(),
+                                      hip.ptr(dm), emb.data_ptr(), ws.data_ptr(),
+                                      hip.current_stream(dev)))
+    return emb
+
+
+# ------------------------------------------------------------------ stand-alone decoder
+class _Episode:
+    def __init__(self):
+        self.t = 0
+
+
+def decoder_step(dec, node_embs, mask, load, greedy):
+    """GraphDecoder.forward as ONE decode-only kernel launch (no env)."""
+    dev = _require_cuda(dec)
+    lib = hip.lib()
+    kind = hip.KIND_IRP if load is not None else hip.KIND_TSP
+    derived = decoder_derived(dec, kind)
+    emb = node_embs.detach().to(device=dev, dtype=torch.float32).contiguous()
+    B, N, _ = emb.shape
+    ep = dec._episode
+    stream = hip.current_stream(dev)
+    if ep is None:
+        ep = _Episode()
+        ep.emb = emb
+        ep.ws = torch.empty(int(lib.vrp_decoder_workspace_bytes(kind, B, N)), dtype=torch.uint8,
+                            device=dev)
+        ep.mask = torch.zeros((2, B, N), dtype=torch.uint8, device=dev)
+        ep.load = torch.ones((B,), dtype=torch.float64, device=dev)
+        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, emb.data_ptr(),
+                                          ep.ws.data_ptr(), stream))
+        dec._episode = ep
+    if mask is None:
+        mask = torch.zeros((B, N))
+    ep.mask[ep.t & 1].copy_(mask.detach().to(dev).ne(0).to(torch.uint8))
+    if load is not None:
+        ep.load.copy_(load.detach().to(dev).to(torch.float64).reshape(B))
+    e = hip.Env()
+    e.kind, e.B, e.N = kind, B, N
+    e.mask, e.load = ep.mask.data_ptr(), ep.load.data_ptr()
+    actions = torch.empty((1, B), dtype=torch.int64, device=dev)
+    logp = torch.zeros((1, B), dtype=torch.float32, device=dev)
+    io = hip.RolloutIO()
+    flags = 2  # VRP_STEP_DECODE_ONLY
+    noise = None
+    if not greedy:
+        noise = torch.empty((B, N)).exponential_(1).to(dev)  # default CPU generator, like
+        flags |= 1                                           # Categorical.sample on CPU
+    # io arrays are indexed by t inside the kernel: offset the base pointers instead
+    t = ep.t
+    io.actions = actions.data_ptr() - t * B * 8
+    io.step_logp = logp.data_ptr() - t * B * 4
+    if noise is not None:
+        io.noise = noise.data_ptr() - t * B * N * 4
+    w = decoder_struct(dec)
+    hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(w), C.byref(e),
+                                  ep.emb.data_ptr(), ep.ws.data_ptr(), C.byref(io), t, t + 1,
+                                  flags, stream))
+    ep.t += 1
+    lp = torch.zeros(B) if greedy else logp.reshape(B, 1)
+    return actions.reshape(B, 1), lp
+
+
+# ------------------------------------------------------------------ full rollouts
+class RolloutResult:
+    """Device tensors of one episode.  `T` (number of env steps until the batch-wide
+    `done`, tsp.py:95) is read back lazily because it needs a stream sync."""
+
+    def __init__(self, acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps):
+        self.acc_loss, self.acc_logp, self.notdone = acc_loss, acc_logp, notdone
+        self.actions, self.logits, self.step_logp, self.emb = actions, logits, step_logp, emb
+        self.max_steps = max_steps
+        self._T = None
+
+    @property
+    def T(self):
+        if self._T is None:
+            nd = self.notdone[: self.max_steps].cpu()
+            zero = (nd == 0).nonzero()
+            self._T = int(zero[0].item()) + 1 if len(zero) else self.max_steps
+        return self._T
+
+
+def max_steps_for(kind, N):
+    """TSP ends after exactly N-1 steps; VRP/IRP after at most 2(N-1)."""
+    return N - 1 if kind == hip.KIND_TSP else 2 * (N - 1)
+
+
+def host_noise(max_steps, B, N):
+    """Parity-mode sampling noise: the reference's Categorical.sample draws
+    `empty(B,N).exponential_(1)` from the default CPU generator once per step."""
+    return torch.stack([torch.empty((B, N)).exponential_(1) for _ in range(max_steps)])
+
+
+def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
+            noise_mode="device"):
+    """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU."""
+    dev = _require_cuda(model)
+    lib = hip.lib()
+    kind = env.KIND
+    if str(env._device) != str(dev):
+        raise RuntimeError(f"env is on {env._device} but the model on {dev}")
+    B, N = env.batch_size, env.num_nodes
+    enc, dec = model.encoder, model.decoder
+    ew, dw = encoder_struct(enc), decoder_struct(dec)
+    derived = decoder_derived(dec, kind)
+    max_steps = max_steps_for(kind, N)
+    stream = hip.current_stream(dev)
+
+    enc_ws = _buf("enc", dev, lib.vrp_encoder_workspace_bytes(B, N, ew.hidden))
+    dec_ws = _buf("dec", dev, lib.vrp_decoder_workspace_bytes(kind, B, N))
+    emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
+    acc_loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    acc_logp = torch.empty((B,), dtype=torch.float32, device=dev)
+    notdone = torch.empty((max_steps + 1,), dtype=torch.int32, device=dev)
+    io = hip.RolloutIO()
+    io.acc_loss, io.acc_logp, io.notdone = acc_loss.data_ptr(), acc_logp.data_ptr(), notdone.data_ptr()
+    actions = logits = step_logp = None
+    if trace or forced is not None:
+        actions = torch.zeros((max_steps, B), dtype=torch.int64, device=dev)
+        io.actions = actions.data_ptr()
+    if trace:
+        logits = torch.zeros((max_steps, B, N), dtype=torch.float32, device=dev)
+        step_logp = torch.zeros((max_steps, B), dtype=torch.float32, device=dev)
+        io.logits, io.step_logp = logits.data_ptr(), step_logp.data_ptr()
+    keep = []
+    if forced is not None:
+        f = torch.zeros((max_steps, B), dtype=torch.int64)
+        ft = torch.as_tensor(forced, dtype=torch.int64)
+        f[: ft.shape[0]] = ft
+        f[ft.shape[0]:] = ft[-1] if ft.shape[0] else 0
+        f = f.to(dev)
+        keep.append(f)
+        io.forced = f.data_ptr()
+    gen_state = None
+    if not greedy:
+        if noise is None:
+            if noise_mode == "host":
+                gen_state = torch.get_rng_state()
+                noise = host_noise(max_steps, B, N)
+            else:
+                noise = torch.empty((max_steps, B, N), dtype=torch.float32,
+                                    device=dev).exponential_(1)
+        noise = torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous()
+        if noise.shape[0] < max_steps:
+            pad = torch.ones((max_steps - noise.shape[0], B, N), device=dev)
+            noise = torch.cat([noise, pad]).contiguous()
+        keep.append(noise)
+        io.noise = noise.data_ptr()
+
+    env._sync_positions()
+    env._parity = 0
+    cenv = env._cenv()
+    hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), derived.data_ptr(), C.byref(cenv),
+                              int(bool(train)), int(not greedy), emb.data_ptr(),
+                              enc_ws.data_ptr(), dec_ws.data_ptr(), C.byref(io), max_steps,
+                              stream))
+    env._mask_fresh = False  # final mask sits in buffer T&1; recompute lazily into buffer 0
+    res = RolloutResult(acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps)
+    res._keep = keep
+    if gen_state is not None:
+        # leave the CPU generator where the reference would: it draws only T steps
+        T = res.T
+        torch.set_rng_state(gen_state)
+        host_noise(T, B, N)
+    env._last_rollout = res  # env.step_count adds its T lazily
+    return res
+
+
+def attach_grad(model, env, res):
+    """Differentiable log-probability of the sampled tour (REINFORCE needs
+    d sum_t log p(a_t) / d theta).  The hand-written backward (K4 in SURVEY.md 7.1)
+    lives in agents/backward.py."""
+    from . import backward
+    return backward.logp_with_grad(model, env, res)

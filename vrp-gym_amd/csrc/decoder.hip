@@ -1,0 +1,615 @@
+// Pointer-attention decoder (D1-D6 of SURVEY.md 8a) fused with the environment
+// step (E4-E8): one launch = one iteration of the rollout loop
+// agents/graph_tsp_agent.py:78-88, i.e. GraphDecoder.forward
+// (agents/graph_decoder.py:51-115) followed by env.step (gym_vrp/envs/tsp.py:60-101).
+//
+// Algebra (all exact up to fp32 re-association):
+//   * glimpse query q = Wq*ctx + bq is linear in [graph_emb, first_, last_(, load)],
+//     the keys K_n = Wk*e_n + bk are per-episode constants, so the glimpse score
+//     q_h.K_{h,n}/sqrt(48) splits into per-episode tables
+//        SG[b][h][n]        graph-embedding + bias part
+//        SF[b][m][h][n]     "first node = m" part      (TSP/VRP)
+//        SL[b][m][h][n]     "last node  = m" part
+//        SLD[b][h][n]       load coefficient           (IRP)
+//        C0[b][h][n]        step-0 placeholders _first_node/_last_node
+//     built once per episode (vrp_decode_prologue); a step only gathers rows.
+//   * sum_n a_n (Wv e_n + bv) = Wv (sum_n a_n e_n) + bv, and _kp/_att_output/out_proj
+//     fold into one 128x384 matrix M, so a step reads only the RAW (N,128)
+//     embedding tile, once, and keeps it in registers for both the glimpse
+//     (z = A*E) and the pointer logits (u = E*w).
+//   * QUIRK D3 reproduced: the float 0/1 mask is ADDED to the glimpse scores and
+//     head h of graph b reads mask row (8b+h) mod B (graph_decoder.py:93-94).
+#include "env_device.h"
+
+int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
+                       const float *R, int ldr, float *C, int ldc, int M, int N, int K,
+                       int relu, hipStream_t stream);
+
+// ------------------------------------------------------------------ derived weights
+struct Derived {
+  float *Wproj;  // (1152,128) = [Wq_first | Wq_last | Wk]  (IRP: [Wq_last' | Wk], 768 rows)
+  float *bproj;  // (1152)       0 | 0 | bk
+  float *Wqg;    // (384,128)  graph-embedding block of the query projection
+  float *bq;     // (384)
+  float *qc0;    // (384)      query contribution of the step-0 placeholders
+  float *wload;  // (384)      query coefficient of the vehicle load (IRP)
+  float *WvT;    // (128,384)  v_proj_weight transposed
+  float *bv;     // (384)
+  float *MT;     // (384,128)  transpose of M = Wkp^T Watt Wo / sqrt(128)
+  float *mb;     // (128)      Wkp^T Watt bo / sqrt(128)
+  float *tmpA;   // (128,384)  Watt Wo
+  float *tmpv;   // (128)      Watt bo
+};
+
+static Derived carve_derived(void *base) {
+  float *p = (float *)base;
+  Derived d;
+  d.Wproj = p; p += 1152 * 128;
+  d.bproj = p; p += 1152;
+  d.Wqg = p;   p += 384 * 128;
+  d.bq = p;    p += 384;
+  d.qc0 = p;   p += 384;
+  d.wload = p; p += 384;
+  d.WvT = p;   p += 128 * 384;
+  d.bv = p;    p += 384;
+  d.MT = p;    p += 384 * 128;
+  d.mb = p;    p += 128;
+  d.tmpA = p;  p += 128 * 384;
+  d.tmpv = p;  p += 128;
+  return d;
+}
+
+extern "C" int64_t vrp_decoder_derived_bytes(void) {
+  return (int64_t)sizeof(float) *
+         (1152 * 128 + 1152 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
+          128 * 384 + 128);
+}
+
+// C[i*scr + j*scc] = alpha * sum_k A[i*sar + k*sac] * Bm[k*sbr + j*sbc] + beta*C.
+// Tiny one-off weight folds only (<= 19 M MAC); one thread per output element.
+__global__ void mm_strided_kernel(float *C, int scr, int scc, const float *A, int sar, int sac,
+                                  const float *Bm, int sbr, int sbc, int M, int N, int K,
+                                  float alpha, float beta) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * N) return;
+  const int i = idx / N, j = idx - i * N;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k)
+    acc = fmaf(A[(size_t)i * sar + (size_t)k * sac], Bm[(size_t)k * sbr + (size_t)j * sbc], acc);
+  float *c = C + (size_t)i * scr + (size_t)j * scc;
+  *c = alpha * acc + (beta != 0.f ? beta * *c : 0.f);
+}
+
+// dst[r*sdr + c*sdc] = src ? src[r*ssr + c*ssc] : 0
+__global__ void copy2d_kernel(float *dst, int sdr, int sdc, const float *src, int ssr, int ssc,
+                              int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx - r * cols;
+  dst[(size_t)r * sdr + (size_t)c * sdc] = src ? src[(size_t)r * ssr + (size_t)c * ssc] : 0.f;
+}
+
+static int mm(hipStream_t st, float *C, int scr, int scc, const float *A, int sar, int sac,
+              const float *Bm, int sbr, int sbc, int M, int N, int K, float alpha, float beta) {
+  hipLaunchKernelGGL(mm_strided_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, C, scr, scc,
+                     A, sar, sac, Bm, sbr, sbc, M, N, K, alpha, beta);
+  VRP_CHECK_LAUNCH("mm_strided");
+  return 0;
+}
+static int cp(hipStream_t st, float *dst, int sdr, int sdc, const float *src, int ssr, int ssc,
+              int rows, int cols) {
+  hipLaunchKernelGGL(copy2d_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, st, dst, sdr,
+                     sdc, src, ssr, ssc, rows, cols);
+  VRP_CHECK_LAUNCH("copy2d");
+  return 0;
+}
+
+extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
+                                   void *stream) {
+  VRP_REQUIRE(w && derived, "decoder_prepare: NULL argument");
+  VRP_REQUIRE(kind >= 0 && kind <= 2, "decoder_prepare: kind=%d", kind);
+  VRP_REQUIRE(kind != VRP_KIND_IRP || w->context_proj_weight, "IRP needs _context_proj");
+  hipStream_t st = (hipStream_t)stream;
+  Derived d = carve_derived(derived);
+  const float *Wq = w->q_proj_weight, *bias = w->in_proj_bias;
+  int r = 0;
+  if (kind != VRP_KIND_IRP) {
+    // ctx = [graph_emb | first_ | last_]   graph_decoder.py:88
+    r |= cp(st, d.Wproj, 128, 1, Wq + 128, 384, 1, 384, 128);
+    r |= cp(st, d.Wproj + 384 * 128, 128, 1, Wq + 256, 384, 1, 384, 128);
+    r |= cp(st, d.Wproj + 768 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
+    r |= cp(st, d.Wqg, 128, 1, Wq, 384, 1, 384, 128);
+    r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 768);
+    r |= cp(st, d.bproj + 768, 0, 1, bias + 384, 0, 1, 1, 384);
+    // qc0 = Wq_first * _first_node + Wq_last * _last_node   graph_decoder.py:79-81
+    r |= mm(st, d.qc0, 1, 0, Wq + 128, 384, 1, w->first_node, 1, 0, 384, 1, 128, 1.f, 0.f);
+    r |= mm(st, d.qc0, 1, 0, Wq + 256, 384, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 1.f);
+    r |= cp(st, d.wload, 0, 1, nullptr, 0, 0, 1, 384);
+  } else {
+    // ctx = _context_proj([graph_emb | last_ | load])   graph_decoder.py:90-91
+    const float *Wc = w->context_proj_weight;  // (384,257)
+    r |= mm(st, d.Wqg, 128, 1, Wq, 384, 1, Wc, 257, 1, 384, 128, 384, 1.f, 0.f);
+    r |= mm(st, d.Wproj, 128, 1, Wq, 384, 1, Wc + 128, 257, 1, 384, 128, 384, 1.f, 0.f);
+    r |= cp(st, d.Wproj + 384 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
+    r |= mm(st, d.wload, 1, 0, Wq, 384, 1, Wc + 256, 257, 0, 384, 1, 384, 1.f, 0.f);
+    r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 384);
+    r |= cp(st, d.bproj + 384, 0, 1, bias + 384, 0, 1, 1, 384);
+    r |= mm(st, d.qc0, 1, 0, d.Wproj, 128, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 0.f);
+  }
+  r |= cp(st, d.bq, 0, 1, bias, 0, 1, 1, 384);
+  r |= cp(st, d.bv, 0, 1, bias + 768, 0, 1, 1, 384);
+  r |= cp(st, d.WvT, 1, 384, w->v_proj_weight, 128, 1, 384, 128);  // WvT[k][j] = Wv[j][k]
+  const float s = 0.08838834764831845f;  // 1/sqrt(128)   graph_decoder.py:97
+  // tmpA = Watt (128,384) * Wo (384,384);  M = s * Wkp^T tmpA;  MT[j][i] = M[i][j]
+  r |= mm(st, d.tmpA, 384, 1, w->att_output_weight, 384, 1, w->out_proj_weight, 384, 1, 128, 384,
+          384, 1.f, 0.f);
+  r |= mm(st, d.MT, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s, 0.f);
+  // tmpv = Watt * bo;  mb = s * Wkp^T tmpv
+  r |= mm(st, d.tmpv, 1, 0, w->att_output_weight, 384, 1, w->out_proj_bias, 1, 0, 128, 1, 384, 1.f,
+          0.f);
+  r |= mm(st, d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s, 0.f);
+  return r ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ per-episode workspace
+struct DecWs {
+  float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
+  float *QG;     // (B,384)     Wq_g g + bq
+  float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
+  float *SG, *C0, *SLD, *base1;  // (B,8,N) each
+  float *SF, *SL;                // (B,N,8,N) each
+  int32_t *last, *first;         // (B)
+};
+
+static int proj_width(int kind) { return kind == VRP_KIND_IRP ? 768 : 1152; }
+
+static DecWs carve_decws(int kind, void *ws, int B, int N) {
+  char *p = (char *)ws;
+  DecWs w;
+  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
+  w.g = (float *)p;     p += vrp_align_up((size_t)B * 128 * 4);
+  w.QG = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
+  w.PROJ = (float *)p;  p += vrp_align_up(R * proj_width(kind) * 4);
+  w.SG = (float *)p;    p += vrp_align_up(hn);
+  w.C0 = (float *)p;    p += vrp_align_up(hn);
+  w.SLD = (float *)p;   p += vrp_align_up(hn);
+  w.base1 = (float *)p; p += vrp_align_up(hn);
+  w.SF = (float *)p;    p += vrp_align_up(tb);
+  w.SL = (float *)p;    p += vrp_align_up(tb);
+  w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
+  w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
+  return w;
+}
+
+extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
+  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
+  return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
+                   vrp_align_up(R * proj_width(kind) * 4) + 4 * vrp_align_up(hn) +
+                   2 * vrp_align_up(tb) + 2 * vrp_align_up((size_t)B * 4));
+}
+
+// graph embedding = mean over nodes (sum, then divide)   graph_decoder.py:75-77
+__global__ __launch_bounds__(128) void graph_mean_kernel(const float *__restrict__ emb, int N,
+                                                         float *__restrict__ g) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float *e = emb + (size_t)b * N * VRP_EMB + c;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += e[(size_t)n * VRP_EMB];
+  g[(size_t)b * VRP_EMB + c] = s / (float)N;
+}
+
+// Glimpse score tables.  One wave per (graph, head); lane = key node n (two per lane when
+// N > 64), which keeps its projected key K_{h,n} (48 floats) in registers; the query rows
+// are wave-uniform and arrive through the scalar path.
+template <int NPL>
+__global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int P,
+                                                           const float *__restrict__ PROJ,
+                                                           const float *__restrict__ QG,
+                                                           const float *__restrict__ qc0,
+                                                           const float *__restrict__ wload,
+                                                           float *__restrict__ SG,
+                                                           float *__restrict__ C0,
+                                                           float *__restrict__ SLD,
+                                                           float *__restrict__ SF,
+                                                           float *__restrict__ SL) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  const int koff = (kind == VRP_KIND_IRP ? 384 : 768) + h * VRP_HD;
+  const int qloff = (kind == VRP_KIND_IRP ? 0 : 384) + h * VRP_HD;
+  const int qfoff = h * VRP_HD;
+  const float c = 0.14433756729740643f;  // 1/sqrt(48)
+  float kk[NPL][VRP_HD];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int n = lane + 64 * i;
+    const float *kp = PROJ + ((size_t)b * N + (n < N ? n : 0)) * P + koff;
+#pragma unroll
+    for (int d = 0; d < VRP_HD; d += 4) {
+      float4 t = *reinterpret_cast<const float4 *>(kp + d);
+      kk[i][d] = t.x; kk[i][d + 1] = t.y; kk[i][d + 2] = t.z; kk[i][d + 3] = t.w;
+    }
+  }
+  auto dot = [&](const float *q, int i) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < VRP_HD; ++d) s = fmaf(q[d], kk[i][d], s);
+    return s * c;
+  };
+  const size_t hn = ((size_t)b * 8 + h) * N;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int n = lane + 64 * i;
+    if (n < N) {
+      SG[hn + n] = dot(QG + (size_t)b * VRP_D + h * VRP_HD, i);
+      C0[hn + n] = dot(qc0 + h * VRP_HD, i);
+      SLD[hn + n] = dot(wload + h * VRP_HD, i);
+    }
+  }
+  for (int m = 0; m < N; ++m) {
+    const float *row = PROJ + ((size_t)b * N + m) * P;
+    const size_t o = (((size_t)b * N + m) * 8 + h) * N;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      if (n < N) {
+        SL[o + n] = dot(row + qloff, i);
+        if (kind != VRP_KIND_IRP) SF[o + n] = dot(row + qfoff, i);
+      }
+    }
+  }
+}
+
+extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
+                                   void *workspace, void *stream) {
+  VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
+  VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "decode_prologue: bad shape B=%d N=%d", B, N);
+  hipStream_t st = (hipStream_t)stream;
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs w = carve_decws(kind, workspace, B, N);
+  const int P = proj_width(kind);
+  hipLaunchKernelGGL(graph_mean_kernel, dim3(B), dim3(128), 0, st, emb, N, w.g);
+  VRP_CHECK_LAUNCH("graph_mean");
+  if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
+                                 st)) return r;
+  if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
+                                 128, 0, st)) return r;
+  if (N <= 64)
+    hipLaunchKernelGGL(score_tables_kernel<1>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL);
+  else
+    hipLaunchKernelGGL(score_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL);
+  VRP_CHECK_LAUNCH("score_tables");
+  return 0;
+}
+
+// ------------------------------------------------------------------ the step kernel
+struct StepParams {
+  int kind, B, N, t, max_steps, sample, decode_only;
+  const float *emb;
+  const float *SG, *C0, *SLD, *SF, *SL;
+  float *base1;
+  int32_t *last, *first;
+  const float *WvT, *bv, *MT, *mb;
+  vrp_env env;
+  vrp_rollout_io io;
+};
+
+#define GPW 4  // graphs per workgroup (one wave each)
+
+template <int NMAX>
+__global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
+  constexpr int NPL = (NMAX + 63) / 64;
+  // Batch-wide done (tsp.py:95,103-104): once the previous step reported every graph
+  // finished, the remaining launches of a fixed-length loop are exact no-ops.
+  if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *a_s = smem;                    // [GPW][NMAX*8]  glimpse attention weights
+  float *zs = a_s + GPW * NMAX * 8;     // [GPW][8*128]   z_h = sum_n a_{h,n} e_n
+  float *os = zs + GPW * 1024;          // [GPW][384]     o = Wv z + bv
+  float *wp = os + GPW * 384;           // [2][GPW][128]  partial sums of M o
+  float *wq = wp + 2 * GPW * 128;       // [GPW][128]     w = M o + mb
+  float *tr = wq + GPW * 128;           // [GPW][NMAX*65] logit partials, transposed
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N, B = p.B;
+  const int braw = blockIdx.x * GPW + wave;
+  const bool active = braw < B;
+  const int b = active ? braw : B - 1;
+  const int par = p.t & 1;
+  const uint8_t *mask_in = p.env.mask + (size_t)par * B * N;
+  uint8_t *mask_out = p.env.mask + (size_t)(par ^ 1) * B * N;
+
+  // ---- phase 1: embedding tile -> registers (the only pass over it) -----------------
+  float2 e[NMAX];
+  {
+    const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      e[n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+  }
+
+  // glimpse scores = table rows + additive scrambled mask, softmax over nodes
+  {
+    const float loadf = (p.kind == VRP_KIND_IRP) ? (float)p.env.load[b] : 0.f;
+    const int last = (p.t > 0) ? p.last[b] : 0;
+    const float *basep = (p.t == 0 ? p.SG : p.base1) + (size_t)b * 8 * N;
+    const float *c0p = p.C0 + (size_t)b * 8 * N;
+    const float *slp = p.SL + ((size_t)b * N + last) * 8 * N;
+    const float *sldp = p.SLD + (size_t)b * 8 * N;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const uint8_t *mrow = mask_in + (size_t)((b * 8 + h) % B) * N;  // QUIRK D3
+      float s[NPL];
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        s[i] = -INFINITY;
+        if (n < N) {
+          float v = basep[h * N + n];
+          v += (p.t == 0) ? c0p[h * N + n] : slp[h * N + n];
+          if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sldp[h * N + n], v);
+          s[i] = v + (float)mrow[n];
+        }
+        m = fmaxf(m, s[i]);
+      }
+      m = wave_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        s[i] = (lane + 64 * i < N) ? expf(s[i] - m) : 0.f;
+        sum += s[i];
+      }
+      sum = wave_sum(sum);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (n < NMAX) a_s[(wave * NMAX + n) * 8 + h] = s[i] / sum;
+      }
+    }
+  }
+  __syncthreads();
+
+  // z_h[2l..2l+1] = sum_n a[h][n] * e[n][2l..2l+1]
+  {
+    float2 z[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
+    const float4 *ap = reinterpret_cast<const float4 *>(a_s + wave * NMAX * 8);
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) {
+      const float4 a0 = ap[2 * n], a1 = ap[2 * n + 1];
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        z[h].x = fmaf(av[h], e[n].x, z[h].x);
+        z[h].y = fmaf(av[h], e[n].y, z[h].y);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h)
+      *reinterpret_cast<float2 *>(zs + wave * 1024 + h * 128 + 2 * lane) = z[h];
+  }
+  __syncthreads();
+
+  // ---- phase 2: o = Wv z + bv  (per head),  w = M o + mb   (shared by the 4 graphs) --
+  for (int j = tid; j < VRP_D; j += 256) {
+    const int h = j / VRP_HD;
+    float acc[GPW];
+    const float bvj = p.bv[j];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) acc[g] = bvj;
+    for (int k = 0; k < 128; k += 4) {
+      const float w0 = p.WvT[(size_t)(k + 0) * VRP_D + j], w1 = p.WvT[(size_t)(k + 1) * VRP_D + j];
+      const float w2 = p.WvT[(size_t)(k + 2) * VRP_D + j], w3 = p.WvT[(size_t)(k + 3) * VRP_D + j];
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        const float4 x = *reinterpret_cast<const float4 *>(zs + g * 1024 + h * 128 + k);
+        acc[g] = fmaf(w0, x.x, acc[g]);
+        acc[g] = fmaf(w1, x.y, acc[g]);
+        acc[g] = fmaf(w2, x.z, acc[g]);
+        acc[g] = fmaf(w3, x.w, acc[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) os[g * VRP_D + j] = acc[g];
+  }
+  __syncthreads();
+  {
+    const int c = tid & 127, half = tid >> 7;
+    float acc[GPW];
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) acc[g] = 0.f;
+    for (int k = half * 192; k < half * 192 + 192; k += 4) {
+      const float w0 = p.MT[(size_t)(k + 0) * 128 + c], w1 = p.MT[(size_t)(k + 1) * 128 + c];
+      const float w2 = p.MT[(size_t)(k + 2) * 128 + c], w3 = p.MT[(size_t)(k + 3) * 128 + c];
+#pragma unroll
+      for (int g = 0; g < GPW; ++g) {
+        const float4 x = *reinterpret_cast<const float4 *>(os + g * VRP_D + k);
+        acc[g] = fmaf(w0, x.x, acc[g]);
+        acc[g] = fmaf(w1, x.y, acc[g]);
+        acc[g] = fmaf(w2, x.z, acc[g]);
+        acc[g] = fmaf(w3, x.w, acc[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) wp[(half * GPW + g) * 128 + c] = acc[g];
+  }
+  __syncthreads();
+  for (int i = tid; i < GPW * 128; i += 256) wq[i] = wp[i] + wp[GPW * 128 + i] + p.mb[i & 127];
+  __syncthreads();
+
+  // ---- phase 3: pointer logits u_n = 10 tanh(w . e_n), own mask -> -inf ---------------
+  {
+    const float2 wv = *reinterpret_cast<const float2 *>(wq + wave * 128 + 2 * lane);
+    float *trw = tr + wave * NMAX * 65;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) trw[n * 65 + lane] = fmaf(wv.x, e[n].x, wv.y * e[n].y);
+  }
+  __syncthreads();
+  float u[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int n = lane + 64 * i;
+    u[i] = -INFINITY;
+    if (n < N) {
+      const float *row = tr + wave * NMAX * 65 + n * 65;
+      float x = 0.f;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) x += row[j];
+      u[i] = mask_in[(size_t)b * N + n] ? -INFINITY : 10.f * tanhf(x);  // graph_decoder.py:97-98
+    }
+  }
+  if (active && p.io.logits) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+      if (lane + 64 * i < N) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
+  }
+
+  // ---- action: greedy argmax (lowest index on ties) or argmax(softmax(u)/q) -----------
+  int idx;
+  float logp = 0.f;  // greedy rollouts report log_prob = 0   graph_decoder.py:100-103
+  if (!p.sample) {
+    float bv_ = u[0];
+    int bi = lane;
+#pragma unroll
+    for (int i = 1; i < NPL; ++i)
+      if (u[i] > bv_) { bv_ = u[i]; bi = lane + 64 * i; }
+    wave_argmax(bv_, bi);
+    idx = bi;
+    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
+  } else {
+    // Categorical(logits=u): logits - logsumexp, probs = softmax, sample = argmax(p/q)
+    float m = u[0];
+#pragma unroll
+    for (int i = 1; i < NPL; ++i) m = fmaxf(m, u[i]);
+    m = wave_max(m);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) se += expf(u[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    float l[NPL], lm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { l[i] = u[i] - lse; lm = fmaxf(lm, l[i]); }
+    lm = wave_max(lm);
+    float pe[NPL], ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { pe[i] = expf(l[i] - lm); ps += pe[i]; }
+    ps = wave_sum(ps);
+    float best = -1.f;
+    int bi = lane;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      if (n < N) {
+        const float q = p.io.noise[((size_t)p.t * B + b) * N + n];
+        const float r = (pe[i] / ps) / q;
+        if (r > best) { best = r; bi = n; }
+      }
+    }
+    wave_argmax(best, bi);
+    idx = bi;
+    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
+    const float lsel = (idx >= 64) ? l[NPL - 1] : l[0];
+    logp = __shfl(lsel, idx & 63, 64);
+  }
+
+  if (!active) return;  // wave-uniform; no barriers below
+
+  if (p.decode_only) {  // GraphDecoder.forward alone (graph_decoder.py:108-113 state update)
+    if (p.t == 0 && p.kind != VRP_KIND_IRP) {
+      const float *sf = p.SF + ((size_t)b * N + idx) * 8 * N;
+      const float *sg = p.SG + (size_t)b * 8 * N;
+      float *b1 = p.base1 + (size_t)b * 8 * N;
+      for (int i = lane; i < 8 * N; i += 64) b1[i] = sg[i] + sf[i];
+    }
+    if (lane == 0) {
+      p.last[b] = idx;
+      if (p.t == 0) p.first[b] = idx;
+      if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
+      if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
+    }
+    return;
+  }
+
+  // ---- environment step on the chosen node + episode accumulators ---------------------
+  EnvStepOut eo = env_step_wave(p.env, b, idx, lane, mask_out);
+  if (p.t == 0 && p.kind != VRP_KIND_IRP) {
+    // first_ := embedding of the first chosen node (graph_decoder.py:111-113):
+    // base1 = SG + SF[first]
+    const float *sf = p.SF + ((size_t)b * N + idx) * 8 * N;
+    const float *sg = p.SG + (size_t)b * 8 * N;
+    float *b1 = p.base1 + (size_t)b * 8 * N;
+    for (int i = lane; i < 8 * N; i += 64) b1[i] = sg[i] + sf[i];
+  }
+  if (lane == 0) {
+    p.io.acc_loss[b] += (float)(-eo.dist);  // fp32 accumulate in step order, tsp_agent:85
+    p.io.acc_logp[b] += logp;
+    p.last[b] = idx;
+    if (p.t == 0) p.first[b] = idx;
+    if (!eo.done) atomicAdd(&p.io.notdone[p.t], 1);
+    if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
+    if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
+  }
+}
+
+template <int NMAX>
+static size_t step_lds_bytes() {
+  return sizeof(float) * (GPW * NMAX * 8 + GPW * 1024 + GPW * 384 + 2 * GPW * 128 + GPW * 128 +
+                          GPW * NMAX * 65);
+}
+
+template <int NMAX>
+static int launch_step(const StepParams &p, hipStream_t st) {
+  const size_t lds = step_lds_bytes<NMAX>();
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_kernel<NMAX>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("decode_step: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(decode_step_kernel<NMAX>, dim3((p.B + GPW - 1) / GPW), dim3(256), lds, st, p);
+  VRP_CHECK_LAUNCH("decode_step");
+  return 0;
+}
+
+extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
+                               const vrp_env *env, const float *emb, void *workspace,
+                               const vrp_rollout_io *io, int t, int max_steps, int flags,
+                               void *stream) {
+  (void)w;
+  const int sample = flags & VRP_STEP_SAMPLE, decode_only = (flags & VRP_STEP_DECODE_ONLY) ? 1 : 0;
+  VRP_REQUIRE(derived && env && emb && workspace && io, "decode_step: NULL argument");
+  VRP_REQUIRE(env->kind == kind, "decode_step: env.kind=%d but kind=%d", env->kind, kind);
+  VRP_REQUIRE(decode_only || (io->acc_loss && io->acc_logp && io->notdone),
+              "decode_step: io accumulators NULL");
+  VRP_REQUIRE(env->mask && (kind != VRP_KIND_IRP || env->load), "decode_step: env.mask/load NULL");
+  VRP_REQUIRE(!sample || io->noise, "decode_step: sampling needs io.noise");
+  VRP_REQUIRE(t >= 0 && t < max_steps, "decode_step: t=%d outside [0,%d)", t, max_steps);
+  const int B = env->B, N = env->N;
+  VRP_REQUIRE(N >= 2 && N <= 104, "decode_step: N=%d unsupported (2..104)", N);
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs ws = carve_decws(kind, workspace, B, N);
+  StepParams p;
+  p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps; p.sample = sample;
+  p.decode_only = decode_only;
+  p.emb = emb;
+  p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SF = ws.SF; p.SL = ws.SL;
+  p.base1 = (kind == VRP_KIND_IRP) ? ws.SG : ws.base1;
+  p.last = ws.last; p.first = ws.first;
+  p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
+  p.env = *env;
+  p.io = *io;
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 24) return launch_step<24>(p, st);
+  if (N <= 40) return launch_step<40>(p, st);
+  if (N <= 64) return launch_step<64>(p, st);
+  return launch_step<104>(p, st);
+}

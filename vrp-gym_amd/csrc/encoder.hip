@@ -1,0 +1,245 @@
+// Graph encoder forward (N1-N3 of SURVEY.md 8a): node/depot embedding followed by
+// L x [MHA(128, 8 heads) + residual + BatchNorm, FF(128->hidden->128) + residual +
+// BatchNorm].  agents/graph_encoder.py:41-58, 95-138, 141-154, 183-198.
+// Dense projections run on the matrix cores (gemm.hip); the per-graph N x N
+// attention, the batch statistics and the normalisation are small HBM-bound kernels.
+#include "common.h"
+
+int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
+                       const float *R, int ldr, float *C, int ldc, int M, int N, int K,
+                       int relu, hipStream_t stream);
+
+// ---- embedding: node_embed / depot_embed select (graph_encoder.py:54, 110-132) -----
+__global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x,
+                                                    const uint8_t *__restrict__ depot_mask,
+                                                    const float *__restrict__ Wn,
+                                                    const float *__restrict__ bn, int node_dim,
+                                                    const float *__restrict__ Wd,
+                                                    const float *__restrict__ bd, int depot_dim,
+                                                    float *__restrict__ out, int rows) {
+  const int c = threadIdx.x & 127;
+  int r = blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (r >= rows) return;
+  const float *xr = x + (size_t)r * 3;
+  float v;
+  if (depot_mask && depot_mask[r]) {
+    v = bd[c];
+    for (int d = 0; d < depot_dim; ++d) v = fmaf(xr[d], Wd[c * depot_dim + d], v);
+  } else {
+    v = bn[c];
+    for (int d = 0; d < node_dim; ++d) v = fmaf(xr[d], Wn[c * node_dim + d], v);
+  }
+  out[(size_t)r * VRP_EMB + c] = v;
+}
+
+// ---- per-graph multi-head self-attention on the projected QKV --------------------
+// One wave per (graph, head); lane = query node (two per lane when N > 64).  K_h and
+// V_h (N x 16 each) sit in LDS and are read as broadcasts.  Two passes over the keys
+// (max, then exp/sum) like torch's softmax.  graph_encoder.py:170-172,196.
+__global__ __launch_bounds__(256) void encoder_attention_kernel(const float *__restrict__ qkv,
+                                                                float *__restrict__ out, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  float *Ks = smem + (size_t)wave * N * 32;
+  float *Vs = Ks + N * 16;
+  const float *base = qkv + (size_t)b * N * 384;
+  for (int idx = lane; idx < N * 4; idx += 64) {
+    const int j = idx >> 2, q4 = (idx & 3) * 4;
+    *reinterpret_cast<float4 *>(Ks + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * 16 + q4);
+    *reinterpret_cast<float4 *>(Vs + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * 16 + q4);
+  }
+  __syncthreads();
+  for (int i = lane; i < N; i += 64) {
+    float q[16];
+#pragma unroll
+    for (int d = 0; d < 16; d += 4) {
+      float4 t = *reinterpret_cast<const float4 *>(base + (size_t)i * 384 + h * 16 + d);
+      q[d] = t.x * 0.25f; q[d + 1] = t.y * 0.25f; q[d + 2] = t.z * 0.25f; q[d + 3] = t.w * 0.25f;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      m = fmaxf(m, s);
+    }
+    float l = 0.f, o[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      const float p = expf(s - m);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) o[d] = fmaf(p, Vs[j * 16 + d], o[d]);
+    }
+    const float inv = 1.f / l;
+    float *dst = out + ((size_t)b * N + i) * VRP_EMB + h * 16;
+#pragma unroll
+    for (int d = 0; d < 16; d += 4)
+      *reinterpret_cast<float4 *>(dst + d) =
+          make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+  }
+}
+
+// ---- BatchNorm1d(128) over the flattened (B*N,128) view (graph_encoder.py:141-154) ---
+// stats: fp64 column sums of x and x^2 (two 128-vectors), zeroed by the caller.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, int rows,
+                                                       double *__restrict__ stats) {
+  __shared__ double sh[2][256];
+  const int c = threadIdx.x & 127, par = threadIdx.x >> 7;
+  double s = 0.0, ss = 0.0;
+  for (int r = blockIdx.x * 2 + par; r < rows; r += gridDim.x * 2) {
+    const double v = (double)x[(size_t)r * VRP_EMB + c];
+    s += v;
+    ss += v * v;
+  }
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (par == 0) {
+    atomicAdd(&stats[c], sh[0][c] + sh[0][c + 128]);
+    atomicAdd(&stats[128 + c], sh[1][c] + sh[1][c + 128]);
+  }
+}
+
+// norm[0:128] = mean, norm[128:256] = weight / sqrt(var + eps), norm[256:384] = bias
+__global__ void bn_finalize_kernel(const double *__restrict__ stats, int rows, int train,
+                                   const float *__restrict__ weight,
+                                   const float *__restrict__ bias, float *running_mean,
+                                   float *running_var, int64_t *num_batches_tracked,
+                                   float *__restrict__ norm) {
+  const int c = threadIdx.x;
+  float mean, var;
+  if (train) {
+    const double m = stats[c] / rows;
+    double v = stats[128 + c] / rows - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    const float unbiased = (float)(v * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
+    running_var[c] = 0.9f * running_var[c] + 0.1f * unbiased;
+    if (c == 0) *num_batches_tracked += 1;
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  norm[c] = mean;
+  norm[128 + c] = weight[c] / sqrtf(var + 1e-5f);
+  norm[256 + c] = bias[c];
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(float *__restrict__ x, size_t n4,
+                                                       const float *__restrict__ norm) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int c = (int)(i & 31) * 4;
+  float4 v = reinterpret_cast<float4 *>(x)[i];
+  v.x = (v.x - norm[c]) * norm[128 + c] + norm[256 + c];
+  v.y = (v.y - norm[c + 1]) * norm[129 + c] + norm[257 + c];
+  v.z = (v.z - norm[c + 2]) * norm[130 + c] + norm[258 + c];
+  v.w = (v.w - norm[c + 3]) * norm[131 + c] + norm[259 + c];
+  reinterpret_cast<float4 *>(x)[i] = v;
+}
+
+struct EncWs {
+  float *h0, *h1, *qkv, *att, *ff, *norm;
+  double *stats;
+};
+
+static EncWs carve_encoder(void *ws, int B, int N, int hidden) {
+  const size_t R = (size_t)B * N;
+  char *p = (char *)ws;
+  EncWs w;
+  w.h0 = (float *)p;   p += vrp_align_up(R * 128 * 4);
+  w.h1 = (float *)p;   p += vrp_align_up(R * 128 * 4);
+  w.qkv = (float *)p;  p += vrp_align_up(R * 384 * 4);
+  w.att = (float *)p;  p += vrp_align_up(R * 128 * 4);
+  w.ff = (float *)p;   p += vrp_align_up(R * (size_t)hidden * 4);
+  w.norm = (float *)p; p += vrp_align_up(384 * 4);
+  w.stats = (double *)p;
+  return w;
+}
+
+extern "C" int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden) {
+  const size_t R = (size_t)B * N;
+  // + feature scratch used by vrp_rollout: x (R,3) fp32 and is_depot (R) u8
+  return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
+                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(384 * 4) +
+                   vrp_align_up(256 * 8) + vrp_align_up(R * 12) + vrp_align_up(R));
+}
+
+static int batchnorm(float *x, int rows, int train, const float *w, const float *b, float *rm,
+                     float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
+  if (train) {
+    if (hipMemsetAsync(ws.stats, 0, 256 * sizeof(double), st) != hipSuccess) {
+      vrp_set_error("bn: memset failed");
+      return 1;
+    }
+    int blocks = (rows + 1) / 2;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);
+    VRP_CHECK_LAUNCH("bn_stats");
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, ws.stats, rows, train, w, b,
+                     rm, rv, nbt, ws.norm);
+  VRP_CHECK_LAUNCH("bn_finalize");
+  const size_t n4 = (size_t)rows * 32;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, n4,
+                     ws.norm);
+  VRP_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int B, int N,
+                                   const float *x, const uint8_t *depot_mask, float *emb,
+                                   void *workspace, void *stream) {
+  VRP_REQUIRE(w && x && emb && workspace, "encoder: NULL argument");
+  VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8, "encoder: num_layers=%d", w->num_layers);
+  VRP_REQUIRE(w->hidden % 128 == 0, "encoder: hidden=%d must be a multiple of 128", w->hidden);
+  VRP_REQUIRE(w->node_dim >= 1 && w->node_dim <= 3, "encoder: node_dim=%d", w->node_dim);
+  VRP_REQUIRE(!depot_mask || w->depot_embed_weight, "encoder: depot mask without depot_embed");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = B * N;
+  EncWs ws = carve_encoder(workspace, B, N, w->hidden);
+  float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;  // so that the last layer lands in emb
+  float *nxt = nullptr;
+  hipLaunchKernelGGL(embed_kernel, dim3((R + 1) / 2), dim3(256), 0, st, x, depot_mask,
+                     w->node_embed_weight, w->node_embed_bias, w->node_dim,
+                     w->depot_embed_weight, w->depot_embed_bias, w->depot_dim, cur, R);
+  VRP_CHECK_LAUNCH("embed");
+  for (int l = 0; l < w->num_layers; ++l) {
+    const vrp_encoder_layer &L = w->layer[l];
+    // out = bn1(x + MHA(x))
+    if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
+                                   ws.qkv, 384, R, 384, 128, 0, st)) return r;
+    const size_t lds = (size_t)4 * N * 32 * sizeof(float);
+    hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
+    VRP_CHECK_LAUNCH("encoder_attention");
+    if (int r = vrp_launch_gemm_nt(ws.att, 128, L.out_proj_weight, 128, L.out_proj_bias, cur, 128,
+                                   ws.h1, 128, R, 128, 128, 0, st)) return r;
+    if (int r = batchnorm(ws.h1, R, train, L.bn1_weight, L.bn1_bias, L.bn1_running_mean,
+                          L.bn1_running_var, L.bn1_num_batches_tracked, ws, st)) return r;
+    // out = bn2(out + FF(out))
+    if (int r = vrp_launch_gemm_nt(ws.h1, 128, L.ff0_weight, 128, L.ff0_bias, nullptr, 0, ws.ff,
+                                   w->hidden, R, w->hidden, 128, 1, st)) return r;
+    nxt = (cur == emb) ? ws.h0 : emb;
+    if (int r = vrp_launch_gemm_nt(ws.ff, w->hidden, L.ff2_weight, w->hidden, L.ff2_bias, ws.h1,
+                                   128, nxt, 128, R, 128, w->hidden, 0, st)) return r;
+    if (int r = batchnorm(nxt, R, train, L.bn2_weight, L.bn2_bias, L.bn2_running_mean,
+                          L.bn2_running_var, L.bn2_num_batches_tracked, ws, st)) return r;
+    cur = nxt;
+  }
+  if (cur != emb) {  // defensive: cannot happen with the parity choice above
+    vrp_set_error("encoder: internal buffer parity error");
+    return 3;
+  }
+  return 0;
+}

@@ -1,0 +1,241 @@
+"""TSPEnv — device-resident batched environment (reference: gym_vrp/envs/tsp.py).
+
+Public surface identical to the reference (constructor, step/reset/get_state/
+generate_mask/is_done/render/enable_video_capturing, attributes visited, depots,
+current_location, sampler, step_count, num_nodes, batch_size, draw_idxs).  State
+lives in contiguous device tensors; `step` is one launch of the fused HIP kernel
+`vrp_env_step` (include/vrpgym_hip.h).  Host numpy views are materialised lazily
+for foreign callers (RandomAgent, tests); the agents of this package never leave
+the device (agents/runtime.py).
+"""
+import copy
+from typing import Tuple, Union
+
+import numpy as np
+
+from ..graph.instances import draw_instances, shard_bounds
+from ..graph.vrp_network import VRPNetwork
+from .common import GymEnv, ObsType
+
+
+class TSPEnv(GymEnv):
+    metadata = {"render.modes": ["human", "rgb_array"]}
+    KIND = 0  # VRP_KIND_TSP
+    _PLOT_DEMAND = False
+
+    def __init__(self, num_nodes: int = 20, batch_size: int = 128, num_draw: int = 6,
+                 seed: int = 69, device=None, shard=None):
+        """Same arguments as the reference (tsp.py:27-58).  Extra, optional:
+        device — torch device of the state (default: current CUDA device);
+        shard  — (rank, world_size): keep only this rank's slice of the
+                 seed-ordered instance stream."""
+        assert (
+            num_draw <= batch_size
+        ), "Num_draw needs to be equal or lower than the number of generated graphs."
+        import torch
+        from vrpgym_hip import require_gpu
+        self._lib = require_gpu()  # loud failure without GPU / library: no CPU fallback
+        self._torch = torch
+        self._device = torch.device(device) if device is not None else torch.device(
+            "cuda", torch.cuda.current_device())
+        np.random.seed(seed)  # tsp.py:48
+        self._step_count = 0
+        self._last_rollout = None
+        self.num_nodes = num_nodes
+        self._global_batch = batch_size
+        self._shard = shard
+        if shard is not None:
+            lo, hi = shard_bounds(batch_size, *shard)
+            self._slice = slice(lo, hi)
+            self.batch_size = hi - lo
+        else:
+            self._slice = slice(0, batch_size)
+            self.batch_size = batch_size
+        self.draw_idxs = np.random.choice(batch_size, num_draw, replace=False)  # tsp.py:55
+        if shard is not None:
+            self.draw_idxs = self.draw_idxs[self.draw_idxs < self.batch_size]
+        self.video_save_path = None
+        self._alloc()
+        self.generate_graphs()
+
+    # ------------------------------------------------------------------ device state
+    def _alloc(self):
+        t, B, N, dev = self._torch, self.batch_size, self.num_nodes, self._device
+        self._pos = t.empty((B, N, 2), dtype=t.float64, device=dev)
+        self._demand = t.zeros((B, N), dtype=t.float64, device=dev)
+        self._depot = t.empty((B,), dtype=t.int32, device=dev)
+        self._visited = t.zeros((B, N), dtype=t.uint8, device=dev)
+        self._mask = t.zeros((2, B, N), dtype=t.uint8, device=dev)
+        self._cur = t.empty((B,), dtype=t.int32, device=dev)
+        self._load = t.ones((B,), dtype=t.float64, device=dev)
+        self._reward = t.empty((B,), dtype=t.float64, device=dev)
+        self._notdone = t.zeros((1,), dtype=t.int32, device=dev)
+        self._actions = t.empty((B,), dtype=t.int64, device=dev)
+        self._parity = 0        # mask buffer holding the current state's mask column
+        self._mask_fresh = False  # fix-ups of generate_mask applied since the last change?
+
+    def _cenv(self):
+        from vrpgym_hip import Env
+        e = Env()
+        e.kind, e.B, e.N = self.KIND, self.batch_size, self.num_nodes
+        e.pos, e.demand, e.depot = self._pos.data_ptr(), self._demand.data_ptr(), self._depot.data_ptr()
+        e.visited, e.mask = self._visited.data_ptr(), self._mask.data_ptr()
+        e.cur, e.load = self._cur.data_ptr(), self._load.data_ptr()
+        return e
+
+    def _stream(self):
+        return self._torch.cuda.current_stream(self._device).cuda_stream
+
+    def _upload_instances(self):
+        t, s = self._torch, self._slice
+        net = self.sampler
+        self._pos.copy_(t.from_numpy(np.ascontiguousarray(net._pos)))
+        self._demand.copy_(t.from_numpy(np.ascontiguousarray(net._demands[:, :, 0])))
+        self._depot.copy_(t.from_numpy(net._depots[:, 0].astype(np.int32)))
+        self._pos_dirty = False
+
+    def _sync_positions(self):
+        """Callers may rewrite coordinates through sampler.graphs[i] (the reference reads
+        them lazily every step, tests/test_env.py:31-36); push them before the next use."""
+        if self.sampler._dirty:
+            self._pos.copy_(self._torch.from_numpy(np.ascontiguousarray(self.sampler._pos)))
+            self.sampler._dirty = False
+
+    # ------------------------------------------------------------------ E1
+    def generate_graphs(self):
+        """tsp.py:162-174: new instances from the global numpy stream, visited := 0,
+        current_location := depots."""
+        pos, depots, demands = draw_instances(self._global_batch, self.num_nodes, 1)
+        s = self._slice
+        self.sampler = VRPNetwork(self.batch_size, self.num_nodes, 1,
+                                  plot_demand=self._PLOT_DEMAND,
+                                  _arrays=(pos[s], depots[s], demands[s]))
+        self.depots = self.sampler.get_depots()
+        self._upload_instances()
+        self._visited.zero_()
+        self._mask.zero_()
+        self._cur.copy_(self._depot)
+        self._load.fill_(1.0)
+        self._parity = 0
+        self._mask_fresh = False
+
+    def reset(self) -> Union[ObsType, Tuple[ObsType, dict]]:
+        """tsp.py:150-160 (no reseed)."""
+        self.step_count = 0
+        self.generate_graphs()
+        return self.get_state()
+
+    @property
+    def step_count(self):
+        """Steps taken since the last reset (device rollouts report theirs lazily)."""
+        extra = self._last_rollout.T if self._last_rollout is not None else 0
+        return self._step_count + extra
+
+    @step_count.setter
+    def step_count(self, value):
+        self._step_count = value
+        self._last_rollout = None
+
+    # ------------------------------------------------------------------ E4-E6
+    def step(self, actions: np.ndarray) -> Tuple[ObsType, float, bool, dict]:
+        """tsp.py:60-101.  `actions` (B,1) host integers (or a device int64 tensor)."""
+        assert (
+            actions.shape[0] == self.batch_size
+        ), "Number of actions need to equal the number of generated graphs."
+        from vrpgym_hip import check
+        t = self._torch
+        self._sync_positions()
+        self._step_count += 1
+        if isinstance(actions, t.Tensor):
+            self._actions.copy_(actions.reshape(-1))
+        else:
+            self._actions.copy_(t.from_numpy(np.ascontiguousarray(
+                np.asarray(actions).reshape(-1).astype(np.int64))))
+        if self.sampler._graphs is not None:  # rendering flags only (vrp_network.py:143-152)
+            edges = np.hstack([self.current_location, np.asarray(actions).reshape(-1, 1)])
+            self.sampler.visit_edges(edges.astype(int))
+        self._notdone.zero_()
+        e = self._cenv()
+        check(self._lib.vrp_env_step(e, self._actions.data_ptr(), self._parity ^ 1,
+                                     self._reward.data_ptr(), self._notdone.data_ptr(),
+                                     self._stream()))
+        self._parity ^= 1
+        self._mask_fresh = True  # vrp_env_step applies generate_mask's fix-ups itself
+        if self.video_save_path is not None:
+            self.vid.capture_frame()
+        done = int(self._notdone.item()) == 0
+        return self.get_state(), self._reward.cpu().numpy(), done, None
+
+    def is_done(self):
+        """tsp.py:103-104."""
+        return bool((self._visited == 1).all().item())
+
+    # ------------------------------------------------------------------ E7
+    def _apply_mask(self):
+        if not self._mask_fresh:
+            from vrpgym_hip import check
+            self._sync_positions()
+            check(self._lib.vrp_env_mask(self._cenv(), self._parity, self._stream()))
+            self._mask_fresh = True
+
+    def generate_mask(self):
+        """tsp.py:131-148: applies the depot fix-ups to `visited` (device side) and
+        returns the mask as a host float64 array like the reference."""
+        self._apply_mask()
+        return self._mask[self._parity].cpu().numpy().astype(np.float64)
+
+    # ------------------------------------------------------------------ E3
+    def get_state(self) -> np.ndarray:
+        """tsp.py:106-129: (B,N,4) float64 = [x, y, is_depot, mask]."""
+        mask = self.generate_mask()
+        is_depot = np.zeros((self.batch_size, self.num_nodes))
+        is_depot[np.arange(self.batch_size), self.depots[:, 0]] = 1
+        return np.dstack([self.sampler.get_graph_positions(), is_depot, mask])
+
+    # ------------------------------------------------------------------ host views
+    @property
+    def visited(self):
+        return self._visited.cpu().numpy().astype(np.float64)
+
+    @visited.setter
+    def visited(self, value):
+        self._visited.copy_(self._torch.from_numpy(np.asarray(value).astype(np.uint8)))
+        self._mask_fresh = False
+
+    @property
+    def current_location(self):
+        return self._cur.cpu().numpy().astype(np.int64).reshape(-1, 1)
+
+    @current_location.setter
+    def current_location(self, value):
+        self._cur.copy_(self._torch.from_numpy(np.asarray(value).reshape(-1).astype(np.int32)))
+        self._mask_fresh = False
+
+    # ------------------------------------------------------------------ misc
+    def __deepcopy__(self, memo):
+        """agents copy the env for the baseline rollout (graph_tsp_agent.py:248)."""
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        t = self._torch
+        for k, v in self.__dict__.items():
+            if isinstance(v, t.Tensor):
+                new.__dict__[k] = v.clone()
+            elif k in ("_lib", "_torch", "vid", "_last_rollout"):
+                new.__dict__[k] = v
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def render(self, mode: str = "human"):
+        return self.sampler.draw(self.draw_idxs)
+
+    def enable_video_capturing(self, video_save_path: str):
+        self.video_save_path = video_save_path
+        if self.video_save_path is not None:
+            try:
+                from gym.wrappers.monitoring.video_recorder import VideoRecorder
+            except Exception as exc:  # gym is an optional dependency
+                raise RuntimeError("video capturing needs the `gym` package") from exc
+            self.sampler.graphs  # materialise the per-graph views so edges get recorded
+            self.vid = VideoRecorder(self, self.video_save_path)
+            self.vid.frames_per_sec = 1

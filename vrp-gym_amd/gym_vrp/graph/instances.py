@@ -1,0 +1,39 @@
+"""Host-side instance sampling in the reference's RNG order.
+
+The reference draws every instance from numpy's *global legacy* stream, one graph
+at a time: `rand(N,2)` -> `choice(N, num_depots, replace=False)` ->
+`uniform(1,10,(N,1)) / (0.2449*N + 26.12)` with the depots' demand forced to 0
+(gym_vrp/graph/vrp_graph.py:28-43, called B times by
+gym_vrp/graph/vrp_network.py:41-42).  The three calls are kept verbatim so that a
+seed reproduces the reference's instances bit for bit; only the networkx graph
+objects around them are gone (the arrays go straight to device tensors).
+"""
+import numpy as np
+
+
+def demand_scale(num_nodes):
+    """vrp_graph.py:41 — linear fit of the capacities used by Kool et al."""
+    return 0.2449 * num_nodes + 26.12
+
+
+def draw_instances(num_graphs, num_nodes, num_depots=1):
+    """Returns pos (B,N,2) f64, depots (B,num_depots) i64, demands (B,N,1) f64."""
+    assert num_nodes >= num_depots, "Number of depots should be lower than number of depots"
+    pos = np.empty((num_graphs, num_nodes, 2), dtype=np.float64)
+    depots = np.empty((num_graphs, num_depots), dtype=np.int64)
+    demands = np.empty((num_graphs, num_nodes, 1), dtype=np.float64)
+    scale = demand_scale(num_nodes)
+    rand, choice, uniform = np.random.rand, np.random.choice, np.random.uniform
+    for g in range(num_graphs):
+        pos[g] = rand(num_nodes, 2)
+        depots[g] = choice(num_nodes, size=num_depots, replace=False)
+        demands[g] = uniform(low=1, high=10, size=(num_nodes, 1)) / scale
+        demands[g, depots[g]] = 0
+    return pos, depots, demands
+
+
+def shard_bounds(num_graphs, rank, world_size):
+    """Rank r owns instances [r*B/R, (r+1)*B/R) of the seed-ordered set."""
+    assert num_graphs % world_size == 0, "batch must divide evenly over ranks"
+    per = num_graphs // world_size
+    return rank * per, (rank + 1) * per

@@ -1,0 +1,129 @@
+"""Loader + struct mirrors for include/vrpgym_hip.h."""
+import ctypes as C
+import os
+
+KIND_TSP, KIND_VRP, KIND_IRP = 0, 1, 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_f32p = C.c_void_p
+c_vp = C.c_void_p
+
+
+class Env(C.Structure):
+    """struct vrp_env"""
+    _fields_ = [("kind", C.c_int32), ("B", C.c_int32), ("N", C.c_int32), ("reserved", C.c_int32),
+                ("pos", c_vp), ("demand", c_vp), ("depot", c_vp), ("visited", c_vp),
+                ("mask", c_vp), ("cur", c_vp), ("load", c_vp)]
+
+
+class EncoderLayer(C.Structure):
+    """struct vrp_encoder_layer"""
+    _fields_ = [(n, c_vp) for n in (
+        "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
+        "bn1_weight", "bn1_bias", "bn1_running_mean", "bn1_running_var",
+        "bn1_num_batches_tracked",
+        "ff0_weight", "ff0_bias", "ff2_weight", "ff2_bias",
+        "bn2_weight", "bn2_bias", "bn2_running_mean", "bn2_running_var",
+        "bn2_num_batches_tracked")]
+
+
+class EncoderWeights(C.Structure):
+    """struct vrp_encoder_weights"""
+    _fields_ = [("node_dim", C.c_int32), ("depot_dim", C.c_int32), ("hidden", C.c_int32),
+                ("num_layers", C.c_int32),
+                ("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
+                ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
+                ("layer", EncoderLayer * 8)]
+
+
+class DecoderWeights(C.Structure):
+    """struct vrp_decoder_weights"""
+    _fields_ = [(n, c_vp) for n in (
+        "first_node", "last_node", "q_proj_weight", "k_proj_weight", "v_proj_weight",
+        "in_proj_bias", "out_proj_weight", "out_proj_bias", "kp_weight",
+        "att_output_weight", "context_proj_weight")]
+
+
+class RolloutIO(C.Structure):
+    """struct vrp_rollout_io"""
+    _fields_ = [(n, c_vp) for n in ("acc_loss", "acc_logp", "notdone", "actions", "forced",
+                                    "noise", "logits", "step_logp")]
+
+
+def library_path():
+    return os.environ.get("VRPGYM_HIP_LIB", os.path.join(_HERE, "libvrpgym_hip.so"))
+
+
+def _declare(lib):
+    i32, i64, vp = C.c_int, C.c_int64, C.c_void_p
+    P = C.POINTER
+    sig = {
+        "vrp_env_mask": (i32, [P(Env), i32, vp]),
+        "vrp_env_step": (i32, [P(Env), vp, i32, vp, vp, vp]),
+        "vrp_env_features": (i32, [P(Env), vp, vp, vp]),
+        "vrp_encoder_workspace_bytes": (i64, [i32, i32, i32]),
+        "vrp_decoder_workspace_bytes": (i64, [i32, i32, i32]),
+        "vrp_decoder_derived_bytes": (i64, []),
+        "vrp_encoder_forward": (i32, [P(EncoderWeights), i32, i32, i32, vp, vp, vp, vp, vp]),
+        "vrp_decoder_prepare": (i32, [i32, P(DecoderWeights), vp, vp]),
+        "vrp_decode_prologue": (i32, [i32, vp, i32, i32, vp, vp, vp]),
+        "vrp_decode_step": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
+                                  i32, i32, i32, vp]),
+        "vrp_rollout": (i32, [i32, P(EncoderWeights), P(DecoderWeights), vp, P(Env), i32, i32,
+                              vp, vp, vp, P(RolloutIO), i32, vp]),
+        "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
+                                    i32, i32, vp]),
+        "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+        "vrp_last_error": (C.c_char_p, []),
+        "vrp_abi_version": (i32, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing from the build
+        fn.restype, fn.argtypes = res, args
+    return sig
+
+
+EXPORTS = None
+
+
+def lib():
+    """The loaded library.  torch is imported first so that exactly one HIP runtime
+    (torch's bundled libamdhip64, soname libamdhip64.so.7) is mapped."""
+    global _LIB, EXPORTS
+    if _LIB is None:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so before our .so)
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"libvrpgym_hip.so not found at {path}: build it with "
+                "`python __graft_entry__.py` or `make -C vrp-gym_amd/csrc` "
+                "(there is no CPU fallback)")
+        _LIB = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        EXPORTS = _declare(_LIB)
+    return _LIB
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("vrp-gym_amd needs an AMD GPU (MI355X/gfx950) visible to "
+                           "PyTorch-ROCm; there is no CPU fallback")
+    return lib()
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().vrp_last_error()
+        raise RuntimeError(f"libvrpgym_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
