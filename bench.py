@@ -120,6 +120,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
         rewind(env)
         cenv = env._cenv()
         hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
+                                          dec_ws.data_ptr(), stream))  # resets the score rows
         res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                for _ in range(T)]
@@ -131,6 +133,25 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
             evs[t][1].record()
         torch.cuda.synchronize()
         durs += [a.elapsed_time(b) * 1e-3 for a, b in evs]
+    # cross-check: the same T launches back to back with ONE event pair around the loop
+    # (per-launch event pairs add a few us of packet overhead to very short kernels)
+    loops = []
+    for _ in range(reps):
+        rewind(env)
+        cenv = env._cenv()
+        hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
+                                          dec_ws.data_ptr(), stream))
+        res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in range(T):
+            hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
+                                          res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
+                                          max_steps, 0 if greedy else 1, stream))
+        e1.record()
+        torch.cuda.synchronize()
+        loops.append(e0.elapsed_time(e1) * 1e-3 / T)
     avg = float(np.mean(durs))
     byts = algorithmic_bytes_per_step(B, N)
     achieved = byts / avg / 1e9
@@ -138,7 +159,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
-            "launches_timed": len(durs)}
+            "launches_timed": len(durs),
+            "loop_us_per_launch": round(float(np.mean(loops)) * 1e6, 3)}
 
 
 def cpu_baseline(kind, N, B, greedy, budget_s=15.0):

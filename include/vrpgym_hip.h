@@ -53,8 +53,8 @@ int vrp_env_mask(const vrp_env *env, int parity, void *stream);
 
 /* E4-E8  TSPEnv.step tsp.py:60-101 / IRPEnv.step irp.py:49-99 for host-driven callers
  * (RandomAgent, user code).  actions (B) int64.  Writes reward_f64 (B) = -distance,
- * *notdone += number of graphs whose visited row is not all ones (evaluated before
- * the fix-ups, tsp.py:95); the caller zeroes *notdone first; done <=> *notdone == 0.
+ * *notdone := 1 if any graph's visited row is not all ones (evaluated before the
+ * fix-ups, tsp.py:95); the caller zeroes *notdone first; done <=> *notdone == 0.
  * Writes mask buffer `parity_out`. */
 int vrp_env_step(const vrp_env *env, const int64_t *actions, int parity_out,
                  double *reward_f64, int32_t *notdone, void *stream);
@@ -118,7 +118,7 @@ int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
 typedef struct vrp_rollout_io {
   float *acc_loss;        /* (B) fp32 sum of -distance, step order  graph_tsp_agent.py:85 */
   float *acc_logp;        /* (B) fp32 sum of log-prob               graph_tsp_agent.py:86 */
-  int32_t *notdone;       /* (max_steps+1) per-step count of unfinished graphs;          */
+  int32_t *notdone;       /* (max_steps+1) per-step flag "some graph is unfinished";     */
                           /*   notdone[t]==0 <=> env.step t returned done (tsp.py:95)    */
   int64_t *actions;       /* (max_steps,B) chosen nodes, or NULL                         */
   const int64_t *forced;  /* (max_steps,B) teacher-forced actions, or NULL               */
@@ -139,9 +139,12 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
  * flags: VRP_STEP_SAMPLE = sample with io->noise instead of argmax;
  *        VRP_STEP_DECODE_ONLY = GraphDecoder.forward alone: no env.step, no
  *        accumulation (only env->{B,N,mask,load} are read; results go to
- *        io->actions / io->step_logp / io->logits). */
+ *        io->actions / io->step_logp / io->logits);
+ *        VRP_STEP_TILE_KERNEL = use the raw-embedding-tile kernel also for N <= 64
+ *        (by default N <= 64 runs the table-driven kernel). */
 #define VRP_STEP_SAMPLE 1
 #define VRP_STEP_DECODE_ONLY 2
+#define VRP_STEP_TILE_KERNEL 4 /* force the raw-tile kernel (default for N > 64) */
 int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     const vrp_env *env, const float *emb, void *workspace,
                     const vrp_rollout_io *io, int t, int max_steps, int flags,
@@ -150,7 +153,8 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
 /* R1  TSPModel/VRPModel/IRPModel.forward (agents/graph_tsp_agent.py:61-92,
  * graph_vrp_agent.py:52-83, graph_irp_agent.py:54-105): mask init, features,
  * encoder, prologue and max_steps decode+env steps, all on `stream`.
- * emb (B,N,128) receives the node embeddings.  max_steps >= 2(N-1) (N-1 for TSP). */
+ * emb (B,N,128) receives the node embeddings.  max_steps >= 2(N-1) (N-1 for TSP).
+ * `sample` carries the step flags VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL. */
 int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
                 void *derived, const vrp_env *env, int train, int sample,
                 float *emb, void *enc_workspace, void *dec_workspace,

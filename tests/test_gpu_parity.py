@@ -239,7 +239,7 @@ def test_decoder_teacher_forced(name, path):
 
 # ------------------------------------------------------------------ R1: rollouts
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
-                     ref_loss=None, ref_logp=None, ref_T=None, train=False):
+                     ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False):
     """HIP rollout vs oracle (and vs reference outputs when given)."""
     from oracle import envs as oenv
     from oracle import policy as opol
@@ -258,7 +258,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     torch.manual_seed(torch_seed)
     with torch.no_grad():
         res = runtime.rollout(model, deepcopy(env), greedy, train=train, trace=True,
-                              noise_mode="host")
+                              noise_mode="host", tile_kernel=tile_kernel)
     T = res.T
     acts = res.actions[:T].cpu().numpy()
     want_acts = ref_actions if ref_actions is not None else oacts
@@ -306,12 +306,14 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     return res, exempt
 
 
+@pytest.mark.parametrize("tile_kernel", [False, True], ids=["table", "tile"])
 @pytest.mark.parametrize("name,path", _load("rollout_*.npz"))
-def test_rollout_against_reference(name, path):
+def test_rollout_against_reference(name, path, tile_kernel):
+    """Both step kernels (table-driven, default for N <= 64; raw-tile, default above)."""
     z = np.load(path)
     _compare_rollout(int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"]), 69, 69,
                      int(z["torch_seed"]), ref_actions=z["actions"], ref_loss=z["acc_loss"],
-                     ref_logp=z["acc_logp"], ref_T=int(z["T"]))
+                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=tile_kernel)
 
 
 @pytest.mark.parametrize("kind,B,N,greedy,train", [
@@ -326,6 +328,8 @@ def test_rollout_against_reference(name, path):
 ])
 def test_rollout_against_oracle(kind, B, N, greedy, train):
     _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train)
+    if N <= 64:
+        _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
 
 
 def test_reference_agent_kats():
@@ -389,3 +393,35 @@ def test_full_size_properties():
             res2 = runtime.rollout(agent.model, env2, True, trace=True)
         assert res2.T == T and torch.equal(res2.actions[:T], res.actions[:T])
         assert torch.equal(res2.acc_loss, res.acc_loss)
+
+
+def test_graph_replay_equals_eager():
+    """The hipGraph-captured rollout (default path) gives bit-identical results to the
+    eager launch sequence, across resets, for greedy and train-mode rollouts, and the
+    agent's twin env keeps model/baseline on identical instances."""
+    import agents
+    from gym_vrp.envs import IRPEnv
+    from agents import runtime
+    env = IRPEnv(12, 33, 1, 5)
+    agent = agents.IRPAgent(seed=69)
+    agent.model.eval()
+    for rep in range(4):  # second sighting captures, later ones replay
+        env.reset()
+        ref_env = deepcopy(env)
+        with torch.no_grad():
+            eager = runtime.rollout(agent.model, ref_env, True, use_graph=False)
+            got = runtime.rollout(agent.model, env, True)
+        assert torch.equal(eager.acc_loss, got.acc_loss), rep
+        assert eager.T == got.T
+        assert np.array_equal(env.visited, ref_env.visited)
+    loss, loss_b, _ = agent.step(env, [True, True])
+    assert torch.equal(loss, loss_b)  # same weights, same instances
+    # train-mode replays keep updating the BN running statistics once per rollout
+    agent.model.train()
+    nb0 = int(agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item())
+    for rep in range(3):
+        env.reset()
+        with torch.no_grad():
+            runtime.rollout(agent.model, env, True, train=True)
+    nb1 = int(agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item())
+    assert nb1 - nb0 == 3

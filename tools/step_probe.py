@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Times the decode_step launch (HIP events) over a sweep of shapes; also usable under
+rocprofv3 --pmc to attribute counters to the step kernel.  GPU box only."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "vrp-gym_amd"), ROOT]
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+shapes = [(0, 20, 512), (0, 20, 2048), (0, 20, 8192), (0, 40, 2048), (0, 40, 8192), (1, 40, 8192),
+          (2, 40, 8192)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+dev = torch.device("cuda", 0)
+for kind, N, B in shapes:
+    r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3)
+    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "loop_us_per_launch", "achieved", "frac")}))

@@ -5,6 +5,7 @@ from the modules' parameters, owns the device scratch buffers, draws the samplin
 noise and launches the library on torch's current stream.  There is no CPU path.
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -132,7 +133,11 @@ def decoder_derived(dec, kind):
     state = _derived_cache.get(dec)
     ver = (kind, _decoder_version(dec), str(dev), dec.attention.q_proj_weight.data_ptr())
     if state is None or state[0] != ver:
-        buf = torch.empty(int(lib.vrp_decoder_derived_bytes()), dtype=torch.uint8, device=dev)
+        if state is not None and state[1].device == dev:
+            buf = state[1]  # refresh in place: captured hipGraphs keep pointing at it
+        else:
+            buf = torch.empty(int(lib.vrp_decoder_derived_bytes()), dtype=torch.uint8,
+                              device=dev)
         w = decoder_struct(dec)
         hip.check(lib.vrp_decoder_prepare(kind, C.byref(w), buf.data_ptr(),
                                           hip.current_stream(dev)))
@@ -250,10 +255,124 @@ def host_noise(max_steps, B, N):
     return torch.stack([torch.empty((B, N)).exponential_(1) for _ in range(max_steps)])
 
 
+_graphs = {}  # key -> _CapturedRollout
+USE_GRAPHS = os.environ.get("VRPGYM_GRAPHS", "1") != "0"
+
+
+class _CapturedRollout:
+    """One hipGraph holding a complete vrp_rollout (mask init, features, encoder,
+    prologue, max_steps fused steps): the ~90 launches of a small-batch rollout replay
+    without host launch latency.  Everything the graph touches is pointer-stable: env
+    tensors, parameters, the in-place derived buffer, private scratch and outputs."""
+
+    def __init__(self, model, env, greedy, train, tile_kernel, dev):
+        lib = hip.lib()
+        kind, B, N = env.KIND, env.batch_size, env.num_nodes
+        self.max_steps = max_steps_for(kind, N)
+        ew, dw = encoder_struct(model.encoder), decoder_struct(model.decoder)
+        self.derived = decoder_derived(model.decoder, kind)
+        self.enc_ws = torch.empty(int(lib.vrp_encoder_workspace_bytes(B, N, ew.hidden)),
+                                  dtype=torch.uint8, device=dev)
+        self.dec_ws = torch.empty(int(lib.vrp_decoder_workspace_bytes(kind, B, N)),
+                                  dtype=torch.uint8, device=dev)
+        self.emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
+        self.acc_loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        self.acc_logp = torch.empty((B,), dtype=torch.float32, device=dev)
+        self.notdone = torch.empty((self.max_steps + 1,), dtype=torch.int32, device=dev)
+        self.noise = None
+        io = hip.RolloutIO()
+        io.acc_loss, io.acc_logp = self.acc_loss.data_ptr(), self.acc_logp.data_ptr()
+        io.notdone = self.notdone.data_ptr()
+        if not greedy:
+            self.noise = torch.ones((self.max_steps, B, N), dtype=torch.float32, device=dev)
+            io.noise = self.noise.data_ptr()
+        self.ptrs = self._pointer_key(model, env)
+        cenv = env._cenv()
+        flags = int(not greedy) | (4 if tile_kernel else 0)
+
+        def launch():
+            hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), self.derived.data_ptr(),
+                                      C.byref(cenv), int(bool(train)), flags,
+                                      self.emb.data_ptr(), self.enc_ws.data_ptr(),
+                                      self.dec_ws.data_ptr(), C.byref(io), self.max_steps,
+                                      hip.current_stream(dev)))
+
+        # warm-up outside the capture (first-use attribute calls, lazy module load)
+        snap = [t.clone() for t in _bn_buffers(model)] if train else None
+        vis, cur, load = env._visited.clone(), env._cur.clone(), env._load.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            launch()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        env._visited.copy_(vis); env._cur.copy_(cur); env._load.copy_(load)
+        if snap is not None:  # the warm-up must not count as a training step
+            for t, s0 in zip(_bn_buffers(model), snap):
+                t.copy_(s0)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            launch()
+        # capture only records; state is untouched
+
+    @staticmethod
+    def _pointer_key(model, env):
+        return (env._pos.data_ptr(), env._visited.data_ptr(), env._mask.data_ptr(),
+                model.encoder.node_embed.weight.data_ptr(),
+                model.decoder.attention.q_proj_weight.data_ptr())
+
+    def valid_for(self, model, env):
+        return self.ptrs == self._pointer_key(model, env)
+
+
+def _bn_buffers(model):
+    return [b for n, b in model.encoder.named_buffers()]
+
+
+def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
+    key = (id(model), id(env), bool(greedy), bool(train), bool(tile_kernel))
+    cap = _graphs.get(key)
+    if cap is None:
+        # capture on the second sighting only: throw-away envs (deepcopies) stay eager
+        seen = env.__dict__.setdefault("_graph_sightings", set())
+        if key not in seen:
+            seen.add(key)
+            return None
+    if cap is None or not cap.valid_for(model, env):
+        if len(_graphs) > 64:
+            _graphs.clear()
+        cap = _CapturedRollout(model, env, greedy, train, tile_kernel, dev)
+        _graphs[key] = cap
+        cap.model_ref, cap.env_ref = weakref.ref(model), weakref.ref(env)
+    elif cap.model_ref() is not model or cap.env_ref() is not env:
+        _graphs.pop(key)  # id() reuse after garbage collection
+        return _graph_rollout(model, env, greedy, train, tile_kernel, dev)
+    decoder_derived(model.decoder, env.KIND)  # in-place refresh if the weights changed
+    if cap.noise is not None:
+        cap.noise.exponential_(1)
+    cap.graph.replay()
+    res = RolloutResult(cap.acc_loss.clone(), cap.acc_logp.clone(), cap.notdone.clone(), None,
+                        None, None, cap.emb, cap.max_steps)
+    return res
+
+
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
-            noise_mode="device"):
+            noise_mode="device", tile_kernel=False, use_graph=None):
     """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU."""
     dev = _require_cuda(model)
+    if use_graph is None:
+        use_graph = USE_GRAPHS
+    if (use_graph and forced is None and noise is None and not trace
+            and (greedy or noise_mode == "device")):
+        if str(env._device) != str(dev):
+            raise RuntimeError(f"env is on {env._device} but the model on {dev}")
+        env._sync_positions()
+        env._parity = 0
+        res = _graph_rollout(model, env, greedy, train, tile_kernel, dev)
+        if res is not None:
+            env._mask_fresh = False
+            env._last_rollout = res
+            return res
     lib = hip.lib()
     kind = env.KIND
     if str(env._device) != str(dev):
@@ -310,7 +429,8 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._parity = 0
     cenv = env._cenv()
     hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), derived.data_ptr(), C.byref(cenv),
-                              int(bool(train)), int(not greedy), emb.data_ptr(),
+                              int(bool(train)), int(not greedy) | (4 if tile_kernel else 0),
+                              emb.data_ptr(),
                               enc_ws.data_ptr(), dec_ws.data_ptr(), C.byref(io), max_steps,
                               stream))
     env._mask_fresh = False  # final mask sits in buffer T&1; recompute lazily into buffer 0

@@ -31,15 +31,43 @@ void vrp_set_error(const char *fmt, ...);
 static inline size_t vrp_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ---- wave-level reductions (all 64 lanes participate) -----------------------
+// DPP row shifts + row broadcasts (no LDS crossbar): after the six steps lane 63 holds
+// the reduction of the whole wave; readlane(63) hands it back as a wave-uniform value.
+#define VRP_DPP(old, src, ctrl, rowmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), \
+      __builtin_bit_cast(int, (float)(src)), (ctrl), (rowmask), 0xF, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += VRP_DPP(0.f, v, 0x111, 0xF);  // row_shr:1
+  v += VRP_DPP(0.f, v, 0x112, 0xF);  // row_shr:2
+  v += VRP_DPP(0.f, v, 0x114, 0xF);  // row_shr:4
+  v += VRP_DPP(0.f, v, 0x118, 0xF);  // row_shr:8   -> lane 15 of each row = row total
+  v += VRP_DPP(0.f, v, 0x142, 0xA);  // row_bcast:15 into rows 1,3
+  v += VRP_DPP(0.f, v, 0x143, 0xC);  // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, VRP_DPP(v, v, 0x111, 0xF));
+  v = fmaxf(v, VRP_DPP(v, v, 0x112, 0xF));
+  v = fmaxf(v, VRP_DPP(v, v, 0x114, 0xF));
+  v = fmaxf(v, VRP_DPP(v, v, 0x118, 0xF));
+  v = fmaxf(v, VRP_DPP(v, v, 0x142, 0xA));
+  v = fmaxf(v, VRP_DPP(v, v, 0x143, 0xC));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// sum over the 8 lanes that share lane>>3 (quad swaps + half-row mirror); every lane of
+// the group ends with the group total
+__device__ __forceinline__ float group8_sum(float v) {
+  v += VRP_DPP(0.f, v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+  v += VRP_DPP(0.f, v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+  v += VRP_DPP(0.f, v, 0x141, 0xF);  // row_half_mirror: lane i <-> 7-i within 8 lanes
   return v;
+}
+// index of the maximum with the lowest index among equals (torch CPU argmax), one value
+// per lane, lane id = candidate index
+__device__ __forceinline__ int wave_argmax_lane(float v) {
+  const float m = wave_max(v);
+  const unsigned long long hit = __ballot(v == m);
+  return __ffsll((long long)hit) - 1;
 }
 // argmax with lowest index among equal values (torch CPU argmax semantics).
 __device__ __forceinline__ void wave_argmax(float &v, int &i) {

@@ -19,6 +19,7 @@
 //     (z = A*E) and the pointer logits (u = E*w).
 //   * QUIRK D3 reproduced: the float 0/1 mask is ADDED to the glimpse scores and
 //     head h of graph b reads mask row (8b+h) mod B (graph_decoder.py:93-94).
+#include <stdlib.h>
 #include "env_device.h"
 
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
@@ -27,8 +28,8 @@ int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const f
 
 // ------------------------------------------------------------------ derived weights
 struct Derived {
-  float *Wproj;  // (1152,128) = [Wq_first | Wq_last | Wk]  (IRP: [Wq_last' | Wk], 768 rows)
-  float *bproj;  // (1152)       0 | 0 | bk
+  float *Wproj;  // (1920,128) = [Wq_first | Wq_last | Wk | M^T | Wv]  (IRP: no Wq_first, 1536 rows)
+  float *bproj;  // (1920)       0 | 0 | bk | 0 | bv
   float *Wqg;    // (384,128)  graph-embedding block of the query projection
   float *bq;     // (384)
   float *qc0;    // (384)      query contribution of the step-0 placeholders
@@ -44,8 +45,8 @@ struct Derived {
 static Derived carve_derived(void *base) {
   float *p = (float *)base;
   Derived d;
-  d.Wproj = p; p += 1152 * 128;
-  d.bproj = p; p += 1152;
+  d.Wproj = p; p += 1920 * 128;
+  d.bproj = p; p += 1920;
   d.Wqg = p;   p += 384 * 128;
   d.bq = p;    p += 384;
   d.qc0 = p;   p += 384;
@@ -61,7 +62,7 @@ static Derived carve_derived(void *base) {
 
 extern "C" int64_t vrp_decoder_derived_bytes(void) {
   return (int64_t)sizeof(float) *
-         (1152 * 128 + 1152 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
+         (1920 * 128 + 1920 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
           128 * 384 + 128);
 }
 
@@ -148,6 +149,12 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   r |= mm(st, d.tmpv, 1, 0, w->att_output_weight, 384, 1, w->out_proj_bias, 1, 0, 128, 1, 384, 1.f,
           0.f);
   r |= mm(st, d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s, 0.f);
+  // table-driven step (N <= 64): per-node KM[m] = M^T e_m and VV[n] = Wv e_n + bv
+  const int o = (kind == VRP_KIND_IRP) ? 768 : 1152;
+  r |= cp(st, d.Wproj + (size_t)o * 128, 128, 1, d.MT, 128, 1, 384, 128);
+  r |= cp(st, d.Wproj + (size_t)(o + 384) * 128, 128, 1, w->v_proj_weight, 128, 1, 384, 128);
+  r |= cp(st, d.bproj + o, 0, 1, nullptr, 0, 0, 1, 384);
+  r |= cp(st, d.bproj + o + 384, 0, 1, bias + 768, 0, 1, 1, 384);
   return r ? 1 : 0;
 }
 
@@ -156,12 +163,21 @@ struct DecWs {
   float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
   float *QG;     // (B,384)     Wq_g g + bq
   float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
-  float *SG, *C0, *SLD, *base1;  // (B,8,N) each
+  float *SG, *C0, *SLD, *base1, *curs;  // (B,8,N) each
   float *SF, *SL;                // (B,N,8,N) each
+  float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:] (N <= 64)
+  float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
 };
 
-static int proj_width(int kind) { return kind == VRP_KIND_IRP ? 768 : 1152; }
+#define VRP_RT_MAX_N 64  // above this the tile kernel (one raw-tile read per step) is used
+static bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
+static int proj_width(int kind, int N) {
+  return (kind == VRP_KIND_IRP ? 768 : 1152) + (use_rtable(N) ? 768 : 0);
+}
+static size_t rtable_floats(int B, int N) {
+  return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
+}
 
 static DecWs carve_decws(int kind, void *ws, int B, int N) {
   char *p = (char *)ws;
@@ -169,13 +185,16 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
   const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
   w.g = (float *)p;     p += vrp_align_up((size_t)B * 128 * 4);
   w.QG = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
-  w.PROJ = (float *)p;  p += vrp_align_up(R * proj_width(kind) * 4);
+  w.PROJ = (float *)p;  p += vrp_align_up(R * proj_width(kind, N) * 4);
   w.SG = (float *)p;    p += vrp_align_up(hn);
   w.C0 = (float *)p;    p += vrp_align_up(hn);
   w.SLD = (float *)p;   p += vrp_align_up(hn);
   w.base1 = (float *)p; p += vrp_align_up(hn);
+  w.curs = (float *)p;  p += vrp_align_up(hn);
   w.SF = (float *)p;    p += vrp_align_up(tb);
   w.SL = (float *)p;    p += vrp_align_up(tb);
+  w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
+  w.cvec = (float *)p;  p += vrp_align_up(R * 4);
   w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
   w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
   return w;
@@ -184,8 +203,9 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
 extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
   return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
-                   vrp_align_up(R * proj_width(kind) * 4) + 4 * vrp_align_up(hn) +
-                   2 * vrp_align_up(tb) + 2 * vrp_align_up((size_t)B * 4));
+                   vrp_align_up(R * proj_width(kind, N) * 4) + 5 * vrp_align_up(hn) +
+                   2 * vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
+                   vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
 }
 
 // graph embedding = mean over nodes (sum, then divide)   graph_decoder.py:75-77
@@ -211,7 +231,8 @@ __global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int 
                                                            float *__restrict__ C0,
                                                            float *__restrict__ SLD,
                                                            float *__restrict__ SF,
-                                                           float *__restrict__ SL) {
+                                                           float *__restrict__ SL,
+                                                           float *__restrict__ curs) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -241,8 +262,11 @@ __global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int 
   for (int i = 0; i < NPL; ++i) {
     const int n = lane + 64 * i;
     if (n < N) {
-      SG[hn + n] = dot(QG + (size_t)b * VRP_D + h * VRP_HD, i);
-      C0[hn + n] = dot(qc0 + h * VRP_HD, i);
+      const float sg = dot(QG + (size_t)b * VRP_D + h * VRP_HD, i);
+      const float c0 = dot(qc0 + h * VRP_HD, i);
+      SG[hn + n] = sg;
+      C0[hn + n] = c0;
+      curs[hn + n] = sg + c0;  // step-0 score row of the table-driven kernel
       SLD[hn + n] = dot(wload + h * VRP_HD, i);
     }
   }
@@ -260,6 +284,47 @@ __global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int 
   }
 }
 
+// Pointer-logit table for the table-driven step:  RT[b][m][h][n] =
+// (M_h^T e_m) . (Wv_h e_n + bv_h), so that u_m = sum_{h,n} a_{h,n} RT[m][h][n] + e_m.mb
+// (the folds of 3.1 carried one step further: no weight matrix is touched per step).
+// One wave per (graph, head); lane = n keeps VV_{h,n} (48 floats) in registers.
+__global__ __launch_bounds__(256) void rtable_kernel(int N, int P, int kmoff,
+                                                     const float *__restrict__ PROJ,
+                                                     float *__restrict__ RT) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  float vv[VRP_HD];
+  {
+    const float *vp = PROJ + ((size_t)b * N + (lane < N ? lane : 0)) * P + kmoff + 384 + h * VRP_HD;
+#pragma unroll
+    for (int d = 0; d < VRP_HD; d += 4) {
+      float4 t = *reinterpret_cast<const float4 *>(vp + d);
+      vv[d] = t.x; vv[d + 1] = t.y; vv[d + 2] = t.z; vv[d + 3] = t.w;
+    }
+  }
+  for (int m = 0; m < N; ++m) {
+    const float *row = PROJ + ((size_t)b * N + m) * P + kmoff + h * VRP_HD;
+    float sacc = 0.f;
+#pragma unroll
+    for (int d = 0; d < VRP_HD; ++d) sacc = fmaf(row[d], vv[d], sacc);
+    if (lane < N) RT[(((size_t)b * N + m) * 8 + h) * N + lane] = sacc;
+  }
+}
+
+// cvec[b][m] = e_m . mb   (one wave per node row)
+__global__ __launch_bounds__(256) void cvec_kernel(const float *__restrict__ emb,
+                                                   const float *__restrict__ mb, int rows,
+                                                   float *__restrict__ cvec) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float2 e = reinterpret_cast<const float2 *>(emb + (size_t)r * VRP_EMB)[lane];
+  const float2 m = reinterpret_cast<const float2 *>(mb)[lane];
+  const float s = wave_sum(fmaf(e.x, m.x, e.y * m.y));
+  if (lane == 0) cvec[r] = s;
+}
+
 extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
                                    void *workspace, void *stream) {
   VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
@@ -267,7 +332,7 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs w = carve_decws(kind, workspace, B, N);
-  const int P = proj_width(kind);
+  const int P = proj_width(kind, N);
   hipLaunchKernelGGL(graph_mean_kernel, dim3(B), dim3(128), 0, st, emb, N, w.g);
   VRP_CHECK_LAUNCH("graph_mean");
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
@@ -276,12 +341,29 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
                                  128, 0, st)) return r;
   if (N <= 64)
     hipLaunchKernelGGL(score_tables_kernel<1>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL);
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
   else
     hipLaunchKernelGGL(score_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL);
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
   VRP_CHECK_LAUNCH("score_tables");
+  if (use_rtable(N)) {
+    hipLaunchKernelGGL(rtable_kernel, dim3(B, 2), dim3(256), 0, st, N, P,
+                       kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
+    VRP_CHECK_LAUNCH("rtable");
+    hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
+                       w.cvec);
+    VRP_CHECK_LAUNCH("cvec");
+  }
   return 0;
+}
+
+// Batch-wide "somebody is not done" flag.  A counter would need one same-address atomic
+// per graph (~11 ns each on gfx950: 90 us at B = 8192); only zero / non-zero matters, so
+// a wave stores 1 only if it does not already see a non-zero value (an L1-bypassing load;
+// racing writers all store the same value).
+__device__ __forceinline__ void flag_notdone(int32_t *flag) {
+  if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ the step kernel
@@ -289,9 +371,10 @@ struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only;
   const float *emb;
   const float *SG, *C0, *SLD, *SF, *SL;
-  float *base1;
+  float *base1, *curs;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
+  const float *RT, *cvec;
   vrp_env env;
   vrp_rollout_io io;
 };
@@ -551,7 +634,258 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
     p.io.acc_logp[b] += logp;
     p.last[b] = idx;
     if (p.t == 0) p.first[b] = idx;
-    if (!eo.done) atomicAdd(&p.io.notdone[p.t], 1);
+    if (!eo.done) flag_notdone(&p.io.notdone[p.t]);
+    if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
+    if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
+  }
+}
+
+// ---------------------------------------------------------------- table-driven step (N <= 64)
+// One wave per graph, no weight matrix and no embedding tile.  Per step a graph streams
+//   3 x (8,N) glimpse score rows, 9 mask rows, its coordinate/visited/demand rows and the
+//   rows RT[b][m][:][:] (8N floats each) of the pointer-logit table -- ONLY for nodes m that
+//   are still selectable: masked logits are -inf whatever their value (graph_decoder.py:98),
+//   so their rows are never read.  Averaged over a TSP episode that halves the traffic.
+// Latency structure (the kernel is launch- and latency-bound at small batch):
+//   * every load that does not depend on the chosen action is issued at kernel entry
+//     (incl. the first RT rows and the whole env row: lane n holds node n's
+//     coordinates/visited/demand; the action's and the current node's values are then
+//     fetched with readlane instead of dependent loads);
+//   * the only dependent global read is SL[b][action] at the end, overlapped with the
+//     env bookkeeping; it is folded into `curs` (= this graph's score row for the next
+//     step) so the next launch starts without a pointer chase;
+//   * the batch-wide done flag is read with everything else and only gates the commits.
+// RT pass: lane = (row slot r = lane>>3, part q = lane&7).  The k-th selectable node
+// (k = 8*pass + r) is found by ballot/prefix; the 8 parts split its row of 2N float4;
+// every wave-level load is 8 x 128 contiguous bytes.
+#define RT_U 8  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
+
+// lane owns float4 indices part + 8*i (i < cnt) of its row; one work item = RT_U of them
+__device__ __forceinline__ void rt_load(float4 (&r)[RT_U], const float4 *rt, int i0, int cnt,
+                                        bool on) {
+#pragma unroll
+  for (int i = 0; i < RT_U; ++i)
+    r[i] = (on && i0 + i < cnt) ? rt[8 * (i0 + i)] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float rt_dot(float acc, const float4 (&r)[RT_U], const float4 *a,
+                                        int i0, int cnt) {
+#pragma unroll
+  for (int i = 0; i < RT_U; ++i) {
+    if (i0 + i < cnt) {
+      const float4 w = a[8 * (i0 + i)];
+      acc = fmaf(w.x, r[i].x, acc);
+      acc = fmaf(w.y, r[i].y, acc);
+      acc = fmaf(w.z, r[i].z, acc);
+      acc = fmaf(w.w, r[i].w, acc);
+    }
+  }
+  return acc;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const long long x = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)x, l);
+  const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// index of the k-th set bit of `bits` (k < popcount), wave-uniform inputs per lane group
+__device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
+  for (int i = 0; i < k; ++i) bits &= bits - 1;
+  return __ffsll((long long)bits) - 1;
+}
+
+__global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
+  __shared__ __attribute__((aligned(16))) float a_s[GPW][8 * VRP_RT_MAX_N];  // a[h][n], hn order
+  __shared__ __attribute__((aligned(16))) float u_s[GPW][VRP_RT_MAX_N];
+  __shared__ int sel_s[GPW][VRP_RT_MAX_N];  // compacted list of selectable nodes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N, B = p.B;
+  const int braw = blockIdx.x * GPW + wave;
+  const bool active = braw < B;
+  const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
+  const int par = p.t & 1;
+  const uint8_t *mask_in = p.env.mask + (size_t)par * B * N;
+  uint8_t *mask_out = p.env.mask + (size_t)(par ^ 1) * B * N;
+  const int n4 = 2 * N;  // float4 per RT row (8N floats)
+  const int rsl = lane >> 3, part = lane & 7;
+  const bool inN = lane < N;
+  const int ln = inN ? lane : 0;
+
+  // ---- entry: issue every action-independent load --------------------------------
+  const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
+  const int own_mask = mask_in[(size_t)b * N + ln];
+  const size_t row = (size_t)b * 8 * N;
+  float sc[8], brow[8], sld[8];
+  int msk[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    sc[h] = p.curs[row + h * N + ln];
+    brow[h] = (p.t == 0 ? p.SG : p.base1)[row + h * N + ln];
+    sld[h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln] : 0.f;
+    msk[h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln];  // QUIRK D3: other graphs' rows
+  }
+  const float cv = p.cvec[(size_t)b * N + ln];
+  // env row (lane = node)
+  double2 xy = make_double2(0.0, 0.0);
+  int vis = 1;
+  double dem = 0.0;
+  if (!p.decode_only) {
+    xy = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln];
+    if (inN) vis = p.env.visited[(size_t)b * N + ln];
+    if (p.kind == VRP_KIND_IRP) dem = p.env.demand[(size_t)b * N + ln];
+  }
+  const int cur = p.decode_only ? 0 : p.env.cur[b];
+  const int dep = p.decode_only ? 0 : p.env.depot[b];
+  const double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+  float accl = 0.f, accp = 0.f;
+  if (!p.decode_only) { accl = p.io.acc_loss[b]; accp = p.io.acc_logp[b]; }
+  float q_noise = 1.f;
+  if (p.sample) q_noise = p.io.noise[((size_t)p.t * B + b) * N + ln];
+
+  // selectable nodes (own mask == 0); their RT rows are the only ones fetched
+  const bool selectable = inN && !own_mask;
+  const unsigned long long sel = __ballot(selectable);
+  const int nsel = __popcll(sel);
+  if (selectable) sel_s[wave][__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+  const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
+  const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
+  const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
+  const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
+  float4 ra[RT_U], rb[RT_U];
+  const int m_first = (rsl < nsel) ? kth_set_bit(sel, rsl) : -1;  // pass 0 rows (k < 8)
+  int m_a = m_first, m_b = -1;
+  rt_load(ra, rtb + (size_t)(m_a < 0 ? 0 : m_a) * n4, 0, cnt, m_a >= 0);
+
+  // ---- glimpse attention weights (lane = n) -----------------------------------------
+  {
+    const float loadf = (float)load0;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      float s = sc[h];
+      if (p.kind == VRP_KIND_IRP) s = fmaf(loadf, sld[h], s);
+      s = inN ? s + (float)msk[h] : -INFINITY;
+      const float m = wave_max(s);
+      const float e = inN ? expf(s - m) : 0.f;
+      const float sum = wave_sum(e);
+      if (inN) a_s[wave][h * N + lane] = e / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- u_m = sum_{h,n} a[h][n] * RT[m][h][n] + cvec[m]  for selectable m ---------------
+  {
+    const float4 *aw = reinterpret_cast<const float4 *>(a_s[wave]) + part;
+    float acc = 0.f;
+    auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
+      const int pass = w / nchunk, ch = w - pass * nchunk;
+      const int k = 8 * pass + rsl;
+      const int m = (pass == 0) ? m_first : (k < nsel ? sel_s[wave][k] : -1);
+      m_out = m;
+      rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
+    };
+    auto consume = [&](const float4 (&r)[RT_U], int w, int m) {
+      const int ch = w % nchunk;
+      acc = rt_dot(acc, r, aw, ch * RT_U, m >= 0 ? cnt : 0);
+      if (ch == nchunk - 1) {
+        acc = group8_sum(acc);
+        if (part == 0 && m >= 0) u_s[wave][m] = acc;
+        acc = 0.f;
+      }
+    };
+    for (int w = 0; w < total; w += 2) {
+      if (w + 1 < total) load_item(rb, w + 1, m_b);
+      consume(ra, w, m_a);
+      if (w + 2 < total) load_item(ra, w + 2, m_a);
+      if (w + 1 < total) consume(rb, w + 1, m_b);
+    }
+  }
+  __syncthreads();
+
+  float u = -INFINITY;
+  if (inN && !own_mask) u = 10.f * tanhf(u_s[wave][lane] + cv);  // graph_decoder.py:97-98
+  if (active && p.io.logits && inN) p.io.logits[((size_t)p.t * B + b) * N + lane] = u;
+
+  int idx;
+  float logp = 0.f;
+  if (!p.sample) {
+    idx = wave_argmax_lane(u);
+    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
+  } else {
+    // Categorical(logits=u): logits - logsumexp, probs = softmax, sample = argmax(p/q)
+    const float m = wave_max(u);
+    const float se = wave_sum(expf(u - m));
+    const float l = u - (m + logf(se));
+    const float lm = wave_max(l);
+    const float pe = expf(l - lm);
+    const float ps = wave_sum(pe);
+    const float ratio = inN ? (pe / ps) / q_noise : -1.f;
+    idx = wave_argmax_lane(ratio);
+    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
+    logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), idx));
+  }
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
+
+  // ---- the only action-dependent reads: next step's score row ------------------------
+  //   base1 = SG + SF[first]  (graph_decoder.py:111-113, fixed after the first step)
+  //   curs  = base1 + SL[last = idx]
+  {
+    const size_t arow = ((size_t)b * N + idx) * 8 * N;
+    float sl[8], sf[8];
+    const bool newbase = (p.t == 0 && p.kind != VRP_KIND_IRP);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      sl[h] = p.SL[arow + h * N + ln];
+      sf[h] = newbase ? p.SF[arow + h * N + ln] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const float b1 = brow[h] + sf[h];
+      if (inN) {
+        if (newbase) p.base1[row + h * N + lane] = b1;
+        p.curs[row + h * N + lane] = b1 + sl[h];
+      }
+    }
+  }
+  if (p.decode_only) {
+    if (lane == 0) {
+      p.last[b] = idx;
+      if (p.t == 0) p.first[b] = idx;
+      if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
+      if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
+    }
+    return;
+  }
+
+  // ---- env.step on registers (same operation order as env_device.h) -------------------
+  if (lane == idx) vis = 1;                                   // tsp.py:86
+  const double ax = readlane_f64(xy.x, idx), ay = readlane_f64(xy.y, idx);
+  const double cx = readlane_f64(xy.x, cur), cy = readlane_f64(xy.y, cur);
+  const double dx = cx - ax, dy = cy - ay;
+  const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+  double load = 1.0;
+  if (p.kind == VRP_KIND_IRP) {                               // irp.py:80-86
+    load = load0 - readlane_f64(dem, idx);
+    if (idx == dep) load = 1.0;
+  }
+  const bool done = __all(vis);                               // before the fix-ups, tsp.py:95
+  if (idx == dep) { if (lane == dep) vis = 1; }               // tsp.py:141-142
+  else if (p.kind != VRP_KIND_TSP) { if (lane == dep) vis = 0; }  // vrp.py:28-31
+  if (__all(vis)) { if (lane == dep) vis = 0; }               // tsp.py:145-146
+  int mk = vis;
+  if (p.kind == VRP_KIND_IRP && inN && dem - load > 0.0) mk = 1;  // irp.py:151-153
+  if (inN) {
+    p.env.visited[(size_t)b * N + lane] = (uint8_t)vis;
+    mask_out[(size_t)b * N + lane] = (uint8_t)mk;
+  }
+  if (lane == 0) {
+    p.env.cur[b] = idx;
+    if (p.kind == VRP_KIND_IRP) p.env.load[b] = load;
+    p.io.acc_loss[b] = accl + (float)(-dist);  // fp32 accumulate in step order, tsp_agent:85
+    p.io.acc_logp[b] = accp + logp;
+    p.last[b] = idx;
+    if (p.t == 0) p.first[b] = idx;
+    if (!done) flag_notdone(&p.io.notdone[p.t]);
     if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
     if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
   }
@@ -603,11 +937,18 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.emb = emb;
   p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SF = ws.SF; p.SL = ws.SL;
   p.base1 = (kind == VRP_KIND_IRP) ? ws.SG : ws.base1;
+  p.curs = ws.curs;
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
+  p.RT = ws.RT; p.cvec = ws.cvec;
   p.env = *env;
   p.io = *io;
   hipStream_t st = (hipStream_t)stream;
+  if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
+    hipLaunchKernelGGL(decode_step_rt_kernel, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
+    VRP_CHECK_LAUNCH("decode_step_rt");
+    return 0;
+  }
   if (N <= 24) return launch_step<24>(p, st);
   if (N <= 40) return launch_step<40>(p, st);
   if (N <= 64) return launch_step<64>(p, st);

@@ -8,6 +8,9 @@
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *R, int ldr, float *C, int ldc, int M, int N, int K,
                        int relu, hipStream_t stream);
+int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, const float *bias,
+                          const float *R, int ldr, const float *norm, float *C, int ldc, int M,
+                          int N, int K, int relu, hipStream_t stream);
 
 // ---- embedding: node_embed / depot_embed select (graph_encoder.py:54, 110-132) -----
 __global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x,
@@ -108,48 +111,57 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
   }
 }
 
-// norm[0:128] = mean, norm[128:256] = weight / sqrt(var + eps), norm[256:384] = bias
-__global__ void bn_finalize_kernel(const double *__restrict__ stats, int rows, int train,
-                                   const float *__restrict__ weight,
-                                   const float *__restrict__ bias, float *running_mean,
-                                   float *running_var, int64_t *num_batches_tracked,
-                                   float *__restrict__ norm) {
-  const int c = threadIdx.x;
-  float mean, var;
-  if (train) {
+// Eval mode: BatchNorm is a per-channel affine known before the layer runs; all 2L
+// triples [mean | weight/sqrt(var+eps) | bias] are produced by ONE launch and applied in
+// the epilogue of the GEMM that produces the normalised tensor.
+__global__ void bn_eval_norms_kernel(vrp_encoder_weights w, float *__restrict__ norms) {
+  const int c = threadIdx.x, l = blockIdx.x >> 1, second = blockIdx.x & 1;
+  const vrp_encoder_layer &L = w.layer[l];
+  const float *rm = second ? L.bn2_running_mean : L.bn1_running_mean;
+  const float *rv = second ? L.bn2_running_var : L.bn1_running_var;
+  const float *wt = second ? L.bn2_weight : L.bn1_weight;
+  const float *bs = second ? L.bn2_bias : L.bn1_bias;
+  float *o = norms + (size_t)blockIdx.x * 384;
+  o[c] = rm[c];
+  o[128 + c] = wt[c] / sqrtf(rv[c] + 1e-5f);
+  o[256 + c] = bs[c];
+}
+
+// Train mode: normalise with the batch statistics (biased variance, eps 1e-5) gathered by
+// bn_stats_kernel; block 0 also updates the running statistics (momentum 0.1, unbiased
+// variance) and num_batches_tracked, like nn.BatchNorm1d.
+__global__ __launch_bounds__(256) void bn_train_apply_kernel(
+    float *__restrict__ x, size_t n4, const double *__restrict__ stats, int rows,
+    const float *__restrict__ weight, const float *__restrict__ bias, float *running_mean,
+    float *running_var, int64_t *num_batches_tracked) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 128) {
+    const int c = threadIdx.x;
     const double m = stats[c] / rows;
     double v = stats[128 + c] / rows - m * m;
     if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
     const float unbiased = (float)(v * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
-    running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
+    running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)m;
     running_var[c] = 0.9f * running_var[c] + 0.1f * unbiased;
     if (c == 0) *num_batches_tracked += 1;
-  } else {
-    mean = running_mean[c];
-    var = running_var[c];
   }
-  norm[c] = mean;
-  norm[128 + c] = weight[c] / sqrtf(var + 1e-5f);
-  norm[256 + c] = bias[c];
-}
-
-__global__ __launch_bounds__(256) void bn_apply_kernel(float *__restrict__ x, size_t n4,
-                                                       const float *__restrict__ norm) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const int c = (int)(i & 31) * 4;
+  const int c0 = (int)(i & 31) * 4;
   float4 v = reinterpret_cast<float4 *>(x)[i];
-  v.x = (v.x - norm[c]) * norm[128 + c] + norm[256 + c];
-  v.y = (v.y - norm[c + 1]) * norm[129 + c] + norm[257 + c];
-  v.z = (v.z - norm[c + 2]) * norm[130 + c] + norm[258 + c];
-  v.w = (v.w - norm[c + 3]) * norm[131 + c] + norm[259 + c];
-  reinterpret_cast<float4 *>(x)[i] = v;
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const double m = stats[c] / rows;
+    double var = stats[128 + c] / rows - m * m;
+    if (var < 0.0) var = 0.0;
+    o[j] = (o[j] - (float)m) * (weight[c] / sqrtf((float)var + 1e-5f)) + bias[c];
+  }
+  reinterpret_cast<float4 *>(x)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 struct EncWs {
-  float *h0, *h1, *qkv, *att, *ff, *norm;
+  float *h0, *h1, *qkv, *att, *ff, *norm;  // norm: (16,384) eval-mode BN affines
   double *stats;
 };
 
@@ -162,7 +174,7 @@ static EncWs carve_encoder(void *ws, int B, int N, int hidden) {
   w.qkv = (float *)p;  p += vrp_align_up(R * 384 * 4);
   w.att = (float *)p;  p += vrp_align_up(R * 128 * 4);
   w.ff = (float *)p;   p += vrp_align_up(R * (size_t)hidden * 4);
-  w.norm = (float *)p; p += vrp_align_up(384 * 4);
+  w.norm = (float *)p; p += vrp_align_up(16 * 384 * 4);
   w.stats = (double *)p;
   return w;
 }
@@ -171,29 +183,24 @@ extern "C" int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden) {
   const size_t R = (size_t)B * N;
   // + feature scratch used by vrp_rollout: x (R,3) fp32 and is_depot (R) u8
   return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
-                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(384 * 4) +
+                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(16 * 384 * 4) +
                    vrp_align_up(256 * 8) + vrp_align_up(R * 12) + vrp_align_up(R));
 }
 
-static int batchnorm(float *x, int rows, int train, const float *w, const float *b, float *rm,
-                     float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
-  if (train) {
-    if (hipMemsetAsync(ws.stats, 0, 256 * sizeof(double), st) != hipSuccess) {
-      vrp_set_error("bn: memset failed");
-      return 1;
-    }
-    int blocks = (rows + 1) / 2;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);
-    VRP_CHECK_LAUNCH("bn_stats");
+static int batchnorm_train(float *x, int rows, const float *w, const float *b, float *rm,
+                           float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
+  if (hipMemsetAsync(ws.stats, 0, 256 * sizeof(double), st) != hipSuccess) {
+    vrp_set_error("bn: memset failed");
+    return 1;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(128), 0, st, ws.stats, rows, train, w, b,
-                     rm, rv, nbt, ws.norm);
-  VRP_CHECK_LAUNCH("bn_finalize");
+  int blocks = (rows + 1) / 2;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);
+  VRP_CHECK_LAUNCH("bn_stats");
   const size_t n4 = (size_t)rows * 32;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, n4,
-                     ws.norm);
-  VRP_CHECK_LAUNCH("bn_apply");
+  hipLaunchKernelGGL(bn_train_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                     x, n4, ws.stats, rows, w, b, rm, rv, nbt);
+  VRP_CHECK_LAUNCH("bn_train_apply");
   return 0;
 }
 
@@ -215,6 +222,11 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
                      w->node_embed_weight, w->node_embed_bias, w->node_dim,
                      w->depot_embed_weight, w->depot_embed_bias, w->depot_dim, cur, R);
   VRP_CHECK_LAUNCH("embed");
+  if (!train) {
+    hipLaunchKernelGGL(bn_eval_norms_kernel, dim3(2 * w->num_layers), dim3(128), 0, st, *w,
+                       ws.norm);
+    VRP_CHECK_LAUNCH("bn_eval_norms");
+  }
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
     // out = bn1(x + MHA(x))
@@ -223,18 +235,22 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
     const size_t lds = (size_t)4 * N * 32 * sizeof(float);
     hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
     VRP_CHECK_LAUNCH("encoder_attention");
-    if (int r = vrp_launch_gemm_nt(ws.att, 128, L.out_proj_weight, 128, L.out_proj_bias, cur, 128,
-                                   ws.h1, 128, R, 128, 128, 0, st)) return r;
-    if (int r = batchnorm(ws.h1, R, train, L.bn1_weight, L.bn1_bias, L.bn1_running_mean,
-                          L.bn1_running_var, L.bn1_num_batches_tracked, ws, st)) return r;
+    if (int r = vrp_launch_gemm_nt_ex(ws.att, 128, L.out_proj_weight, 128, L.out_proj_bias, cur,
+                                      128, train ? nullptr : ws.norm + (2 * l) * 384, ws.h1, 128,
+                                      R, 128, 128, 0, st)) return r;
+    if (train)
+      if (int r = batchnorm_train(ws.h1, R, L.bn1_weight, L.bn1_bias, L.bn1_running_mean,
+                                  L.bn1_running_var, L.bn1_num_batches_tracked, ws, st)) return r;
     // out = bn2(out + FF(out))
     if (int r = vrp_launch_gemm_nt(ws.h1, 128, L.ff0_weight, 128, L.ff0_bias, nullptr, 0, ws.ff,
                                    w->hidden, R, w->hidden, 128, 1, st)) return r;
     nxt = (cur == emb) ? ws.h0 : emb;
-    if (int r = vrp_launch_gemm_nt(ws.ff, w->hidden, L.ff2_weight, w->hidden, L.ff2_bias, ws.h1,
-                                   128, nxt, 128, R, 128, w->hidden, 0, st)) return r;
-    if (int r = batchnorm(nxt, R, train, L.bn2_weight, L.bn2_bias, L.bn2_running_mean,
-                          L.bn2_running_var, L.bn2_num_batches_tracked, ws, st)) return r;
+    if (int r = vrp_launch_gemm_nt_ex(ws.ff, w->hidden, L.ff2_weight, w->hidden, L.ff2_bias,
+                                      ws.h1, 128, train ? nullptr : ws.norm + (2 * l + 1) * 384,
+                                      nxt, 128, R, 128, w->hidden, 0, st)) return r;
+    if (train)
+      if (int r = batchnorm_train(nxt, R, L.bn2_weight, L.bn2_bias, L.bn2_running_mean,
+                                  L.bn2_running_var, L.bn2_num_batches_tracked, ws, st)) return r;
     cur = nxt;
   }
   if (cur != emb) {  // defensive: cannot happen with the parity choice above

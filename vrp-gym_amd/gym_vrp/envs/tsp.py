@@ -222,9 +222,32 @@ class TSPEnv(GymEnv):
                 new.__dict__[k] = v.clone()
             elif k in ("_lib", "_torch", "vid", "_last_rollout"):
                 new.__dict__[k] = v
+            elif k in ("_twin_env", "_graph_sightings"):
+                continue
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
+
+    def twin(self):
+        """A second env holding the same instances and state, for the baseline rollout
+        (the reference deep-copies the env every step, graph_tsp_agent.py:248).  The twin
+        object and its device tensors are reused across calls, so captured hipGraphs of
+        the baseline rollout stay valid; only the contents are refreshed."""
+        tw = self.__dict__.get("_twin_env")
+        if tw is None:
+            tw = copy.deepcopy(self)
+            self.__dict__["_twin_env"] = tw
+            return tw
+        t = self._torch
+        for k, v in self.__dict__.items():
+            if k in ("_twin_env", "_graph_sightings"):
+                continue
+            if isinstance(v, t.Tensor):
+                tw.__dict__[k].copy_(v)
+            elif k not in ("_lib", "_torch", "vid"):
+                tw.__dict__[k] = v if k in ("sampler", "depots", "demands", "draw_idxs") \
+                    else copy.copy(v)
+        return tw
 
     def render(self, mode: str = "human"):
         return self.sampler.draw(self.draw_idxs)
