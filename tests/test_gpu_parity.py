@@ -425,3 +425,63 @@ def test_graph_replay_equals_eager():
             runtime.rollout(agent.model, env, True, train=True)
     nb1 = int(agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item())
     assert nb1 - nb0 == 3
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_training_step_against_reference(kind):
+    """One REINFORCE step (agent.step(env,(False,True)) + backward) on the reference's
+    inputs: sampled actions identical (host noise = the reference's CPU stream), loss and
+    per-parameter gradient norms as the reference computed them (tests/golden/trainstep_*)."""
+    z = np.load(os.path.join(G, f"trainstep_k{kind}.npz"))
+    B, N = int(z["B"]), int(z["N"])
+    agent = _agents()[kind](seed=69)
+    env = _envs()[kind](N, B, 1, 69)
+    agent.model.train()
+    agent.model.sampling_noise = agent.target_model.sampling_noise = "host"
+    torch.manual_seed(int(z["torch_seed"]))
+    loss_m, loss_b, logp = agent.step(env, (False, True))
+    assert np.max(np.abs(loss_m.detach().cpu().numpy() - z["loss_m"])) < TOL
+    assert np.max(np.abs(loss_b.cpu().numpy() - z["loss_b"])) < TOL
+    assert np.max(np.abs(logp.detach().cpu().numpy() - z["logp"])) < 5 * TOL
+    adv = (loss_m - loss_b) * -1
+    loss = (adv * logp).mean()
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    agent.opt.zero_grad()
+    loss.backward()
+    got = {k: (p.grad.norm().item() if p.grad is not None else -1.0)
+           for k, p in agent.model.named_parameters()}
+    for k, want in zip(z["grad_keys"], z["grad_norms"]):
+        g = got[str(k)]
+        if want < 0:
+            assert g < 0, f"{k} must not receive a gradient"
+        else:
+            assert abs(g - want) <= 2e-3 * max(want, 1e-3), (str(k), g, float(want))
+    tot = np.sqrt(sum(v * v for v in got.values() if v >= 0))
+    assert abs(tot - float(z["grad_total"])) < 1e-3 * float(z["grad_total"])
+    nb = agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item()
+    assert nb == 1  # exactly one train-mode encoder pass per step, like the reference
+    agent.opt.step()
+
+
+def test_train_loop_csv_and_checkpoints(tmp_path):
+    """TSPAgent.train end to end on the GPU: CSV schema, finite losses, baseline update,
+    checkpoint cadence (graph_tsp_agent.py:150-225)."""
+    import csv
+    import agents
+    from gym_vrp.envs import VRPEnv
+    env = VRPEnv(num_nodes=10, batch_size=32, seed=3)
+    agent = agents.VRPAgent(seed=3, csv_path=str(tmp_path / "log.csv"))
+    w0 = agent.model.decoder._kp.weight.detach().clone()
+    agent.train(env, epochs=3, check_point_dir=str(tmp_path / "ckpt") + "/")
+    rows = list(csv.reader(open(tmp_path / "log.csv")))
+    assert rows[0] == ["Epoch", "Loss", "Cost", "Advantage", "Time"] and len(rows) == 4
+    assert all(np.isfinite(float(v)) for r in rows[1:] for v in r)
+    assert not torch.equal(w0, agent.model.decoder._kp.weight.detach())
+    assert os.path.isdir(tmp_path / "ckpt")
+    agent.save_model(50, str(tmp_path / "ckpt") + "/")
+    sd = torch.load(tmp_path / "ckpt" / "model_epoch_50.pt", map_location="cpu")
+    assert list(sd.keys()) == list(agent.model.state_dict().keys())
+    fresh = agents.VRPAgent(seed=4)
+    fresh.model.load_state_dict(sd)
+    loss = fresh.evaluate(VRPEnv(num_nodes=10, batch_size=8, seed=1))
+    assert loss.shape == (8,) and torch.isfinite(loss).all()
