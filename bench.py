@@ -40,6 +40,16 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+            return json.load(fh)["workloads"][workload]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def algorithmic_bytes_per_step(B, N):
     """bytes(B,N) = B*(523*N + 72) per decode+env step."""
     return B * (523 * N + 72)
@@ -157,7 +167,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
     achieved = byts / avg / 1e9
     return {"bound": "hbm", "kernel": "decode_step_kernel", "workload": f"kind{kind}_N{N}_B{B}",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(f"kind{kind}_N{N}_B{B}"),
             "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
             "launches_timed": len(durs),
             "loop_us_per_launch": round(float(np.mean(loops)) * 1e6, 3)}

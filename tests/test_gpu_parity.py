@@ -410,19 +410,33 @@ def test_graph_replay_equals_eager():
         ref_env = deepcopy(env)
         with torch.no_grad():
             eager = runtime.rollout(agent.model, ref_env, True, use_graph=False)
-            got = runtime.rollout(agent.model, env, True)
+            got = runtime.rollout(agent.model, env, True, use_graph=True)
         assert torch.equal(eager.acc_loss, got.acc_loss), rep
         assert eager.T == got.T
         assert np.array_equal(env.visited, ref_env.visited)
     loss, loss_b, _ = agent.step(env, [True, True])
     assert torch.equal(loss, loss_b)  # same weights, same instances
+    # many replays, with and without a sync in between (a captured hipMemsetAsync node
+    # used to race with the first step kernels: the accumulators are now zeroed by a kernel)
+    from gym_vrp.envs import TSPEnv
+    env2 = TSPEnv(20, 512, 1, 69)
+    ag2 = agents.TSPAgent(seed=69)
+    ag2.model.eval()
+    with torch.no_grad():
+        want = runtime.rollout(ag2.model, deepcopy(env2), True, use_graph=False).acc_loss
+        for rep in range(40):
+            env2._visited.zero_(); env2._cur.copy_(env2._depot); env2._mask_fresh = False
+            got = runtime.rollout(ag2.model, env2, True, use_graph=True)
+            if rep % 2:
+                torch.cuda.synchronize()
+            assert torch.equal(got.acc_loss, want), rep
     # train-mode replays keep updating the BN running statistics once per rollout
     agent.model.train()
     nb0 = int(agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item())
     for rep in range(3):
         env.reset()
         with torch.no_grad():
-            runtime.rollout(agent.model, env, True, train=True)
+            runtime.rollout(agent.model, env, True, train=True, use_graph=True)
     nb1 = int(agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item())
     assert nb1 - nb0 == 3
 

@@ -23,6 +23,16 @@ static void feature_scratch(void *enc_ws, int B, int N, int hidden, float **x, u
   *isd = (uint8_t *)(p + vrp_align_up(R * 12));
 }
 
+// Episode accumulators := 0.  A kernel rather than hipMemsetAsync: memset nodes inside a
+// captured hipGraph were observed to race with the kernels that follow them (ROCm 7.0
+// runtime bundled with torch 2.10), kernels keep stream order.
+__global__ void rollout_init_kernel(float *acc_loss, float *acc_logp, int32_t *notdone, int B,
+                                    int nflags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { acc_loss[i] = 0.f; acc_logp[i] = 0.f; }
+  if (i < nflags) notdone[i] = 0;
+}
+
 extern "C" int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,
                                  const vrp_env *env, const float *emb, void *dec_workspace,
                                  const vrp_rollout_io *io, int max_steps, int flags,
@@ -30,12 +40,10 @@ extern "C" int vrp_rollout_steps(int kind, const void *derived, const vrp_decode
   VRP_REQUIRE(io && io->acc_loss && io->acc_logp && io->notdone, "rollout: io NULL");
   hipStream_t st = (hipStream_t)stream;
   const int B = env->B;
-  if (hipMemsetAsync(io->acc_loss, 0, sizeof(float) * B, st) != hipSuccess ||
-      hipMemsetAsync(io->acc_logp, 0, sizeof(float) * B, st) != hipSuccess ||
-      hipMemsetAsync(io->notdone, 0, sizeof(int32_t) * (max_steps + 1), st) != hipSuccess) {
-    vrp_set_error("rollout: memset failed");
-    return 1;
-  }
+  const int n = (B > max_steps + 1) ? B : max_steps + 1;
+  hipLaunchKernelGGL(rollout_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, io->acc_loss,
+                     io->acc_logp, io->notdone, B, max_steps + 1);
+  VRP_CHECK_LAUNCH("rollout_init");
   for (int t = 0; t < max_steps; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,
                                 flags, stream))

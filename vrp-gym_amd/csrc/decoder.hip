@@ -368,7 +368,7 @@ __device__ __forceinline__ void flag_notdone(int32_t *flag) {
 
 // ------------------------------------------------------------------ the step kernel
 struct StepParams {
-  int kind, B, N, t, max_steps, sample, decode_only;
+  int kind, B, N, t, max_steps, sample, decode_only, fence;
   const float *emb;
   const float *SG, *C0, *SLD, *SF, *SL;
   float *base1, *curs;
@@ -711,6 +711,7 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
   const bool inN = lane < N;
   const int ln = inN ? lane : 0;
 
+  if (p.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // ---- entry: issue every action-independent load --------------------------------
   const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
   const int own_mask = mask_in[(size_t)b * N + ln];
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
     if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
     if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
   }
+  if (p.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 template <int NMAX>
@@ -934,6 +936,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   StepParams p;
   p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps; p.sample = sample;
   p.decode_only = decode_only;
+  { static const char *e = getenv("VRP_FENCE"); p.fence = e ? atoi(e) : 0; }
   p.emb = emb;
   p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SF = ws.SF; p.SL = ws.SL;
   p.base1 = (kind == VRP_KIND_IRP) ? ws.SG : ws.base1;

@@ -187,12 +187,12 @@ extern "C" int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden) {
                    vrp_align_up(256 * 8) + vrp_align_up(R * 12) + vrp_align_up(R));
 }
 
+__global__ void bn_zero_stats_kernel(double *stats) { stats[threadIdx.x] = 0.0; }
+
 static int batchnorm_train(float *x, int rows, const float *w, const float *b, float *rm,
                            float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
-  if (hipMemsetAsync(ws.stats, 0, 256 * sizeof(double), st) != hipSuccess) {
-    vrp_set_error("bn: memset failed");
-    return 1;
-  }
+  hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, ws.stats);
+  VRP_CHECK_LAUNCH("bn_zero_stats");
   int blocks = (rows + 1) / 2;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);

@@ -5,30 +5,63 @@
 // (agents/graph_encoder.py:170-181) and the decoder's per-episode projections
 // (agents/graph_decoder.py:83,94).
 //
-// Tile: BM x 128 per 256-thread workgroup (BM = 128 or 64), BK = 32; the 4 waves sit
+// Tile: BM x 128 per 256-thread workgroup, (BM,BK) = (128,32) or (64,64); the 4 waves sit
 // 2x2 and own (BM/2) x 64 each as MFMA 32x32 accumulators.  LDS rows are padded to 33
-// floats so the per-lane fragment reads (lane -> row, fixed k) are bank-conflict free.
-// The next K-tile is fetched into registers while the current one feeds the MFMAs.
+// floats... (see slot() below).  Two LDS buffers: the next K-tile is fetched into
+// registers while the current one feeds the MFMAs and staged into the other buffer,
+// one barrier per K-tile.
 // Epilogue (fused, in this order): + bias, + residual, BatchNorm affine
 // ((v - mean) * mult + beta, eval mode), ReLU.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BN 128
-#define BK 32
-#define LDT (BK + 1)
 
-template <int BM>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
+// LDS tile: float4 slots indexed (kq, row) -> kq*ROWS + (row ^ kq).  The XOR spreads the
+// eight kq values of one row over distinct 16-byte bank groups, so both the staging
+// writes (lanes along k) and the fragment reads (lanes along rows) are conflict-free
+// 128-bit accesses.
+__device__ __forceinline__ int slot(int kq, int row, int rows) { return kq * rows + (row ^ kq); }
+
+// RS = rows covered by one pass of the 256 threads (256 / (BK/4) lanes along k)
+template <int AS, int WS, int RS>
+__device__ __forceinline__ void gemm_fetch(float4 (&av)[AS], float4 (&wv)[WS], const float *A,
+                                           int lda, const float *W, int ldw, int m0, int n0,
+                                           int lr, int lq, int k0, int M) {
+#pragma unroll
+  for (int s = 0; s < AS; ++s) {
+    const int r = m0 + lr + RS * s;
+    av[s] = (r < M) ? *reinterpret_cast<const float4 *>(A + (size_t)r * lda + k0 + 4 * lq)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int s = 0; s < WS; ++s)
+    wv[s] = *reinterpret_cast<const float4 *>(W + (size_t)(n0 + lr + RS * s) * ldw + k0 + 4 * lq);
+}
+template <int AS, int WS, int RS, int BM>
+__device__ __forceinline__ void gemm_stage(const float4 (&av)[AS], const float4 (&wv)[WS],
+                                           float4 *As, float4 *Ws, int lr, int lq) {
+#pragma unroll
+  for (int s = 0; s < AS; ++s) As[slot(lq, lr + RS * s, BM)] = av[s];
+#pragma unroll
+  for (int s = 0; s < WS; ++s) Ws[slot(lq, lr + RS * s, BN)] = wv[s];
+}
+
+template <int BM, int BK>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ R, int ldr,
     const float *__restrict__ norm, float *__restrict__ C, int ldc, int M, int N, int K,
     int relu) {
   constexpr int MI = BM / 64;   // 32-row MFMA tiles per wave along M
-  constexpr int AS = BM / 32;   // float4 loads per thread for the A tile
-  __shared__ float As[BM * LDT];
-  __shared__ float Ws[BN * LDT];
+  constexpr int KQ = BK / 4;    // float4 along k per row
+  constexpr int RS = 256 / KQ;  // rows staged per pass of the workgroup
+  constexpr int AS = BM / RS;   // float4 loads per thread for the A tile
+  constexpr int WS = BN / RS;   // ... and for the W tile
+  __shared__ float4 As[2][KQ * BM];
+  __shared__ float4 Ws[2][KQ * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -41,54 +74,45 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int lr = tid >> 3;        // 0..31  row within a 32-row slab
-  const int lk = (tid & 7) * 4;   // k offset of this thread's float4
-  float4 av[AS], wv[4];
+  const int lr = tid / KQ;   // row within an RS-row slab
+  const int lq = tid % KQ;   // kq of this thread's float4 (lanes run along k)
+  float4 av[AS], wv[WS];
 
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int s = 0; s < AS; ++s) {
-      const int r = m0 + lr + 32 * s;
-      av[s] = (r < M) ? *reinterpret_cast<const float4 *>(A + (size_t)r * lda + k0 + lk)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      wv[s] = *reinterpret_cast<const float4 *>(W + (size_t)(n0 + lr + 32 * s) * ldw + k0 + lk);
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int s = 0; s < AS; ++s) {
-      float *d = As + (lr + 32 * s) * LDT + lk;
-      d[0] = av[s].x; d[1] = av[s].y; d[2] = av[s].z; d[3] = av[s].w;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float *e = Ws + (lr + 32 * s) * LDT + lk;
-      e[0] = wv[s].x; e[1] = wv[s].y; e[2] = wv[s].z; e[3] = wv[s].w;
-    }
-  };
-
-  fetch(0);
+  gemm_fetch<AS, WS, RS>(av, wv, A, lda, W, ldw, m0, n0, lr, lq, 0, M);
+  gemm_stage<AS, WS, RS, BM>(av, wv, As[0], Ws[0], lr, lq);
+  __syncthreads();
   const int fr = lane & 31, fk = lane >> 5;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    stage();
+  const int nkt = K / BK;
+#define GEMM_COMPUTE(buf)                                                                     \
+  _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                         \
+    float4 a4[MI], b4[2];                                                                     \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                            \
+        a4[i] = As[buf][slot(kq, wm * (BM / 2) + i * 32 + fr, BM)];                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+        b4[j] = Ws[buf][slot(kq, wn * 64 + j * 32 + fr, BN)];                                 \
+    /* MFMA 32x32x2 wants A[row][k0+fk]: k-pair 0 = (x,y), k-pair 1 = (z,w) */                \
+    _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {                                        \
+      float a[MI], b[2];                                                                      \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
+          a[i] = pr ? (fk ? a4[i].w : a4[i].z) : (fk ? a4[i].y : a4[i].x);                    \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+          b[j] = pr ? (fk ? b4[j].w : b4[j].z) : (fk ? b4[j].y : b4[j].x);                    \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                         \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0); \
+    }                                                                                         \
+  }
+  for (int kt = 0; kt + 1 < nkt; ++kt) {
+    const int buf = kt & 1;
+    // next tile: in flight during the MFMA block, staged into the buffer nobody reads
+    gemm_fetch<AS, WS, RS>(av, wv, A, lda, W, ldw, m0, n0, lr, lq, (kt + 1) * BK, M);
+    GEMM_COMPUTE(buf)
+    gemm_stage<AS, WS, RS, BM>(av, wv, As[buf ^ 1], Ws[buf ^ 1], lr, lq);
     __syncthreads();
-    if (k0 + BK < K) fetch(k0 + BK);  // in flight during the MFMA block below
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[MI], b[2];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = As[(wm * (BM / 2) + i * 32 + fr) * LDT + kk + fk];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Ws[(wn * 64 + j * 32 + fr) * LDT + kk + fk];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
+  }
+  {
+    const int buf = (nkt - 1) & 1;
+    GEMM_COMPUTE(buf)
   }
 
   // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -120,19 +144,35 @@ int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, cons
                           const float *R, int ldr, const float *norm, float *C, int ldc, int M,
                           int N, int K, int relu, hipStream_t stream) {
   VRP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
-  VRP_REQUIRE(N % BN == 0 && K % BK == 0, "gemm: N=%d must be a multiple of %d and K=%d of %d",
-              N, BN, K, BK);
+  VRP_REQUIRE(N % BN == 0 && K % 64 == 0, "gemm: N=%d must be a multiple of %d and K=%d of 64",
+              N, BN, K);
   VRP_REQUIRE((lda % 4) == 0 && (ldw % 4) == 0, "gemm: lda/ldw must be multiples of 4");
   VRP_REQUIRE(!norm || N == 128, "gemm: fused BatchNorm needs N == 128");
   const long tiles128 = (long)(N / BN) * ((M + 127) / 128);
-  if (tiles128 >= 1024) {  // enough workgroups to fill 256 CUs several times over
+  static const char *force = getenv("VRP_GEMM_VARIANT");  // tuning aid: "64x32", "64x64", "128x32"
+  if (force && force[0] == '6') {
+    dim3 grid(N / BN, (M + 63) / 64);
+    if (force[3] == '3')
+      hipLaunchKernelGGL((gemm_nt_kernel<64, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw,
+                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, lda, W, ldw,
+                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+  } else if (tiles128 >= 1024 || (force && force[0] == '1')) {  // enough workgroups to fill 256 CUs
     dim3 grid(N / BN, (M + 127) / 128);
-    hipLaunchKernelGGL(gemm_nt_kernel<128>, grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, C, ldc, M, N, K, relu);
   } else {
+    // few workgroups: a workgroup's own latency is the kernel's duration.  Measured on
+    // MI355X at M = 10240 (tools/gemm_probe.py): K = 128 -> 64x128x32 tiles (3 workgroups
+    // per CU overlap each other's load latency), K >= 512 -> 64x128x64 (half the barriers).
     dim3 grid(N / BN, (M + 63) / 64);
-    hipLaunchKernelGGL(gemm_nt_kernel<64>, grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
-                       ldr, norm, C, ldc, M, N, K, relu);
+    if (K >= 512)
+      hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, lda, W, ldw,
+                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+    else
+      hipLaunchKernelGGL((gemm_nt_kernel<64, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw,
+                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
   }
   VRP_CHECK_LAUNCH("gemm_nt");
   return 0;
