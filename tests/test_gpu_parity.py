@@ -328,7 +328,7 @@ def test_rollout_against_reference(name, path, tile_kernel):
 ])
 def test_rollout_against_oracle(kind, B, N, greedy, train):
     _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train)
-    if N <= 64:
+    if N <= 104:  # the raw-tile kernel (opt-in flag) stays covered at every size it supports
         _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
 
 

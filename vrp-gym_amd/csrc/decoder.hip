@@ -170,7 +170,7 @@ struct DecWs {
   int32_t *last, *first;         // (B)
 };
 
-#define VRP_RT_MAX_N 64  // above this the tile kernel (one raw-tile read per step) is used
+#define VRP_RT_MAX_N 128  // above this the tile kernel (one raw-tile read per step) is used
 static bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 static int proj_width(int kind, int N) {
   return (kind == VRP_KIND_IRP ? 768 : 1152) + (use_rtable(N) ? 768 : 0);
@@ -288,27 +288,33 @@ __global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int 
 // (M_h^T e_m) . (Wv_h e_n + bv_h), so that u_m = sum_{h,n} a_{h,n} RT[m][h][n] + e_m.mb
 // (the folds of 3.1 carried one step further: no weight matrix is touched per step).
 // One wave per (graph, head); lane = n keeps VV_{h,n} (48 floats) in registers.
+template <int NPL>
 __global__ __launch_bounds__(256) void rtable_kernel(int N, int P, int kmoff,
                                                      const float *__restrict__ PROJ,
                                                      float *__restrict__ RT) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  float vv[VRP_HD];
-  {
-    const float *vp = PROJ + ((size_t)b * N + (lane < N ? lane : 0)) * P + kmoff + 384 + h * VRP_HD;
+  float vv[NPL][VRP_HD];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int n = lane + 64 * i;
+    const float *vp = PROJ + ((size_t)b * N + (n < N ? n : 0)) * P + kmoff + 384 + h * VRP_HD;
 #pragma unroll
     for (int d = 0; d < VRP_HD; d += 4) {
       float4 t = *reinterpret_cast<const float4 *>(vp + d);
-      vv[d] = t.x; vv[d + 1] = t.y; vv[d + 2] = t.z; vv[d + 3] = t.w;
+      vv[i][d] = t.x; vv[i][d + 1] = t.y; vv[i][d + 2] = t.z; vv[i][d + 3] = t.w;
     }
   }
   for (int m = 0; m < N; ++m) {
     const float *row = PROJ + ((size_t)b * N + m) * P + kmoff + h * VRP_HD;
-    float sacc = 0.f;
 #pragma unroll
-    for (int d = 0; d < VRP_HD; ++d) sacc = fmaf(row[d], vv[d], sacc);
-    if (lane < N) RT[(((size_t)b * N + m) * 8 + h) * N + lane] = sacc;
+    for (int i = 0; i < NPL; ++i) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int d = 0; d < VRP_HD; ++d) sacc = fmaf(row[d], vv[i][d], sacc);
+      if (lane + 64 * i < N) RT[(((size_t)b * N + m) * 8 + h) * N + lane + 64 * i] = sacc;
+    }
   }
 }
 
@@ -347,8 +353,12 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
                        w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
   VRP_CHECK_LAUNCH("score_tables");
   if (use_rtable(N)) {
-    hipLaunchKernelGGL(rtable_kernel, dim3(B, 2), dim3(256), 0, st, N, P,
-                       kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
+    if (N <= 64)
+      hipLaunchKernelGGL(rtable_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P,
+                         kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
+    else
+      hipLaunchKernelGGL(rtable_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P,
+                         kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
     VRP_CHECK_LAUNCH("rtable");
     hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
                        w.cvec);
@@ -693,10 +703,12 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
   return __ffsll((long long)bits) - 1;
 }
 
-__global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
-  __shared__ __attribute__((aligned(16))) float a_s[GPW][8 * VRP_RT_MAX_N];  // a[h][n], hn order
-  __shared__ __attribute__((aligned(16))) float u_s[GPW][VRP_RT_MAX_N];
-  __shared__ int sel_s[GPW][VRP_RT_MAX_N];  // compacted list of selectable nodes
+template <int NPL>  // nodes per lane: 1 (N <= 64) or 2 (N <= 128); node = lane + 64*i
+__global__ __launch_bounds__(256, (NPL == 1 ? 3 : 2)) void decode_step_rt_kernel(StepParams p) {
+  constexpr int NMAXL = 64 * NPL;
+  __shared__ __attribute__((aligned(16))) float a_s[GPW][8 * NMAXL];  // a[h][n], hn order
+  __shared__ __attribute__((aligned(16))) float u_s[GPW][NMAXL];
+  __shared__ int sel_s[GPW][NMAXL];  // compacted list of selectable nodes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N, B = p.B;
@@ -708,52 +720,69 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
   uint8_t *mask_out = p.env.mask + (size_t)(par ^ 1) * B * N;
   const int n4 = 2 * N;  // float4 per RT row (8N floats)
   const int rsl = lane >> 3, part = lane & 7;
-  const bool inN = lane < N;
-  const int ln = inN ? lane : 0;
+  bool inN[NPL];
+  int ln[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
 
   if (p.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   // ---- entry: issue every action-independent load --------------------------------
   const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
-  const int own_mask = mask_in[(size_t)b * N + ln];
   const size_t row = (size_t)b * 8 * N;
-  float sc[8], brow[8], sld[8];
-  int msk[8];
+  int own_mask[NPL];
+  float sc[NPL][8], brow[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
+  int msk[NPL][8];
+  double2 xy[NPL];
+  int vis[NPL];
+  double dem[NPL];
 #pragma unroll
-  for (int h = 0; h < 8; ++h) {
-    sc[h] = p.curs[row + h * N + ln];
-    brow[h] = (p.t == 0 ? p.SG : p.base1)[row + h * N + ln];
-    sld[h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln] : 0.f;
-    msk[h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln];  // QUIRK D3: other graphs' rows
-  }
-  const float cv = p.cvec[(size_t)b * N + ln];
-  // env row (lane = node)
-  double2 xy = make_double2(0.0, 0.0);
-  int vis = 1;
-  double dem = 0.0;
-  if (!p.decode_only) {
-    xy = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln];
-    if (inN) vis = p.env.visited[(size_t)b * N + ln];
-    if (p.kind == VRP_KIND_IRP) dem = p.env.demand[(size_t)b * N + ln];
+  for (int i = 0; i < NPL; ++i) {
+    own_mask[i] = mask_in[(size_t)b * N + ln[i]];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      sc[i][h] = p.curs[row + h * N + ln[i]];
+      brow[i][h] = (p.t == 0 ? p.SG : p.base1)[row + h * N + ln[i]];
+      sld[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
+      msk[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
+    }
+    cv[i] = p.cvec[(size_t)b * N + ln[i]];
+    xy[i] = make_double2(0.0, 0.0);
+    vis[i] = 1;
+    dem[i] = 0.0;
+    if (!p.decode_only) {  // env row (lane = node)
+      xy[i] = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln[i]];
+      if (inN[i]) vis[i] = p.env.visited[(size_t)b * N + ln[i]];
+      if (p.kind == VRP_KIND_IRP) dem[i] = p.env.demand[(size_t)b * N + ln[i]];
+    }
+    q_noise[i] = p.sample ? p.io.noise[((size_t)p.t * B + b) * N + ln[i]] : 1.f;
   }
   const int cur = p.decode_only ? 0 : p.env.cur[b];
   const int dep = p.decode_only ? 0 : p.env.depot[b];
   const double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
   float accl = 0.f, accp = 0.f;
   if (!p.decode_only) { accl = p.io.acc_loss[b]; accp = p.io.acc_logp[b]; }
-  float q_noise = 1.f;
-  if (p.sample) q_noise = p.io.noise[((size_t)p.t * B + b) * N + ln];
 
   // selectable nodes (own mask == 0); their RT rows are the only ones fetched
-  const bool selectable = inN && !own_mask;
-  const unsigned long long sel = __ballot(selectable);
-  const int nsel = __popcll(sel);
-  if (selectable) sel_s[wave][__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+  unsigned long long sel[NPL];
+  int nsel = 0;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const bool s_i = inN[i] && !own_mask[i];
+    sel[i] = __ballot(s_i);
+    if (s_i) sel_s[wave][nsel + __popcll(sel[i] & ((1ull << lane) - 1ull))] = lane + 64 * i;
+    nsel += __popcll(sel[i]);
+  }
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
   const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
   float4 ra[RT_U], rb[RT_U];
-  const int m_first = (rsl < nsel) ? kth_set_bit(sel, rsl) : -1;  // pass 0 rows (k < 8)
+  int m_first = -1;  // pass 0 rows (k = rsl < 8)
+  if (rsl < nsel) {
+    const int c0 = __popcll(sel[0]);
+    m_first = (NPL == 1 || rsl < c0) ? kth_set_bit(sel[0], rsl)
+                                     : 64 + kth_set_bit(sel[NPL - 1], rsl - c0);
+  }
   int m_a = m_first, m_b = -1;
   rt_load(ra, rtb + (size_t)(m_a < 0 ? 0 : m_a) * n4, 0, cnt, m_a >= 0);
 
@@ -762,13 +791,22 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
     const float loadf = (float)load0;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      float s = sc[h];
-      if (p.kind == VRP_KIND_IRP) s = fmaf(loadf, sld[h], s);
-      s = inN ? s + (float)msk[h] : -INFINITY;
-      const float m = wave_max(s);
-      const float e = inN ? expf(s - m) : 0.f;
-      const float sum = wave_sum(e);
-      if (inN) a_s[wave][h * N + lane] = e / sum;
+      float s[NPL], mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        s[i] = sc[i][h];
+        if (p.kind == VRP_KIND_IRP) s[i] = fmaf(loadf, sld[i][h], s[i]);
+        s[i] = inN[i] ? s[i] + (float)msk[i][h] : -INFINITY;
+        mx = fmaxf(mx, s[i]);
+      }
+      const float m = wave_max(mx);
+      float e[NPL], es = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? expf(s[i] - m) : 0.f; es += e[i]; }
+      const float sum = wave_sum(es);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+        if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i] / sum;
     }
   }
   __syncthreads();
@@ -802,27 +840,64 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
   }
   __syncthreads();
 
-  float u = -INFINITY;
-  if (inN && !own_mask) u = 10.f * tanhf(u_s[wave][lane] + cv);  // graph_decoder.py:97-98
-  if (active && p.io.logits && inN) p.io.logits[((size_t)p.t * B + b) * N + lane] = u;
+  float u[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    u[i] = -INFINITY;
+    if (inN[i] && !own_mask[i])
+      u[i] = 10.f * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
+    if (active && p.io.logits && inN[i])
+      p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
+  }
+
+  // lowest node index among the maxima (torch CPU argmax): slot 0 holds nodes < 64
+  auto argmax_nodes = [&](const float (&v)[NPL]) {
+    float mx = v[0];
+#pragma unroll
+    for (int i = 1; i < NPL; ++i) mx = fmaxf(mx, v[i]);
+    const float m = wave_max(mx);
+    int res = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const unsigned long long hit = __ballot(v[i] == m);
+      if (!found && hit) { res = 64 * i + __ffsll((long long)hit) - 1; found = true; }
+    }
+    return res;
+  };
 
   int idx;
   float logp = 0.f;
   if (!p.sample) {
-    idx = wave_argmax_lane(u);
+    idx = argmax_nodes(u);
     if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
   } else {
     // Categorical(logits=u): logits - logsumexp, probs = softmax, sample = argmax(p/q)
-    const float m = wave_max(u);
-    const float se = wave_sum(expf(u - m));
-    const float l = u - (m + logf(se));
-    const float lm = wave_max(l);
-    const float pe = expf(l - lm);
-    const float ps = wave_sum(pe);
-    const float ratio = inN ? (pe / ps) / q_noise : -1.f;
-    idx = wave_argmax_lane(ratio);
+    float mx = u[0];
+#pragma unroll
+    for (int i = 1; i < NPL; ++i) mx = fmaxf(mx, u[i]);
+    const float m = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) se += expf(u[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    float l[NPL], lmx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { l[i] = u[i] - lse; lmx = fmaxf(lmx, l[i]); }
+    const float lm = wave_max(lmx);
+    float pe[NPL], ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { pe[i] = expf(l[i] - lm); ps += pe[i]; }
+    ps = wave_sum(ps);
+    float ratio[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) ratio[i] = inN[i] ? (pe[i] / ps) / q_noise[i] : -1.f;
+    idx = argmax_nodes(ratio);
     if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
-    logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), idx));
+    const float lsel = (NPL > 1 && idx >= 64) ? l[NPL - 1] : l[0];
+    logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lsel),
+                                                               idx & 63));
   }
   idx = __builtin_amdgcn_readfirstlane(idx);
   if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
@@ -832,21 +907,25 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
   //   curs  = base1 + SL[last = idx]
   {
     const size_t arow = ((size_t)b * N + idx) * 8 * N;
-    float sl[8], sf[8];
     const bool newbase = (p.t == 0 && p.kind != VRP_KIND_IRP);
+    float sl[NPL][8], sf[NPL][8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      sl[h] = p.SL[arow + h * N + ln];
-      sf[h] = newbase ? p.SF[arow + h * N + ln] : 0.f;
-    }
+    for (int i = 0; i < NPL; ++i)
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const float b1 = brow[h] + sf[h];
-      if (inN) {
-        if (newbase) p.base1[row + h * N + lane] = b1;
-        p.curs[row + h * N + lane] = b1 + sl[h];
+      for (int h = 0; h < 8; ++h) {
+        sl[i][h] = p.SL[arow + h * N + ln[i]];
+        sf[i][h] = newbase ? p.SF[arow + h * N + ln[i]] : 0.f;
       }
-    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const float b1 = brow[i][h] + sf[i][h];
+        if (inN[i]) {
+          if (newbase) p.base1[row + h * N + lane + 64 * i] = b1;
+          p.curs[row + h * N + lane + 64 * i] = b1 + sl[i][h];
+        }
+      }
   }
   if (p.decode_only) {
     if (lane == 0) {
@@ -859,25 +938,48 @@ __global__ __launch_bounds__(256, 3) void decode_step_rt_kernel(StepParams p) {
   }
 
   // ---- env.step on registers (same operation order as env_device.h) -------------------
-  if (lane == idx) vis = 1;                                   // tsp.py:86
-  const double ax = readlane_f64(xy.x, idx), ay = readlane_f64(xy.y, idx);
-  const double cx = readlane_f64(xy.x, cur), cy = readlane_f64(xy.y, cur);
-  const double dx = cx - ax, dy = cy - ay;
+  auto node_f64 = [&](const double (&v)[NPL], int n) {
+    return (NPL > 1 && n >= 64) ? readlane_f64(v[NPL - 1], n - 64) : readlane_f64(v[0], n);
+  };
+  double px[NPL], py[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { px[i] = xy[i].x; py[i] = xy[i].y; }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) if (lane + 64 * i == idx) vis[i] = 1;  // tsp.py:86
+  const double dx = node_f64(px, cur) - node_f64(px, idx);
+  const double dy = node_f64(py, cur) - node_f64(py, idx);
   const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
   double load = 1.0;
   if (p.kind == VRP_KIND_IRP) {                               // irp.py:80-86
-    load = load0 - readlane_f64(dem, idx);
+    load = load0 - node_f64(dem, idx);
     if (idx == dep) load = 1.0;
   }
-  const bool done = __all(vis);                               // before the fix-ups, tsp.py:95
-  if (idx == dep) { if (lane == dep) vis = 1; }               // tsp.py:141-142
-  else if (p.kind != VRP_KIND_TSP) { if (lane == dep) vis = 0; }  // vrp.py:28-31
-  if (__all(vis)) { if (lane == dep) vis = 0; }               // tsp.py:145-146
-  int mk = vis;
-  if (p.kind == VRP_KIND_IRP && inN && dem - load > 0.0) mk = 1;  // irp.py:151-153
-  if (inN) {
-    p.env.visited[(size_t)b * N + lane] = (uint8_t)vis;
-    mask_out[(size_t)b * N + lane] = (uint8_t)mk;
+  auto all_visited = [&]() {
+    int ok = 1;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) ok &= vis[i];
+    return __all(ok);
+  };
+  const bool done = all_visited();                            // before the fix-ups, tsp.py:95
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    if (lane + 64 * i == dep) {
+      if (idx == dep) vis[i] = 1;                             // tsp.py:141-142
+      else if (p.kind != VRP_KIND_TSP) vis[i] = 0;            // vrp.py:28-31
+    }
+  }
+  if (all_visited()) {                                        // tsp.py:145-146
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) if (lane + 64 * i == dep) vis[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    int mk = vis[i];
+    if (p.kind == VRP_KIND_IRP && inN[i] && dem[i] - load > 0.0) mk = 1;  // irp.py:151-153
+    if (inN[i]) {
+      p.env.visited[(size_t)b * N + lane + 64 * i] = (uint8_t)vis[i];
+      mask_out[(size_t)b * N + lane + 64 * i] = (uint8_t)mk;
+    }
   }
   if (lane == 0) {
     p.env.cur[b] = idx;
@@ -930,7 +1032,9 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   VRP_REQUIRE(!sample || io->noise, "decode_step: sampling needs io.noise");
   VRP_REQUIRE(t >= 0 && t < max_steps, "decode_step: t=%d outside [0,%d)", t, max_steps);
   const int B = env->B, N = env->N;
-  VRP_REQUIRE(N >= 2 && N <= 104, "decode_step: N=%d unsupported (2..104)", N);
+  VRP_REQUIRE(N >= 2 && N <= VRP_MAX_NODES, "decode_step: N=%d unsupported (2..%d)", N, VRP_MAX_NODES);
+  VRP_REQUIRE(use_rtable(N) || N <= 104, "decode_step: tile kernel supports N <= 104");
+  VRP_REQUIRE(!(flags & VRP_STEP_TILE_KERNEL) || N <= 104, "decode_step: tile kernel supports N <= 104");
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs ws = carve_decws(kind, workspace, B, N);
   StepParams p;
@@ -948,7 +1052,10 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.io = *io;
   hipStream_t st = (hipStream_t)stream;
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
-    hipLaunchKernelGGL(decode_step_rt_kernel, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
+    if (N <= 64)
+      hipLaunchKernelGGL(decode_step_rt_kernel<1>, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL(decode_step_rt_kernel<2>, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
     VRP_CHECK_LAUNCH("decode_step_rt");
     return 0;
   }
