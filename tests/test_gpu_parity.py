@@ -261,40 +261,54 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
                               noise_mode="host", tile_kernel=tile_kernel)
     T = res.T
     acts = res.actions[:T].cpu().numpy()
-    want_acts = ref_actions if ref_actions is not None else oacts
-    want_T = ref_T if ref_T is not None else oT
-    exempt = np.zeros(B, bool)
-    for b in range(B):
-        for t in range(min(T, len(want_acts))):
-            if acts[t, b] != want_acts[t, b]:
-                # legitimate only at a near tie of the oracle's own logits at that step
-                # (teacher-forced oracle logits along the HIP path are checked below)
-                exempt[b] = True
-                break
-    if exempt.any() or T != want_T:
-        # teacher-forced: oracle follows the HIP actions; every divergence must be a near tie
-        trace2 = []
+
+    def diverged(want):
+        out = {}
+        for b in range(B):
+            for t in range(min(T, len(want))):
+                if acts[t, b] != want[t, b]:
+                    out[b] = t
+                    break
+        return out
+
+    div_oracle = diverged(oacts)
+    forced_trace = trace
+    if div_oracle or T != oT:
+        # the oracle follows the HIP actions; every divergence must sit on a near tie of the
+        # oracle's own logits at that step
+        forced_trace = []
         torch.manual_seed(torch_seed)
         with torch.no_grad():
-            ol, olp, oT2 = opol.rollout(sd, deepcopy(oe), greedy, train=train, trace=trace2,
-                                        forced=acts)
+            ol, olp, oT2 = opol.rollout(sd, deepcopy(oe), greedy, train=train,
+                                        trace=forced_trace, forced=acts)
         assert oT2 == T
-        if greedy:
-            for b in np.flatnonzero(exempt):
-                t = next(t for t in range(T) if acts[t, b] != want_acts[t, b])
-                u = trace2[t]["u"][b] if t < len(trace2) else None
-                top = torch.sort(u, descending=True).values
-                assert (top[0] - u[acts[t, b]]).item() < TIE_GAP, (b, t, top[:3], acts[t, b])
-        assert exempt.sum() <= max(1, B // 50), f"{exempt.sum()} of {B} graphs diverged"
-    else:
-        assert T == want_T
+    div_ref = diverged(ref_actions) if ref_actions is not None else {}
+    if greedy:
+        # Along the HIP action path the oracle must agree with every HIP choice up to a
+        # near tie.  (A graph may also leave the free-running oracle's path WITHOUT a tie of
+        # its own: the scrambled glimpse mask couples it to graphs that flipped earlier.)
+        U = torch.stack([st["u"] for st in forced_trace])               # (T,B,N)
+        chosen = U.gather(2, torch.as_tensor(acts)[:, :, None])[..., 0]
+        slack = U.max(dim=2).values - chosen
+        assert slack.max().item() < TIE_GAP, slack.max().item()
+        roots = int((slack > 0).any(dim=0).sum())                       # graphs with a tie flip
+        assert roots <= max(2, B // 20), f"{roots} of {B} graphs chose a near-tie runner-up"
+        if not roots:
+            assert not div_oracle, "diverged from the oracle without any near tie"
+    if ref_T is not None and not div_ref:
+        assert T == ref_T
+    exempt = np.zeros(B, bool)
+    exempt[list(div_ref)] = True
     loss, logp = res.acc_loss.cpu(), res.acc_logp.cpu()
     assert (loss - ol).abs().max().item() < TOL, (loss - ol).abs().max().item()
     assert (logp - olp).abs().max().item() < TOL * (1 if greedy else max(1, T / 4)), \
         (logp - olp).abs().max().item()
-    if ref_loss is not None and not exempt.any():
-        assert np.max(np.abs(loss.numpy() - ref_loss)) < TOL
-        assert np.max(np.abs(logp.numpy() - ref_logp)) < TOL * (1 if greedy else max(1, T / 4))
+    if ref_loss is not None:
+        ok = ~exempt
+        assert np.max(np.abs(loss.numpy() - ref_loss)[ok]) < TOL
+        assert np.max(np.abs(logp.numpy() - ref_logp)[ok]) < TOL * (1 if greedy else max(1, T / 4))
+    trace = forced_trace
+    exempt[:] = False
     # per-step logits along the same action path
     if not exempt.any():
         for t in range(T):

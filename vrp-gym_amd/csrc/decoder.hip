@@ -331,6 +331,120 @@ __global__ __launch_bounds__(256) void cvec_kernel(const float *__restrict__ emb
   if (lane == 0) cvec[r] = s;
 }
 
+// ------------------------------------------------------------------ tables on the matrix cores
+// All per-episode tables are per-(graph, head) products of two (N x 48) row blocks of PROJ:
+//   SL = QL KK^T / sqrt(48),  SF = QF KK^T / sqrt(48),  RT = KM VV^T,
+//   [SG; C0; SLD] = [QG; qc0; wload] KK^T / sqrt(48)        (three extra query rows)
+// One wave per (graph, head) runs them as 16x16 tiles of v_mfma_f32_16x16x4_f32 (exact
+// fp32).  The 48-long inner dimension is split over the four 16-lane groups: group q
+// holds k in [12q, 12q+12) of its row (three float4 loads), MFMA step s consumes element
+// s of every group -- a fixed permutation of k applied to both operands.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NTMAX>
+__device__ __forceinline__ void load_rows12(float (&dst)[12], const float *row_ptr, bool on) {
+  if (on) {
+#pragma unroll
+    for (int d = 0; d < 12; d += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(row_ptr + d);
+      dst[d] = t.x; dst[d + 1] = t.y; dst[d + 2] = t.z; dst[d + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 12; ++d) dst[d] = 0.f;
+  }
+}
+
+template <int NTMAX>  // 16-column tiles per row: ceil(N/16) <= NTMAX
+__global__ __launch_bounds__(256) void pair_tables_kernel(
+    int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
+    const float *__restrict__ qc0, const float *__restrict__ wload, float *__restrict__ SG,
+    float *__restrict__ C0, float *__restrict__ SLD, float *__restrict__ SF,
+    float *__restrict__ SL, float *__restrict__ curs, float *__restrict__ RT) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  const int i16 = lane & 15, q = lane >> 4;
+  const int NT = (N + 15) >> 4;
+  const bool irp = kind == VRP_KIND_IRP;
+  const int qfoff = 0, qloff = irp ? 0 : 384, kkoff = irp ? 384 : 768, kmoff = irp ? 768 : 1152;
+  const int vvoff = kmoff + 384;
+  const int hq = h * VRP_HD + 12 * q;
+  const float c = 0.14433756729740643f;  // 1/sqrt(48)
+  const float *rows = PROJ + (size_t)b * N * P;
+
+  float bf[NTMAX][12];
+  auto load_b = [&](int off) {
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) {
+      const int n = nt * 16 + i16;
+      load_rows12<NTMAX>(bf[nt], rows + (size_t)(n < N ? n : 0) * P + off + hq, nt < NT && n < N);
+    }
+  };
+  // one 16-row tile of A against every column tile; store(row, col, value)
+  auto tile_rows = [&](const float (&af)[12], auto &&store) {
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) {
+      if (nt < NT) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < 12; ++s_)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], bf[nt][s_], acc, 0, 0, 0);
+        const int n = nt * 16 + i16;  // D: col = lane&15, row = (lane>>4)*4 + reg
+        if (n < N) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) store(q * 4 + r, n, acc[r]);
+        }
+      }
+    }
+  };
+
+  // ---- glimpse score tables: B operand = projected keys -----------------------------
+  load_b(kkoff);
+  {
+    float af[12];
+    // three extra query rows: 0 = graph embedding + bq, 1 = step-0 placeholders, 2 = load
+    const float *src = (i16 == 0) ? QG + (size_t)b * VRP_D : (i16 == 1 ? qc0 : wload);
+    load_rows12<NTMAX>(af, src + hq, i16 < 3);
+    const size_t hn = ((size_t)b * 8 + h) * N;
+    float sg_keep[NTMAX];  // rows 0/1 live in lanes q == 0, regs 0/1
+    tile_rows(af, [&](int r, int n, float v) {
+      v *= c;
+      if (r == 0) { SG[hn + n] = v; sg_keep[0] = v; }
+      if (r == 1) { C0[hn + n] = v; curs[hn + n] = sg_keep[0] + v; }  // step-0 score row
+      if (r == 2) SLD[hn + n] = v;
+    });
+  }
+  for (int mt = 0; mt < NT; ++mt) {
+    const int m = mt * 16 + i16;
+    const float *rp = rows + (size_t)(m < N ? m : 0) * P;
+    float af[12];
+    load_rows12<NTMAX>(af, rp + qloff + hq, m < N);
+    tile_rows(af, [&](int r, int n, float v) {
+      const int mm = mt * 16 + r;
+      if (mm < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = v * c;
+    });
+    if (!irp) {
+      load_rows12<NTMAX>(af, rp + qfoff + hq, m < N);
+      tile_rows(af, [&](int r, int n, float v) {
+        const int mm = mt * 16 + r;
+        if (mm < N) SF[(((size_t)b * N + mm) * 8 + h) * N + n] = v * c;
+      });
+    }
+  }
+  // ---- pointer-logit table: B operand = projected values ------------------------------
+  load_b(vvoff);
+  for (int mt = 0; mt < NT; ++mt) {
+    const int m = mt * 16 + i16;
+    float af[12];
+    load_rows12<NTMAX>(af, rows + (size_t)(m < N ? m : 0) * P + kmoff + hq, m < N);
+    tile_rows(af, [&](int r, int n, float v) {
+      const int mm = mt * 16 + r;
+      if (mm < N) RT[(((size_t)b * N + mm) * 8 + h) * N + n] = v;
+    });
+  }
+}
+
 extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
                                    void *workspace, void *stream) {
   VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
@@ -345,6 +459,23 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
                                  st)) return r;
   if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
                                  128, 0, st)) return r;
+  static const char *valu_tables = getenv("VRP_VALU_TABLES");  // A/B aid: the VALU kernels
+  if (!valu_tables && use_rtable(N)) {
+    if (N <= 32)
+      hipLaunchKernelGGL(pair_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
+    else if (N <= 64)
+      hipLaunchKernelGGL(pair_tables_kernel<4>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
+    else
+      hipLaunchKernelGGL(pair_tables_kernel<8>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
+    VRP_CHECK_LAUNCH("pair_tables");
+    hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
+                       w.cvec);
+    VRP_CHECK_LAUNCH("cvec");
+    return 0;
+  }
   if (N <= 64)
     hipLaunchKernelGGL(score_tables_kernel<1>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
                        w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
