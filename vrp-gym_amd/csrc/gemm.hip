@@ -23,7 +23,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // eight kq values of one row over distinct 16-byte bank groups, so both the staging
 // writes (lanes along k) and the fragment reads (lanes along rows) are conflict-free
 // 128-bit accesses.
-__device__ __forceinline__ int slot(int kq, int row, int rows) { return kq * rows + (row ^ kq); }
+template <int KQ_>
+__device__ __forceinline__ int slot(int kq, int row, int rows) {
+  return kq * rows + (row ^ (KQ_ == 4 ? (kq << 1) : kq));  // KQ = 4: keep 8 staging lanes apart
+}
 
 // RS = rows covered by one pass of the 256 threads (256 / (BK/4) lanes along k)
 template <int AS, int WS, int RS>
@@ -44,13 +47,13 @@ template <int AS, int WS, int RS, int BM>
 __device__ __forceinline__ void gemm_stage(const float4 (&av)[AS], const float4 (&wv)[WS],
                                            float4 *As, float4 *Ws, int lr, int lq) {
 #pragma unroll
-  for (int s = 0; s < AS; ++s) As[slot(lq, lr + RS * s, BM)] = av[s];
+  for (int s = 0; s < AS; ++s) As[slot<256 / RS>(lq, lr + RS * s, BM)] = av[s];
 #pragma unroll
-  for (int s = 0; s < WS; ++s) Ws[slot(lq, lr + RS * s, BN)] = wv[s];
+  for (int s = 0; s < WS; ++s) Ws[slot<256 / RS>(lq, lr + RS * s, BN)] = wv[s];
 }
 
 template <int BM, int BK>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
+__global__ __launch_bounds__(256, (BK == 16 ? 4 : 2)) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ R, int ldr,
     const float *__restrict__ norm, float *__restrict__ C, int ldc, int M, int N, int K,
@@ -87,9 +90,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(
   _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                         \
     float4 a4[MI], b4[2];                                                                     \
     _Pragma("unroll") for (int i = 0; i < MI; ++i)                                            \
-        a4[i] = As[buf][slot(kq, wm * (BM / 2) + i * 32 + fr, BM)];                           \
+        a4[i] = As[buf][slot<KQ>(kq, wm * (BM / 2) + i * 32 + fr, BM)];                           \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-        b4[j] = Ws[buf][slot(kq, wn * 64 + j * 32 + fr, BN)];                                 \
+        b4[j] = Ws[buf][slot<KQ>(kq, wn * 64 + j * 32 + fr, BN)];                                 \
     /* MFMA 32x32x2 wants A[row][k0+fk]: k-pair 0 = (x,y), k-pair 1 = (z,w) */                \
     _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {                                        \
       float a[MI], b[2];                                                                      \
@@ -158,9 +161,20 @@ int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, cons
     else
       hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, lda, W, ldw,
                          bias, R, ldr, norm, C, ldc, M, N, K, relu);
-  } else if (tiles128 >= 1024 || (force && force[0] == '1')) {  // enough workgroups to fill 256 CUs
+  } else if (force && force[0] == 's') {
+    dim3 grid(N / BN, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 16>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
+                       ldr, norm, C, ldc, M, N, K, relu);
+  } else if (force && force[0] == '1') {
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
+                       ldr, norm, C, ldc, M, N, K, relu);
+  } else if (tiles128 >= 1024) {
+    // enough workgroups to fill 256 CUs several times over: 128x128x16 tiles, 32 KB of LDS
+    // and 114 VGPRs -> 4 workgroups per CU overlap each other's barriers and load latency
+    // (measured 89-108 TFLOP/s at M = 327680 vs 76-102 for the 128x128x32 tile at 2 per CU)
+    dim3 grid(N / BN, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 16>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, C, ldc, M, N, K, relu);
   } else {
     // few workgroups: a workgroup's own latency is the kernel's duration.  Measured on
