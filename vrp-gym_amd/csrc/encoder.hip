@@ -3,6 +3,7 @@
 // BatchNorm].  agents/graph_encoder.py:41-58, 95-138, 141-154, 183-198.
 // Dense projections run on the matrix cores (gemm.hip); the per-graph N x N
 // attention, the batch statistics and the normalisation are small HBM-bound kernels.
+#include <stdlib.h>
 #include "common.h"
 
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
@@ -160,6 +161,159 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
   reinterpret_cast<float4 *>(x)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// ---- fused post-attention block (eval mode) --------------------------------------------
+//   y1 = BN1(x + att Wo^T + bo);   y = BN2(y1 + relu(y1 W1^T + b1) W2^T + b2)
+// (MultiHeadAttentionLayer.forward agents/graph_encoder.py:196-197 with BatchNorm as the
+// per-channel affine it is in eval mode).  One workgroup owns RTW rows; the activations
+// (att, x/y1, the 128-wide slices of the hidden layer) never leave LDS, the weights stream
+// from L2 straight into registers.  Every stage is the same micro-kernel
+//   C (RTW x 128) = A (RTW x 128, LDS) * Wslice^T (128 x 128)
+// on v_mfma_f32_32x32x2_f32 (exact fp32): wave w owns output columns 32w..32w+31 for all
+// rows, so each weight element is read once per workgroup.  The K = 128 inner dimension is
+// split between the two 32-lane halves (half g walks k = 64g + s), a fixed permutation
+// applied to both operands.  LDS rows are padded to 132 floats: the per-lane float4
+// fragment reads (lane = row) and the column-contiguous result writes are conflict-free.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define EB_LD 132
+
+template <int MI>
+__device__ __forceinline__ void eb_load_w(float (&w)[64], const float *wrow) {
+#pragma unroll
+  for (int s = 0; s < 64; s += 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(wrow + s);
+    w[s] = t.x; w[s + 1] = t.y; w[s + 2] = t.z; w[s + 3] = t.w;
+  }
+}
+template <int MI>
+__device__ __forceinline__ void eb_mma(f32x16 (&acc)[MI], const float *abuf, const float (&w)[64],
+                                       int lane) {
+  const int i = lane & 31, g = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 64; s += 4) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const float4 a = *reinterpret_cast<const float4 *>(abuf + (mi * 32 + i) * EB_LD + 64 * g + s);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[s], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[s + 1], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[s + 2], acc[mi], 0, 0, 0);
+      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[s + 3], acc[mi], 0, 0, 0);
+    }
+  }
+}
+
+template <int RTW>
+__global__ __launch_bounds__(256, 1) void encoder_block_kernel(
+    const float *__restrict__ att, const float *__restrict__ x, const float *__restrict__ Wo,
+    const float *__restrict__ bo, const float *__restrict__ norm1, const float *__restrict__ W1,
+    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+    const float *__restrict__ norm2, float *__restrict__ y, int rows, int hidden) {
+  constexpr int MI = RTW / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;                 // att tile, then the hidden-layer slices
+  float *bufB = smem + RTW * EB_LD;   // x tile, then y1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * RTW;
+  const int j = lane & 31, g = lane >> 5;
+  const int ncol = wave * 32 + j;     // this lane's output column / weight row
+
+  float w[64];
+  eb_load_w<MI>(w, Wo + (size_t)ncol * 128 + 64 * g);   // in flight while the tiles land
+  for (int idx = tid; idx < RTW * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
+    if (row0 + r < rows) {
+      va = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+      vx = *reinterpret_cast<const float4 *>(x + (size_t)(row0 + r) * 128 + c4);
+    }
+    *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = va;
+    *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = vx;
+  }
+  __syncthreads();
+
+  f32x16 acc[MI], gacc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[mi][r] = 0.f; gacc[mi][r] = 0.f; }
+
+  // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
+  eb_mma<MI>(acc, bufA, w, lane);
+  eb_load_w<MI>(w, W1 + (size_t)ncol * 128 + 64 * g);   // next stage's weights
+  {
+    const float bb = bo[ncol], mean = norm1[ncol], mult = norm1[128 + ncol], beta = norm1[256 + ncol];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        float *p = bufB + row * EB_LD + ncol;
+        *p = (acc[mi][r] + bb + *p - mean) * mult + beta;   // x -> y1 in place
+      }
+  }
+  __syncthreads();  // y1 complete; nobody reads att (bufA) any more
+
+  // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T --------------
+  const int nchunk = hidden / 128;
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    eb_mma<MI>(acc, bufB, w, lane);                      // w = W1 rows of slice c
+    eb_load_w<MI>(w, W2 + (size_t)ncol * hidden + c * 128 + 64 * g);
+    {
+      const float bb = b1[c * 128 + ncol];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          bufA[row * EB_LD + ncol] = fmaxf(acc[mi][r] + bb, 0.f);
+        }
+    }
+    __syncthreads();  // slice c of the hidden layer is in bufA
+    eb_mma<MI>(gacc, bufA, w, lane);                     // w = W2[:, slice c]
+    if (c + 1 < nchunk) eb_load_w<MI>(w, W1 + (size_t)((c + 1) * 128 + ncol) * 128 + 64 * g);
+    __syncthreads();  // everybody done with bufA before the next slice overwrites it
+  }
+
+  // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
+  {
+    const float bb = b2[ncol], mean = norm2[ncol], mult = norm2[128 + ncol], beta = norm2[256 + ncol];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (row0 + row < rows) {
+          const float v = gacc[mi][r] + bb + bufB[row * EB_LD + ncol];
+          y[(size_t)(row0 + row) * 128 + ncol] = (v - mean) * mult + beta;
+        }
+      }
+  }
+}
+
+template <int RTW>
+static int launch_encoder_block(const float *att, const float *x, const vrp_encoder_layer &L,
+                                const float *norm1, const float *norm2, float *y, int rows,
+                                int hidden, hipStream_t st) {
+  const size_t lds = (size_t)2 * RTW * EB_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block_kernel<RTW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_block: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(encoder_block_kernel<RTW>, dim3((rows + RTW - 1) / RTW), dim3(256), lds, st,
+                     att, x, L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
+                     L.ff2_weight, L.ff2_bias, norm2, y, rows, hidden);
+  VRP_CHECK_LAUNCH("encoder_block");
+  return 0;
+}
+
 struct EncWs {
   float *h0, *h1, *qkv, *att, *ff, *norm;  // norm: (16,384) eval-mode BN affines
   double *stats;
@@ -235,6 +389,18 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
     const size_t lds = (size_t)4 * N * 32 * sizeof(float);
     hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
     VRP_CHECK_LAUNCH("encoder_attention");
+    static const char *unfused = getenv("VRP_ENCODER_UNFUSED");  // A/B aid
+    if (!train && !unfused) {
+      // eval: out-proj + BN1 + FF + BN2 in one kernel, activations stay in LDS
+      nxt = (cur == emb) ? ws.h0 : emb;
+      const float *n1 = ws.norm + (2 * l) * 384, *n2 = ws.norm + (2 * l + 1) * 384;
+      const int r = (R >= 64 * 1024)
+                        ? launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st)
+                        : launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      if (r) return r;
+      cur = nxt;
+      continue;
+    }
     if (int r = vrp_launch_gemm_nt_ex(ws.att, 128, L.out_proj_weight, 128, L.out_proj_bias, cur,
                                       128, train ? nullptr : ws.norm + (2 * l) * 384, ws.h1, 128,
                                       R, 128, 128, 0, st)) return r;
