@@ -834,16 +834,19 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
   return __ffsll((long long)bits) - 1;
 }
 
-template <int NPL>  // nodes per lane: 1 (N <= 64) or 2 (N <= 128); node = lane + 64*i
-__global__ __launch_bounds__(256, (NPL == 1 ? 3 : 2)) void decode_step_rt_kernel(StepParams p) {
+// WPG = waves (= graphs) per workgroup: 4 for large batches; 1 for small ones, where the
+// kernel is latency-bound and single-wave workgroups spread over more CUs and never wait
+// for a sibling wave at the two barriers.
+template <int NPL, int WPG>  // nodes per lane: 1 (N <= 64) or 2 (N <= 128); node = lane + 64*i
+__global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_kernel(StepParams p) {
   constexpr int NMAXL = 64 * NPL;
-  __shared__ __attribute__((aligned(16))) float a_s[GPW][8 * NMAXL];  // a[h][n], hn order
-  __shared__ __attribute__((aligned(16))) float u_s[GPW][NMAXL];
-  __shared__ int sel_s[GPW][NMAXL];  // compacted list of selectable nodes
+  __shared__ __attribute__((aligned(16))) float a_s[WPG][8 * NMAXL];  // a[h][n], hn order
+  __shared__ __attribute__((aligned(16))) float u_s[WPG][NMAXL];
+  __shared__ int sel_s[WPG][NMAXL];  // compacted list of selectable nodes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N = p.N, B = p.B;
-  const int braw = blockIdx.x * GPW + wave;
+  const int braw = blockIdx.x * WPG + wave;
   const bool active = braw < B;
   const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
   const int par = p.t & 1;
@@ -1183,10 +1186,15 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.io = *io;
   hipStream_t st = (hipStream_t)stream;
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
-    if (N <= 64)
-      hipLaunchKernelGGL(decode_step_rt_kernel<1>, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
+    const bool small = B <= 2048;
+    if (N <= 64 && small)
+      hipLaunchKernelGGL((decode_step_rt_kernel<1, 1>), dim3(B), dim3(64), 0, st, p);
+    else if (N <= 64)
+      hipLaunchKernelGGL((decode_step_rt_kernel<1, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
+    else if (small)
+      hipLaunchKernelGGL((decode_step_rt_kernel<2, 1>), dim3(B), dim3(64), 0, st, p);
     else
-      hipLaunchKernelGGL(decode_step_rt_kernel<2>, dim3((B + GPW - 1) / GPW), dim3(256), 0, st, p);
+      hipLaunchKernelGGL((decode_step_rt_kernel<2, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
     VRP_CHECK_LAUNCH("decode_step_rt");
     return 0;
   }
