@@ -394,9 +394,12 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
       // eval: out-proj + BN1 + FF + BN2 in one kernel, activations stay in LDS
       nxt = (cur == emb) ? ws.h0 : emb;
       const float *n1 = ws.norm + (2 * l) * 384, *n2 = ws.norm + (2 * l + 1) * 384;
+      // row tile: enough workgroups to occupy all 256 CUs at every batch size
       const int r = (R >= 64 * 1024)
                         ? launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st)
-                        : launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+                        : (R >= 16 * 1024
+                               ? launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st)
+                               : launch_encoder_block<32>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st));
       if (r) return r;
       cur = nxt;
       continue;
