@@ -165,6 +165,14 @@ int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *
                       const vrp_env *env, const float *emb, void *dec_workspace,
                       const vrp_rollout_io *io, int max_steps, int flags, void *stream);
 
+/* E1  Host-side instance sampler, bit-exact with numpy's legacy global stream
+ * (VRPGraph.__init__ gym_vrp/graph/vrp_graph.py:28-43 called B times,
+ * vrp_network.py:41-42): rand(N,2) -> choice(N,1,replace=False) -> uniform(1,10)/C per
+ * graph.  key_host (624 words) / *pos_host are numpy's MT19937 state from
+ * np.random.get_state(), advanced in place; all pointers are HOST pointers. */
+int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
+                            double *pos_out_host, int64_t *depots_host, double *demands_host);
+
 /* Building blocks exported for tests and profiling. */
 int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                 const float *residual, int ldr, float *C, int ldc, int M, int N, int K,

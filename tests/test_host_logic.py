@@ -30,6 +30,47 @@ def test_instances_match_reference_rng_order():
             assert np.array_equal(dem, z[f"demands{r}"])
 
 
+def test_native_instance_sampler_is_bit_exact():
+    """csrc/instances.hip replays numpy's legacy stream: same arrays AND same generator
+    state afterwards as the three-numpy-calls-per-graph loop."""
+    from gym_vrp.graph.instances import draw_instances
+    import vrpgym_hip
+    assert hasattr(vrpgym_hip.lib(), "vrp_draw_instances_host")
+    for B, N, seed in [(1, 2, 0), (5, 6, 69), (64, 20, 123), (17, 100, 7), (300, 33, 2 ** 31 - 1)]:
+        np.random.seed(seed)
+        np.random.rand(seed % 5)  # arbitrary stream position
+        want = draw_instances(B, N, native=False)
+        tail_want = np.random.rand(3)
+        np.random.seed(seed)
+        np.random.rand(seed % 5)
+        got = draw_instances(B, N, native=True)
+        tail_got = np.random.rand(3)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        assert np.array_equal(tail_want, tail_got)
+    for f in sorted(glob.glob(os.path.join(G, "instances_*.npz"))):  # and the reference's own
+        z = np.load(f)
+        np.random.seed(int(z["seed"]))
+        np.random.choice(int(z["B"]), int(z["num_draw"]), replace=False)
+        pos, dep, dem = draw_instances(int(z["B"]), int(z["N"]), native=True)
+        assert np.array_equal(pos, z["pos0"]) and np.array_equal(dep, z["depots0"])
+        assert np.array_equal(dem, z["demands0"])
+
+
+def test_reference_checkpoint_loads():
+    """A state_dict with the reference's keys/shapes (here: the oracle's restatement of the
+    reference's modules) loads into the product models, and back."""
+    import agents
+    from oracle import policy as opol
+    for kind, cls in enumerate((agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)):
+        sd, _ = opol.init_state_dicts(kind, seed=5)
+        a = cls(seed=1)
+        missing = a.model.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        for k, v in a.model.state_dict().items():
+            assert torch.equal(v.cpu(), sd[k]), k
+
+
 def test_shard_bounds_partition():
     from gym_vrp.graph.instances import shard_bounds
     spans = [shard_bounds(8192, r, 8) for r in range(8)]
@@ -133,6 +174,12 @@ if rank == 1:
         for p in a.model.parameters():
             p.add_(1.0)
 D.broadcast_model(a.model)
+bn = a.model.encoder.attention_layers[0].bn1.norm
+bn.running_mean.fill_(float(rank))
+bn.num_batches_tracked.fill_(3 + rank)
+D.average_buffers(a.model)
+assert torch.allclose(bn.running_mean, torch.full_like(bn.running_mean, 0.5))
+assert int(bn.num_batches_tracked) == 3
 chk = torch.stack([p.detach().sum() for p in a.model.parameters()]).sum()
 both = [torch.empty_like(chk) for _ in range(2)]
 dist.all_gather(both, chk)

@@ -62,3 +62,18 @@ def broadcast_model(model, src=0):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src=src)
+
+
+def average_buffers(model):
+    """BatchNorm running statistics are buffers, not gradients: every rank accumulates its
+    own shard's statistics.  They are averaged whenever the weights are copied into the
+    baseline or checkpointed, so replicas stay identical."""
+    if not is_distributed():
+        return
+    world = dist.get_world_size()
+    for b in model.buffers():
+        if b.dtype.is_floating_point:
+            dist.all_reduce(b.data, op=dist.ReduceOp.SUM)
+            b.data.div_(world)
+        else:  # num_batches_tracked: identical on all ranks by construction; keep rank 0's
+            dist.broadcast(b.data, src=0)

@@ -119,6 +119,10 @@ class TSPAgent:
         """state_dict every 50 epochs (graph_tsp_agent.py:210-225)."""
         os.makedirs(check_point_dir, exist_ok=True)
         if episode % 50 == 0 and episode != 0:
+            from . import distributed
+            distributed.average_buffers(self.model)
+            if distributed.is_distributed() and torch.distributed.get_rank() != 0:
+                return
             torch.save(self.model.state_dict(), check_point_dir + f"model_epoch_{episode}.pt")
 
     def step(self, env, rollouts: Tuple[bool, bool]):
@@ -157,4 +161,5 @@ class TSPAgent:
         _, p_value = stats.ttest_rel(cur.tolist(), base.tolist())
         if advantage.item() <= 0 and p_value <= 0.05:
             print("replacing baceline")
+            distributed.average_buffers(self.model)
             self.target_model.load_state_dict(self.model.state_dict())

@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemm_stage(const float4 (&av)[AS], const float4 
 }
 
 template <int BM, int BK>
-__global__ __launch_bounds__(256, (BK == 16 ? 4 : 2)) void gemm_nt_kernel(
+__global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ R, int ldr,
     const float *__restrict__ norm, float *__restrict__ C, int ldc, int M, int N, int K,

@@ -1,0 +1,91 @@
+// Host-side instance sampler, bit-exact with numpy's legacy global stream (E1 of
+// SURVEY.md 8a).  The reference draws every instance with three numpy calls per graph:
+//   np.random.rand(N,2); np.random.choice(N, size=1, replace=False);
+//   np.random.uniform(1, 10, (N,1)) / (0.2449*N + 26.12)
+// (gym_vrp/graph/vrp_graph.py:28-43, called B times by vrp_network.py:41-42).  Calling
+// them from Python costs ~30 us per graph (0.26 s at B = 8192).  This file replays the
+// same MT19937 stream natively: the caller hands over numpy's generator state
+// (np.random.get_state()), the stream is advanced exactly as numpy would, and the state
+// goes back with np.random.set_state().  Algorithms restated from numpy's legacy
+// RandomState: random_sample = genrand_res53, choice(replace=False) = permutation =
+// Fisher-Yates from the top with the masked-rejection random_interval (32-bit draws),
+// uniform = low + (high-low)*random_sample.
+#include <stdint.h>
+#include "common.h"
+
+namespace {
+struct MT {
+  uint32_t *mt;
+  int pos;
+  inline uint32_t next() {
+    constexpr int N = 624, M = 397;
+    if (pos >= N) {
+      int kk = 0;
+      uint32_t y;
+      for (; kk < N - M; ++kk) {
+        y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      for (; kk < N - 1; ++kk) {
+        y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      y = (mt[N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+      mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  inline double sample() {  // genrand_res53
+    const uint32_t a = next() >> 5, b = next() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+  inline uint32_t interval(uint32_t mx) {  // uniform on [0, mx], masked rejection
+    if (mx == 0) return 0;
+    uint32_t mask = mx;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = (next() & mask)) > mx) {}
+    return v;
+  }
+};
+}  // namespace
+
+// key: numpy's 624-word MT19937 state (in/out); *pos: its position (in/out).
+// pos_out (B,N,2) f64, depots (B) i64, demands (B,N) f64.  Host pointers.
+extern "C" int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
+                                       double *pos_out_host, int64_t *depots_host,
+                                       double *demands_host) {
+  VRP_REQUIRE(key_host && pos_host && pos_out_host && depots_host && demands_host,
+              "draw_instances: NULL argument");
+  VRP_REQUIRE(B > 0 && N > 0 && N <= 65536, "draw_instances: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(*pos_host >= 0 && *pos_host <= 624, "draw_instances: bad generator position");
+  MT g{key_host, *pos_host};
+  const double scale = 0.2449 * N + 26.12;  // vrp_graph.py:41
+  uint32_t *perm = new uint32_t[N];
+  for (int b = 0; b < B; ++b) {
+    double *p = pos_out_host + (size_t)b * N * 2;
+    for (int i = 0; i < 2 * N; ++i) p[i] = g.sample();          // rand(N,2)
+    for (int i = 0; i < N; ++i) perm[i] = (uint32_t)i;          // permutation(N)[:1]
+    for (int i = N - 1; i > 0; --i) {
+      const uint32_t j = g.interval((uint32_t)i);
+      const uint32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+    depots_host[b] = perm[0];
+    double *d = demands_host + (size_t)b * N;
+    for (int i = 0; i < N; ++i) {
+      const double u = g.sample();
+      const double v = 1.0 + 9.0 * u;                           // uniform(1,10)
+      d[i] = v / scale;
+    }
+    d[perm[0]] = 0.0;                                           // vrp_graph.py:43
+  }
+  delete[] perm;
+  *pos_host = g.pos;
+  return 0;
+}

@@ -75,6 +75,7 @@ def _declare(lib):
                               vp, vp, vp, P(RolloutIO), i32, vp]),
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                     i32, i32, vp]),
+        "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
