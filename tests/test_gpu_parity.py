@@ -346,6 +346,36 @@ def test_rollout_against_oracle(kind, B, N, greedy, train):
         _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
 
 
+@pytest.mark.parametrize("kind,B,N,greedy", [
+    (0, 1, 2, True),      # smallest legal instance: one graph, depot + one customer
+    (1, 1, 3, False),     # B = 1: every scrambled-mask row is the graph's own
+    (2, 6, 9, False),     # B not a multiple of the 4 graphs per workgroup, sampling
+    (1, 5, 128, True),    # VRP_MAX_NODES: two nodes per lane, up to 254 steps
+    (0, 2051, 11, True),  # B just above the single-wave-workgroup threshold
+])
+def test_rollout_edge_shapes(kind, B, N, greedy):
+    _compare_rollout(kind, B, N, greedy, 3, 69, 9)
+
+
+def test_api_error_behaviour():
+    """Errors mirror the reference's asserts; library misuse raises with vrp_last_error()."""
+    import agents
+    import vrpgym_hip as hip
+    from gym_vrp.envs import IRPEnv, TSPEnv
+    env = TSPEnv(5, 4, 1, 1)
+    with pytest.raises(AssertionError, match="Number of actions"):
+        env.step(np.zeros((3, 1), dtype=int))
+    with pytest.raises(AssertionError, match="Num_draw"):
+        TSPEnv(5, 2, 3)
+    with pytest.raises(TypeError):
+        agents.TSPAgent(seed=1).model(IRPEnv(5, 4, 1, 1), True)   # wrong env kind
+    lib = hip.lib()
+    rc = lib.vrp_gemm_nt(None, 128, None, 128, None, None, 0, None, 100, 4, 100, 128, 0, None)
+    assert rc != 0 and b"multiple" in lib.vrp_last_error()
+    with pytest.raises(RuntimeError, match="libvrpgym_hip error"):
+        hip.check(rc)
+
+
 def test_reference_agent_kats():
     """tests/test_agent.py:72-114 of the reference, unchanged but for the import root:
     greedy agent.step on B=2, N=4 must give the reference's published values."""
