@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x,
 
 // ---- per-graph multi-head self-attention on the projected QKV --------------------
 // One wave per (graph, head); lane = query node (two per lane when N > 64).  K_h and
-// V_h (N x 16 each) sit in LDS and are read as broadcasts.  Two passes over the keys
-// (max, then exp/sum) like torch's softmax.  graph_encoder.py:170-172,196.
+// V_h (N x 16 each) sit in LDS and are read as broadcasts.  One pass over the keys with a
+// running maximum (flash-style); equal to torch's softmax up to fp32 rounding.
+// graph_encoder.py:170-172,196.
 __global__ __launch_bounds__(256) void encoder_attention_kernel(const float *__restrict__ qkv,
                                                                 float *__restrict__ out, int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -63,20 +64,22 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float *__r
       float4 t = *reinterpret_cast<const float4 *>(base + (size_t)i * 384 + h * 16 + d);
       q[d] = t.x * 0.25f; q[d + 1] = t.y * 0.25f; q[d + 2] = t.z * 0.25f; q[d + 3] = t.w * 0.25f;
     }
-    float m = -INFINITY;
-    for (int j = 0; j < N; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
-      m = fmaxf(m, s);
-    }
-    float l = 0.f, o[16];
+    // single pass over the keys with a running maximum (scores are computed once); the
+    // accumulators are rescaled only when the maximum moves
+    float m = -INFINITY, l = 0.f, o[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) o[d] = 0.f;
     for (int j = 0; j < N; ++j) {
       float s = 0.f;
 #pragma unroll
       for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      if (s > m) {
+        const float corr = expf(m - s);  // exp(-inf) = 0 on the first key
+        l *= corr;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] *= corr;
+        m = s;
+      }
       const float p = expf(s - m);
       l += p;
 #pragma unroll
