@@ -8,7 +8,7 @@
 //     the keys K_n = Wk*e_n + bk are per-episode constants, so the glimpse score
 //     q_h.K_{h,n}/sqrt(48) splits into per-episode tables
 //        SG[b][h][n]        graph-embedding + bias part
-//        SF[b][m][h][n]     "first node = m" part      (TSP/VRP)
+//        base1[b][h][n]     SG + "first node" part, one row built after step 0 (TSP/VRP)
 //        SL[b][m][h][n]     "last node  = m" part
 //        SLD[b][h][n]       load coefficient           (IRP)
 //        C0[b][h][n]        step-0 placeholders _first_node/_last_node
@@ -28,8 +28,9 @@ int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const f
 
 // ------------------------------------------------------------------ derived weights
 struct Derived {
-  float *Wproj;  // (1920,128) = [Wq_first | Wq_last | Wk | M^T | Wv]  (IRP: no Wq_first, 1536 rows)
-  float *bproj;  // (1920)       0 | 0 | bk | 0 | bv
+  float *Wproj;  // (1536,128) = [Wq_last | Wk | M^T | Wv]
+  float *bproj;  // (1536)       0 | bk | 0 | bv
+  float *Wqf;    // (384,128)  first-node block of the query projection (TSP/VRP)
   float *Wqg;    // (384,128)  graph-embedding block of the query projection
   float *bq;     // (384)
   float *qc0;    // (384)      query contribution of the step-0 placeholders
@@ -45,8 +46,9 @@ struct Derived {
 static Derived carve_derived(void *base) {
   float *p = (float *)base;
   Derived d;
-  d.Wproj = p; p += 1920 * 128;
-  d.bproj = p; p += 1920;
+  d.Wproj = p; p += 1536 * 128;
+  d.bproj = p; p += 1536;
+  d.Wqf = p;   p += 384 * 128;
   d.Wqg = p;   p += 384 * 128;
   d.bq = p;    p += 384;
   d.qc0 = p;   p += 384;
@@ -62,7 +64,7 @@ static Derived carve_derived(void *base) {
 
 extern "C" int64_t vrp_decoder_derived_bytes(void) {
   return (int64_t)sizeof(float) *
-         (1920 * 128 + 1920 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
+         (1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
           128 * 384 + 128);
 }
 
@@ -116,12 +118,9 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   int r = 0;
   if (kind != VRP_KIND_IRP) {
     // ctx = [graph_emb | first_ | last_]   graph_decoder.py:88
-    r |= cp(st, d.Wproj, 128, 1, Wq + 128, 384, 1, 384, 128);
-    r |= cp(st, d.Wproj + 384 * 128, 128, 1, Wq + 256, 384, 1, 384, 128);
-    r |= cp(st, d.Wproj + 768 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
+    r |= cp(st, d.Wqf, 128, 1, Wq + 128, 384, 1, 384, 128);
+    r |= cp(st, d.Wproj, 128, 1, Wq + 256, 384, 1, 384, 128);
     r |= cp(st, d.Wqg, 128, 1, Wq, 384, 1, 384, 128);
-    r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 768);
-    r |= cp(st, d.bproj + 768, 0, 1, bias + 384, 0, 1, 1, 384);
     // qc0 = Wq_first * _first_node + Wq_last * _last_node   graph_decoder.py:79-81
     r |= mm(st, d.qc0, 1, 0, Wq + 128, 384, 1, w->first_node, 1, 0, 384, 1, 128, 1.f, 0.f);
     r |= mm(st, d.qc0, 1, 0, Wq + 256, 384, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 1.f);
@@ -129,14 +128,15 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   } else {
     // ctx = _context_proj([graph_emb | last_ | load])   graph_decoder.py:90-91
     const float *Wc = w->context_proj_weight;  // (384,257)
+    r |= cp(st, d.Wqf, 0, 1, nullptr, 0, 0, 1, 384 * 128);
     r |= mm(st, d.Wqg, 128, 1, Wq, 384, 1, Wc, 257, 1, 384, 128, 384, 1.f, 0.f);
     r |= mm(st, d.Wproj, 128, 1, Wq, 384, 1, Wc + 128, 257, 1, 384, 128, 384, 1.f, 0.f);
-    r |= cp(st, d.Wproj + 384 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
     r |= mm(st, d.wload, 1, 0, Wq, 384, 1, Wc + 256, 257, 0, 384, 1, 384, 1.f, 0.f);
-    r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 384);
-    r |= cp(st, d.bproj + 384, 0, 1, bias + 384, 0, 1, 1, 384);
     r |= mm(st, d.qc0, 1, 0, d.Wproj, 128, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 0.f);
   }
+  r |= cp(st, d.Wproj + 384 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
+  r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 384);
+  r |= cp(st, d.bproj + 384, 0, 1, bias + 384, 0, 1, 1, 384);
   r |= cp(st, d.bq, 0, 1, bias, 0, 1, 1, 384);
   r |= cp(st, d.bv, 0, 1, bias + 768, 0, 1, 1, 384);
   r |= cp(st, d.WvT, 1, 384, w->v_proj_weight, 128, 1, 384, 128);  // WvT[k][j] = Wv[j][k]
@@ -149,12 +149,11 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   r |= mm(st, d.tmpv, 1, 0, w->att_output_weight, 384, 1, w->out_proj_bias, 1, 0, 128, 1, 384, 1.f,
           0.f);
   r |= mm(st, d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s, 0.f);
-  // table-driven step (N <= 64): per-node KM[m] = M^T e_m and VV[n] = Wv e_n + bv
-  const int o = (kind == VRP_KIND_IRP) ? 768 : 1152;
-  r |= cp(st, d.Wproj + (size_t)o * 128, 128, 1, d.MT, 128, 1, 384, 128);
-  r |= cp(st, d.Wproj + (size_t)(o + 384) * 128, 128, 1, w->v_proj_weight, 128, 1, 384, 128);
-  r |= cp(st, d.bproj + o, 0, 1, nullptr, 0, 0, 1, 384);
-  r |= cp(st, d.bproj + o + 384, 0, 1, bias + 768, 0, 1, 1, 384);
+  // per-node KM[m] = M^T e_m and VV[n] = Wv e_n + bv for the pointer-logit table
+  r |= cp(st, d.Wproj + (size_t)768 * 128, 128, 1, d.MT, 128, 1, 384, 128);
+  r |= cp(st, d.Wproj + (size_t)1152 * 128, 128, 1, w->v_proj_weight, 128, 1, 384, 128);
+  r |= cp(st, d.bproj + 768, 0, 1, nullptr, 0, 0, 1, 384);
+  r |= cp(st, d.bproj + 1152, 0, 1, bias + 768, 0, 1, 1, 384);
   return r ? 1 : 0;
 }
 
@@ -164,7 +163,8 @@ struct DecWs {
   float *QG;     // (B,384)     Wq_g g + bq
   float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
   float *SG, *C0, *SLD, *base1, *curs;  // (B,8,N) each
-  float *SF, *SL;                // (B,N,8,N) each
+  float *SL;                     // (B,N,8,N)
+  float *Efirst, *QF1;           // (B,128) (B,384): first chosen node and its query part
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:] (N <= 64)
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
@@ -173,7 +173,8 @@ struct DecWs {
 #define VRP_RT_MAX_N 128  // above this the tile kernel (one raw-tile read per step) is used
 static bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 static int proj_width(int kind, int N) {
-  return (kind == VRP_KIND_IRP ? 768 : 1152) + (use_rtable(N) ? 768 : 0);
+  (void)kind;
+  return 768 + (use_rtable(N) ? 768 : 0);  // [QL | KK] (+ [KM | VV])
 }
 static size_t rtable_floats(int B, int N) {
   return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
@@ -191,7 +192,8 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
   w.SLD = (float *)p;   p += vrp_align_up(hn);
   w.base1 = (float *)p; p += vrp_align_up(hn);
   w.curs = (float *)p;  p += vrp_align_up(hn);
-  w.SF = (float *)p;    p += vrp_align_up(tb);
+  w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
+  w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
   w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
@@ -204,7 +206,8 @@ extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
   return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
                    vrp_align_up(R * proj_width(kind, N) * 4) + 5 * vrp_align_up(hn) +
-                   2 * vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
+                   vrp_align_up(tb) + vrp_align_up((size_t)B * 128 * 4) +
+                   vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(rtable_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
 }
 
@@ -216,106 +219,6 @@ __global__ __launch_bounds__(128) void graph_mean_kernel(const float *__restrict
   float s = 0.f;
   for (int n = 0; n < N; ++n) s += e[(size_t)n * VRP_EMB];
   g[(size_t)b * VRP_EMB + c] = s / (float)N;
-}
-
-// Glimpse score tables.  One wave per (graph, head); lane = key node n (two per lane when
-// N > 64), which keeps its projected key K_{h,n} (48 floats) in registers; the query rows
-// are wave-uniform and arrive through the scalar path.
-template <int NPL>
-__global__ __launch_bounds__(256) void score_tables_kernel(int kind, int N, int P,
-                                                           const float *__restrict__ PROJ,
-                                                           const float *__restrict__ QG,
-                                                           const float *__restrict__ qc0,
-                                                           const float *__restrict__ wload,
-                                                           float *__restrict__ SG,
-                                                           float *__restrict__ C0,
-                                                           float *__restrict__ SLD,
-                                                           float *__restrict__ SF,
-                                                           float *__restrict__ SL,
-                                                           float *__restrict__ curs) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x;
-  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  const int koff = (kind == VRP_KIND_IRP ? 384 : 768) + h * VRP_HD;
-  const int qloff = (kind == VRP_KIND_IRP ? 0 : 384) + h * VRP_HD;
-  const int qfoff = h * VRP_HD;
-  const float c = 0.14433756729740643f;  // 1/sqrt(48)
-  float kk[NPL][VRP_HD];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int n = lane + 64 * i;
-    const float *kp = PROJ + ((size_t)b * N + (n < N ? n : 0)) * P + koff;
-#pragma unroll
-    for (int d = 0; d < VRP_HD; d += 4) {
-      float4 t = *reinterpret_cast<const float4 *>(kp + d);
-      kk[i][d] = t.x; kk[i][d + 1] = t.y; kk[i][d + 2] = t.z; kk[i][d + 3] = t.w;
-    }
-  }
-  auto dot = [&](const float *q, int i) {
-    float s = 0.f;
-#pragma unroll
-    for (int d = 0; d < VRP_HD; ++d) s = fmaf(q[d], kk[i][d], s);
-    return s * c;
-  };
-  const size_t hn = ((size_t)b * 8 + h) * N;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int n = lane + 64 * i;
-    if (n < N) {
-      const float sg = dot(QG + (size_t)b * VRP_D + h * VRP_HD, i);
-      const float c0 = dot(qc0 + h * VRP_HD, i);
-      SG[hn + n] = sg;
-      C0[hn + n] = c0;
-      curs[hn + n] = sg + c0;  // step-0 score row of the table-driven kernel
-      SLD[hn + n] = dot(wload + h * VRP_HD, i);
-    }
-  }
-  for (int m = 0; m < N; ++m) {
-    const float *row = PROJ + ((size_t)b * N + m) * P;
-    const size_t o = (((size_t)b * N + m) * 8 + h) * N;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int n = lane + 64 * i;
-      if (n < N) {
-        SL[o + n] = dot(row + qloff, i);
-        if (kind != VRP_KIND_IRP) SF[o + n] = dot(row + qfoff, i);
-      }
-    }
-  }
-}
-
-// Pointer-logit table for the table-driven step:  RT[b][m][h][n] =
-// (M_h^T e_m) . (Wv_h e_n + bv_h), so that u_m = sum_{h,n} a_{h,n} RT[m][h][n] + e_m.mb
-// (the folds of 3.1 carried one step further: no weight matrix is touched per step).
-// One wave per (graph, head); lane = n keeps VV_{h,n} (48 floats) in registers.
-template <int NPL>
-__global__ __launch_bounds__(256) void rtable_kernel(int N, int P, int kmoff,
-                                                     const float *__restrict__ PROJ,
-                                                     float *__restrict__ RT) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x;
-  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  float vv[NPL][VRP_HD];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int n = lane + 64 * i;
-    const float *vp = PROJ + ((size_t)b * N + (n < N ? n : 0)) * P + kmoff + 384 + h * VRP_HD;
-#pragma unroll
-    for (int d = 0; d < VRP_HD; d += 4) {
-      float4 t = *reinterpret_cast<const float4 *>(vp + d);
-      vv[i][d] = t.x; vv[i][d + 1] = t.y; vv[i][d + 2] = t.z; vv[i][d + 3] = t.w;
-    }
-  }
-  for (int m = 0; m < N; ++m) {
-    const float *row = PROJ + ((size_t)b * N + m) * P + kmoff + h * VRP_HD;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int d = 0; d < VRP_HD; ++d) sacc = fmaf(row[d], vv[i][d], sacc);
-      if (lane + 64 * i < N) RT[(((size_t)b * N + m) * 8 + h) * N + lane + 64 * i] = sacc;
-    }
-  }
 }
 
 // cvec[b][m] = e_m . mb   (one wave per node row)
@@ -333,7 +236,7 @@ __global__ __launch_bounds__(256) void cvec_kernel(const float *__restrict__ emb
 
 // ------------------------------------------------------------------ tables on the matrix cores
 // All per-episode tables are per-(graph, head) products of two (N x 48) row blocks of PROJ:
-//   SL = QL KK^T / sqrt(48),  SF = QF KK^T / sqrt(48),  RT = KM VV^T,
+//   SL = QL KK^T / sqrt(48),  RT = KM VV^T,
 //   [SG; C0; SLD] = [QG; qc0; wload] KK^T / sqrt(48)        (three extra query rows)
 // One wave per (graph, head) runs them as 16x16 tiles of v_mfma_f32_16x16x4_f32 (exact
 // fp32).  The 48-long inner dimension is split over the four 16-lane groups: group q
@@ -359,16 +262,15 @@ template <int NTMAX>  // 16-column tiles per row: ceil(N/16) <= NTMAX
 __global__ __launch_bounds__(256) void pair_tables_kernel(
     int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
     const float *__restrict__ qc0, const float *__restrict__ wload, float *__restrict__ SG,
-    float *__restrict__ C0, float *__restrict__ SLD, float *__restrict__ SF,
-    float *__restrict__ SL, float *__restrict__ curs, float *__restrict__ RT) {
+    float *__restrict__ C0, float *__restrict__ SLD, float *__restrict__ SL,
+    float *__restrict__ curs, float *__restrict__ RT) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
   const int i16 = lane & 15, q = lane >> 4;
   const int NT = (N + 15) >> 4;
-  const bool irp = kind == VRP_KIND_IRP;
-  const int qfoff = 0, qloff = irp ? 0 : 384, kkoff = irp ? 384 : 768, kmoff = irp ? 768 : 1152;
-  const int vvoff = kmoff + 384;
+  (void)kind;
+  const int qloff = 0, kkoff = 384, kmoff = 768, vvoff = 1152;
   const int hq = h * VRP_HD + 12 * q;
   const float c = 0.14433756729740643f;  // 1/sqrt(48)
   const float *rows = PROJ + (size_t)b * N * P;
@@ -424,13 +326,6 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
       const int mm = mt * 16 + r;
       if (mm < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = v * c;
     });
-    if (!irp) {
-      load_rows12<NTMAX>(af, rp + qfoff + hq, m < N);
-      tile_rows(af, [&](int r, int n, float v) {
-        const int mm = mt * 16 + r;
-        if (mm < N) SF[(((size_t)b * N + mm) * 8 + h) * N + n] = v * c;
-      });
-    }
   }
   // ---- pointer-logit table: B operand = projected values ------------------------------
   load_b(vvoff);
@@ -459,42 +354,20 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
                                  st)) return r;
   if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
                                  128, 0, st)) return r;
-  static const char *valu_tables = getenv("VRP_VALU_TABLES");  // A/B aid: the VALU kernels
-  if (!valu_tables && use_rtable(N)) {
-    if (N <= 32)
-      hipLaunchKernelGGL(pair_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
-    else if (N <= 64)
-      hipLaunchKernelGGL(pair_tables_kernel<4>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
-    else
-      hipLaunchKernelGGL(pair_tables_kernel<8>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                         w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs, w.RT);
-    VRP_CHECK_LAUNCH("pair_tables");
-    hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
-                       w.cvec);
-    VRP_CHECK_LAUNCH("cvec");
-    return 0;
-  }
-  if (N <= 64)
-    hipLaunchKernelGGL(score_tables_kernel<1>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
+  VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
+  if (N <= 32)
+    hipLaunchKernelGGL(pair_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
+  else if (N <= 64)
+    hipLaunchKernelGGL(pair_tables_kernel<4>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
   else
-    hipLaunchKernelGGL(score_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SF, w.SL, w.curs);
-  VRP_CHECK_LAUNCH("score_tables");
-  if (use_rtable(N)) {
-    if (N <= 64)
-      hipLaunchKernelGGL(rtable_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P,
-                         kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
-    else
-      hipLaunchKernelGGL(rtable_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P,
-                         kind == VRP_KIND_IRP ? 768 : 1152, w.PROJ, w.RT);
-    VRP_CHECK_LAUNCH("rtable");
-    hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
-                       w.cvec);
-    VRP_CHECK_LAUNCH("cvec");
-  }
+    hipLaunchKernelGGL(pair_tables_kernel<8>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
+                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
+  VRP_CHECK_LAUNCH("pair_tables");
+  hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
+                     w.cvec);
+  VRP_CHECK_LAUNCH("cvec");
   return 0;
 }
 
@@ -507,11 +380,57 @@ __device__ __forceinline__ void flag_notdone(int32_t *flag) {
     __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// After the first step of a TSP/VRP episode first_ := embedding of the first chosen node
+// (graph_decoder.py:111-113) and stays fixed: its query part is folded ONCE into the
+// per-graph score row  base1 = SG + (Wq_first e_first) . K / sqrt(48)  instead of keeping
+// an (N,8,N) table for every possible first node.  Three small launches after step 0:
+// gather e_first, QF1 = e_first Wq_first^T (MFMA GEMM), this kernel.
+__global__ __launch_bounds__(128) void gather_first_kernel(const float *__restrict__ emb,
+                                                           const int32_t *__restrict__ first,
+                                                           int N, float *__restrict__ out) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  out[(size_t)b * VRP_EMB + c] = emb[((size_t)b * N + first[b]) * VRP_EMB + c];
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void first_row_kernel(int N, int P, const float *__restrict__ PROJ,
+                                                        const float *__restrict__ QF1,
+                                                        const float *__restrict__ SG,
+                                                        const float *__restrict__ SL,
+                                                        const int32_t *__restrict__ first,
+                                                        float *__restrict__ base1,
+                                                        float *__restrict__ curs) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  const float c = 0.14433756729740643f;  // 1/sqrt(48)
+  const float *q = QF1 + (size_t)b * VRP_D + h * VRP_HD;
+  const size_t hn = ((size_t)b * 8 + h) * N;
+  const size_t sl = (((size_t)b * N + first[b]) * 8 + h) * N;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int n = lane + 64 * i;
+    if (n < N) {
+      const float *kp = PROJ + ((size_t)b * N + n) * P + 384 + h * VRP_HD;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < VRP_HD; d += 4) {
+        const float4 k4 = *reinterpret_cast<const float4 *>(kp + d);
+        s = fmaf(q[d], k4.x, s); s = fmaf(q[d + 1], k4.y, s);
+        s = fmaf(q[d + 2], k4.z, s); s = fmaf(q[d + 3], k4.w, s);
+      }
+      const float b1 = SG[hn + n] + s * c;
+      base1[hn + n] = b1;
+      curs[hn + n] = b1 + SL[sl + n];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ the step kernel
 struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only, fence;
   const float *emb;
-  const float *SG, *C0, *SLD, *SF, *SL;
+  const float *SG, *C0, *SLD, *SL;
   float *base1, *curs;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
@@ -745,12 +664,6 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
   if (!active) return;  // wave-uniform; no barriers below
 
   if (p.decode_only) {  // GraphDecoder.forward alone (graph_decoder.py:108-113 state update)
-    if (p.t == 0 && p.kind != VRP_KIND_IRP) {
-      const float *sf = p.SF + ((size_t)b * N + idx) * 8 * N;
-      const float *sg = p.SG + (size_t)b * 8 * N;
-      float *b1 = p.base1 + (size_t)b * 8 * N;
-      for (int i = lane; i < 8 * N; i += 64) b1[i] = sg[i] + sf[i];
-    }
     if (lane == 0) {
       p.last[b] = idx;
       if (p.t == 0) p.first[b] = idx;
@@ -762,14 +675,7 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 
   // ---- environment step on the chosen node + episode accumulators ---------------------
   EnvStepOut eo = env_step_wave(p.env, b, idx, lane, mask_out);
-  if (p.t == 0 && p.kind != VRP_KIND_IRP) {
-    // first_ := embedding of the first chosen node (graph_decoder.py:111-113):
-    // base1 = SG + SF[first]
-    const float *sf = p.SF + ((size_t)b * N + idx) * 8 * N;
-    const float *sg = p.SG + (size_t)b * 8 * N;
-    float *b1 = p.base1 + (size_t)b * 8 * N;
-    for (int i = lane; i < 8 * N; i += 64) b1[i] = sg[i] + sf[i];
-  }
+  // (TSP/VRP: base1 for the steps after this one is built by first_row_kernel)
   if (lane == 0) {
     p.io.acc_loss[b] += (float)(-eo.dist);  // fp32 accumulate in step order, tsp_agent:85
     p.io.acc_logp[b] += logp;
@@ -1037,29 +943,20 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
   if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
 
   // ---- the only action-dependent reads: next step's score row ------------------------
-  //   base1 = SG + SF[first]  (graph_decoder.py:111-113, fixed after the first step)
-  //   curs  = base1 + SL[last = idx]
-  {
+  //   curs = base1 + SL[last = idx];  base1 = SG for IRP, and for TSP/VRP the row that
+  //   first_row_kernel builds right after step 0 (which then also writes curs)
+  if (!(p.t == 0 && p.kind != VRP_KIND_IRP)) {
     const size_t arow = ((size_t)b * N + idx) * 8 * N;
-    const bool newbase = (p.t == 0 && p.kind != VRP_KIND_IRP);
-    float sl[NPL][8], sf[NPL][8];
+    float sl[NPL][8];
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        sl[i][h] = p.SL[arow + h * N + ln[i]];
-        sf[i][h] = newbase ? p.SF[arow + h * N + ln[i]] : 0.f;
-      }
+      for (int h = 0; h < 8; ++h) sl[i][h] = p.SL[arow + h * N + ln[i]];
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const float b1 = brow[i][h] + sf[i][h];
-        if (inN[i]) {
-          if (newbase) p.base1[row + h * N + lane + 64 * i] = b1;
-          p.curs[row + h * N + lane + 64 * i] = b1 + sl[i][h];
-        }
-      }
+      for (int h = 0; h < 8; ++h)
+        if (inN[i]) p.curs[row + h * N + lane + 64 * i] = brow[i][h] + sl[i][h];
   }
   if (p.decode_only) {
     if (lane == 0) {
@@ -1152,6 +1049,8 @@ static int launch_step(const StepParams &p, hipStream_t st) {
   return 0;
 }
 
+static int launch_step_any(const StepParams &p, int flags, hipStream_t st);
+
 extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                                const vrp_env *env, const float *emb, void *workspace,
                                const vrp_rollout_io *io, int t, int max_steps, int flags,
@@ -1176,7 +1075,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.decode_only = decode_only;
   { static const char *e = getenv("VRP_FENCE"); p.fence = e ? atoi(e) : 0; }
   p.emb = emb;
-  p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SF = ws.SF; p.SL = ws.SL;
+  p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SL = ws.SL;
   p.base1 = (kind == VRP_KIND_IRP) ? ws.SG : ws.base1;
   p.curs = ws.curs;
   p.last = ws.last; p.first = ws.first;
@@ -1185,6 +1084,27 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.env = *env;
   p.io = *io;
   hipStream_t st = (hipStream_t)stream;
+  if (int r = launch_step_any(p, flags, st)) return r;
+  if (t == 0 && kind != VRP_KIND_IRP) {
+    // first_ is now known: fold its query part into base1 (and curs) once per episode
+    const int P = proj_width(kind, N);
+    hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
+    VRP_CHECK_LAUNCH("gather_first");
+    if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
+                                   384, 128, 0, st)) return r;
+    if (N <= 64)
+      hipLaunchKernelGGL(first_row_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
+                         ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
+    else
+      hipLaunchKernelGGL(first_row_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
+                         ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
+    VRP_CHECK_LAUNCH("first_row");
+  }
+  return 0;
+}
+
+static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
+  const int B = p.B, N = p.N;
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
     const bool small = B <= 2048;
     if (N <= 64 && small)
