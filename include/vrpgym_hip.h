@@ -140,15 +140,24 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
  *        VRP_STEP_DECODE_ONLY = GraphDecoder.forward alone: no env.step, no
  *        accumulation (only env->{B,N,mask,load} are read; results go to
  *        io->actions / io->step_logp / io->logits);
- *        VRP_STEP_TILE_KERNEL = use the raw-embedding-tile kernel also for N <= 64
- *        (by default N <= 64 runs the table-driven kernel). */
+ *        VRP_STEP_TILE_KERNEL = use the raw-embedding-tile kernel instead of the
+ *        table-driven one;
+ *        VRP_STEP_NO_FIRST_ROW = do not append vrp_decode_first_row to step 0. */
 #define VRP_STEP_SAMPLE 1
 #define VRP_STEP_DECODE_ONLY 2
-#define VRP_STEP_TILE_KERNEL 4 /* force the raw-tile kernel (default for N > 64) */
+#define VRP_STEP_TILE_KERNEL 4 /* use the raw-embedding-tile kernel (N <= 104) */
+#define VRP_STEP_NO_FIRST_ROW 8 /* t == 0: the caller runs vrp_decode_first_row itself */
 int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     const vrp_env *env, const float *emb, void *workspace,
                     const vrp_rollout_io *io, int t, int max_steps, int flags,
                     void *stream);
+
+/* D2  GraphDecoder.forward's `first_` update (agents/graph_decoder.py:111-113) for
+ * TSP/VRP: after step 0 the first chosen node is fixed; its part of the glimpse query is
+ * folded once into the per-graph score row.  Appended to step 0 by vrp_decode_step
+ * unless VRP_STEP_NO_FIRST_ROW is set.  No-op for IRP. */
+int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
+                         void *workspace, void *stream);
 
 /* R1  TSPModel/VRPModel/IRPModel.forward (agents/graph_tsp_agent.py:61-92,
  * graph_vrp_agent.py:52-83, graph_irp_agent.py:54-105): mask init, features,

@@ -1085,21 +1085,31 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.io = *io;
   hipStream_t st = (hipStream_t)stream;
   if (int r = launch_step_any(p, flags, st)) return r;
-  if (t == 0 && kind != VRP_KIND_IRP) {
-    // first_ is now known: fold its query part into base1 (and curs) once per episode
-    const int P = proj_width(kind, N);
-    hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
-    VRP_CHECK_LAUNCH("gather_first");
-    if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
-                                   384, 128, 0, st)) return r;
-    if (N <= 64)
-      hipLaunchKernelGGL(first_row_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
-                         ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
-    else
-      hipLaunchKernelGGL(first_row_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
-                         ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
-    VRP_CHECK_LAUNCH("first_row");
-  }
+  if (t == 0 && kind != VRP_KIND_IRP && !(flags & VRP_STEP_NO_FIRST_ROW))
+    return vrp_decode_first_row(kind, derived, B, N, emb, workspace, stream);
+  return 0;
+}
+
+// first_ is known after step 0: fold its query part into base1 (and curs) once per episode
+extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
+                                    void *workspace, void *stream) {
+  VRP_REQUIRE(derived && emb && workspace, "decode_first_row: NULL argument");
+  if (kind == VRP_KIND_IRP) return 0;  // the IRP context has no first-node term
+  hipStream_t st = (hipStream_t)stream;
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs ws = carve_decws(kind, workspace, B, N);
+  const int P = proj_width(kind, N);
+  hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
+  VRP_CHECK_LAUNCH("gather_first");
+  if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
+                                 384, 128, 0, st)) return r;
+  if (N <= 64)
+    hipLaunchKernelGGL(first_row_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
+                       ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
+  else
+    hipLaunchKernelGGL(first_row_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
+                       ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
+  VRP_CHECK_LAUNCH("first_row");
   return 0;
 }
 

@@ -219,8 +219,11 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
   const int j = lane & 31, g = lane >> 5;
   const int ncol = wave * 32 + j;     // this lane's output column / weight row
 
-  float w[64];
-  eb_load_w<MI>(w, Wo + (size_t)ncol * 128 + 64 * g);   // in flight while the tiles land
+  // Two weight-fragment sets alternate (wa: Wo, then the W2 slices; wb: the W1 slices): the
+  // loads of stage k+1 are issued before the MFMAs of stage k, so every weight fetch has a
+  // whole MFMA stage to land.
+  float wa[64], wb[64];
+  eb_load_w<MI>(wa, Wo + (size_t)ncol * 128 + 64 * g);   // in flight while the tiles land
   for (int idx = tid; idx < RTW * 32; idx += 256) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
@@ -240,8 +243,8 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
     for (int r = 0; r < 16; ++r) { acc[mi][r] = 0.f; gacc[mi][r] = 0.f; }
 
   // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
-  eb_mma<MI>(acc, bufA, w, lane);
-  eb_load_w<MI>(w, W1 + (size_t)ncol * 128 + 64 * g);   // next stage's weights
+  eb_load_w<MI>(wb, W1 + (size_t)ncol * 128 + 64 * g);   // W1 slice 0, lands during this stage
+  eb_mma<MI>(acc, bufA, wa, lane);
   {
     const float bb = bo[ncol], mean = norm1[ncol], mult = norm1[128 + ncol], beta = norm1[256 + ncol];
 #pragma unroll
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-    eb_mma<MI>(acc, bufB, w, lane);                      // w = W1 rows of slice c
-    eb_load_w<MI>(w, W2 + (size_t)ncol * hidden + c * 128 + 64 * g);
+    eb_load_w<MI>(wa, W2 + (size_t)ncol * hidden + c * 128 + 64 * g);   // W2[:, slice c]
+    eb_mma<MI>(acc, bufB, wb, lane);                                     // wb = W1 slice c
     {
       const float bb = b1[c * 128 + ncol];
 #pragma unroll
@@ -275,8 +278,8 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
         }
     }
     __syncthreads();  // slice c of the hidden layer is in bufA
-    eb_mma<MI>(gacc, bufA, w, lane);                     // w = W2[:, slice c]
-    if (c + 1 < nchunk) eb_load_w<MI>(w, W1 + (size_t)((c + 1) * 128 + ncol) * 128 + 64 * g);
+    if (c + 1 < nchunk) eb_load_w<MI>(wb, W1 + (size_t)((c + 1) * 128 + ncol) * 128 + 64 * g);
+    eb_mma<MI>(gacc, bufA, wa, lane);                                    // wa = W2[:, slice c]
     __syncthreads();  // everybody done with bufA before the next slice overwrites it
   }
 

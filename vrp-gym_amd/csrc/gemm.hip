@@ -169,8 +169,8 @@ int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, cons
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, C, ldc, M, N, K, relu);
-  } else if (tiles128 >= 1024) {
-    // enough workgroups to fill 256 CUs several times over: 128x128x16 tiles, 32 KB of LDS
+  } else if (tiles128 >= 512) {
+    // at least two workgroups per CU: 128x128x16 tiles, 32 KB of LDS
     // and 114 VGPRs -> 4 workgroups per CU overlap each other's barriers and load latency
     // (measured 89-108 TFLOP/s at M = 327680 vs 76-102 for the 128x128x32 tile at 2 per CU)
     dim3 grid(N / BN, (M + 127) / 128);

@@ -71,6 +71,7 @@ def _declare(lib):
         "vrp_decode_prologue": (i32, [i32, vp, i32, i32, vp, vp, vp]),
         "vrp_decode_step": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                   i32, i32, i32, vp]),
+        "vrp_decode_first_row": (i32, [i32, vp, i32, i32, vp, vp, vp]),
         "vrp_rollout": (i32, [i32, P(EncoderWeights), P(DecoderWeights), vp, P(Env), i32, i32,
                               vp, vp, vp, P(RolloutIO), i32, vp]),
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
