@@ -182,6 +182,22 @@ int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *
 int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
                             double *pos_out_host, int64_t *depots_host, double *demands_host);
 
+/* ---- backward pass (K4): building blocks, each unit-tested against torch autograd ---- */
+/* C (N1,N2) (+)= X^T Y over R rows; deterministic split-K; slab_ws from *_workspace_bytes. */
+int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);
+int vrp_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1, int N2,
+                int accumulate, void *slab_ws, void *stream);
+/* out (N) (+)= column sums of Y (R,N). */
+int vrp_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *stream);
+/* BatchNorm1d(128) backward with batch statistics (agents/graph_encoder.py:141-154 in
+ * train mode): stats = [mean | invstd], z = pre-normalisation input. */
+int64_t vrp_bn_bwd_workspace_bytes(void);
+int vrp_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma, int R,
+               float *dz, float *dgamma, float *dbeta, int accumulate, void *ws, void *stream);
+/* Encoder self-attention backward per (graph, head) (graph_encoder.py:170-172,196):
+ * qkv (B*N,384) forward projections, dO (B*N,128) -> dqkv (B*N,384). */
+int vrp_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N, void *stream);
+
 /* Building blocks exported for tests and profiling. */
 int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                 const float *residual, int ldr, float *C, int ldc, int M, int N, int K,

@@ -1,0 +1,373 @@
+// Building blocks of the hand-written backward pass (K4 of SURVEY.md 7.1): the gradient of
+// sum_t log p(a_t) w.r.t. every parameter (REINFORCE, agents/graph_tsp_agent.py:178-186).
+//   gemm_tn     dW = dY^T X        (weight gradients; fp32 MFMA, deterministic split-K)
+//   colsum      db = sum_r dY[r]   (bias gradients)
+//   transpose   W^T copies so that dX = dY W runs on the forward GEMM kernel
+//   bn_bwd      BatchNorm1d backward with batch statistics (train mode)
+//   attn_bwd    per-(graph, head) softmax-attention backward of the encoder
+//   embed_bwd   node/depot embedding weight gradients
+// Everything is fp32; reductions over rows are done in a fixed order (no float atomics), so
+// gradients are bitwise reproducible.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ C = X^T Y (split over rows)
+// X (R,N1), Y (R,N2) row-major.  Workgroup (tile i, tile j, split s) computes the 128x128
+// tile of X[r0:r1]^T Y[r0:r1] with v_mfma_f32_32x32x2_f32 (A[i][k=r] = X[r][i]: lanes run
+// along i, so the LDS reads of a row-major (r, col) tile are conflict-free) and writes it to
+// slab s; a second kernel sums the slabs in order.
+#define TN_BR 32
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict__ X, int ldx,
+                                                         const float *__restrict__ Y, int ldy,
+                                                         float *__restrict__ slabs, int R, int N1,
+                                                         int N2, int rows_per_split) {
+  __shared__ float4 Xs[TN_BR * 32];  // [r][128 cols] as float4
+  __shared__ float4 Ys[TN_BR * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128, sp = blockIdx.z;
+  const int r_begin = sp * rows_per_split;
+  const int r_end = min(R, r_begin + rows_per_split);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int lr = tid >> 5, lc = tid & 31;  // 8 rows x 32 float4 columns per pass
+  const int fi = lane & 31, fk = lane >> 5;
+  for (int r0 = r_begin; r0 < r_end; r0 += TN_BR) {
+#pragma unroll
+    for (int s = 0; s < TN_BR / 8; ++s) {
+      const int r = r0 + lr + 8 * s;
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
+      if (r < r_end) {
+        xv = *reinterpret_cast<const float4 *>(X + (size_t)r * ldx + i0 + 4 * lc);
+        yv = *reinterpret_cast<const float4 *>(Y + (size_t)r * ldy + j0 + 4 * lc);
+      }
+      Xs[(lr + 8 * s) * 32 + lc] = xv;
+      Ys[(lr + 8 * s) * 32 + lc] = yv;
+    }
+    __syncthreads();
+    const float *xs = reinterpret_cast<const float *>(Xs);
+    const float *ys = reinterpret_cast<const float *>(Ys);
+#pragma unroll
+    for (int rr = 0; rr < TN_BR; rr += 2) {
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = xs[(rr + fk) * 128 + wm * 64 + t * 32 + fi];
+        b[t] = ys[(rr + fk) * 128 + wn * 64 + t * 32 + fi];
+      }
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float *out = slabs + (size_t)sp * N1 * N2;
+  const int col = lane & 31, rq = lane >> 5;
+#pragma unroll
+  for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wm * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rq;
+        const int j = j0 + wn * 64 + tb * 32 + col;
+        out[(size_t)i * N2 + j] = acc[ta][tb][r];
+      }
+}
+
+// C[i] (+)= sum_s slabs[s][i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs,
+                                                          float *__restrict__ C, size_t n,
+                                                          int nsplit, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? C[i] : 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + i];
+  C[i] = s;
+}
+
+extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2) {
+  int nsplit = (R + 2047) / 2048;
+  if (nsplit > 128) nsplit = 128;
+  return (int64_t)nsplit * N1 * N2 * sizeof(float);
+}
+
+int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
+                       int N2, int accumulate, void *slab_ws, hipStream_t st) {
+  VRP_REQUIRE(R > 0 && N1 % 128 == 0 && N2 % 128 == 0, "gemm_tn: bad shape R=%d N1=%d N2=%d", R,
+              N1, N2);
+  int nsplit = (R + 2047) / 2048;
+  if (nsplit > 128) nsplit = 128;
+  int rps = (R + nsplit - 1) / nsplit;
+  rps = (rps + TN_BR - 1) / TN_BR * TN_BR;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 128, N2 / 128, nsplit), dim3(256), 0, st, X, ldx, Y,
+                     ldy, (float *)slab_ws, R, N1, N2, rps);
+  VRP_CHECK_LAUNCH("gemm_tn");
+  const size_t n = (size_t)N1 * N2;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const float *)slab_ws, C, n, nsplit, accumulate);
+  VRP_CHECK_LAUNCH("slab_reduce");
+  return 0;
+}
+
+extern "C" int vrp_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R,
+                           int N1, int N2, int accumulate, void *slab_ws, void *stream) {
+  return vrp_launch_gemm_tn(X, ldx, Y, ldy, C, R, N1, N2, accumulate, slab_ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// out[c] (+)= sum_r Y[r][c]; one workgroup per 64 columns, fp64 accumulation, fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ Y, int ldy, int R,
+                                                     int N, float *__restrict__ out,
+                                                     int accumulate) {
+  __shared__ double sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double s = 0.0;
+  if (c < N)
+    for (int r = part; r < R; r += 4) s += (double)Y[(size_t)r * ldy + c];
+  sh[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < N) {
+    const double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)t;
+  }
+}
+
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, Y, ldy, R, N, out,
+                     accumulate);
+  VRP_CHECK_LAUNCH("colsum");
+  return 0;
+}
+
+extern "C" int vrp_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+                          void *stream) {
+  return vrp_launch_colsum(Y, ldy, R, N, out, accumulate, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ transpose (small weights)
+__global__ void transpose_kernel(const float *__restrict__ src, int rows, int cols, int lds,
+                                 float *__restrict__ dst) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  const int r = idx / cols, c = idx - r * cols;
+  dst[(size_t)c * rows + r] = src[(size_t)r * lds + c];
+}
+
+int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *dst, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, st, src, rows,
+                     cols, lds, dst);
+  VRP_CHECK_LAUNCH("transpose");
+  return 0;
+}
+
+// ------------------------------------------------------------------ BatchNorm1d backward (train)
+// y = (z - mean) * invstd * gamma + beta over R rows.  Given dy:
+//   dbeta = sum dy,  dgamma = sum dy * xhat,
+//   dz = gamma * invstd / R * (R * dy - dbeta - xhat * dgamma)
+// sums[0:128] = sum dy, sums[128:256] = sum dy*xhat  (fp64, zeroed by the caller)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ dy,
+                                                            const float *__restrict__ z,
+                                                            const float *__restrict__ stats, int R,
+                                                            double *__restrict__ sums) {
+  __shared__ double sh[2][256];
+  const int c = threadIdx.x & 127, par = threadIdx.x >> 7;
+  const float mean = stats[c], invstd = stats[128 + c];
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = blockIdx.x * 2 + par; r < R; r += gridDim.x * 2) {
+    const float d = dy[(size_t)r * 128 + c];
+    const float xh = (z[(size_t)r * 128 + c] - mean) * invstd;
+    s0 += (double)d;
+    s1 += (double)d * (double)xh;
+  }
+  sh[0][threadIdx.x] = s0;
+  sh[1][threadIdx.x] = s1;
+  __syncthreads();
+  if (par == 0) {  // per-block partials go to a slab; summed in order by the apply kernel
+    sums[(size_t)blockIdx.x * 256 + c] = sh[0][c] + sh[0][c + 128];
+    sums[(size_t)blockIdx.x * 256 + 128 + c] = sh[1][c] + sh[1][c + 128];
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks,
+                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                       double *__restrict__ totals, int accumulate) {
+  const int c = threadIdx.x;  // 0..255
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 256 + c];
+  totals[c] = s;
+  if (c < 128) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
+  else dgamma[c - 128] = (accumulate ? dgamma[c - 128] : 0.f) + (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dy,
+                                                           const float *__restrict__ z,
+                                                           const float *__restrict__ stats,
+                                                           const float *__restrict__ gamma,
+                                                           const double *__restrict__ totals, int R,
+                                                           float *__restrict__ dz) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * 128) return;
+  const int c = (int)(i & 127);
+  const float mean = stats[c], invstd = stats[128 + c];
+  const float xh = (z[i] - mean) * invstd;
+  const float db = (float)totals[c], dg = (float)totals[128 + c];
+  dz[i] = gamma[c] * invstd * (dy[i] - (db + xh * dg) / (float)R);
+}
+
+extern "C" int64_t vrp_bn_bwd_workspace_bytes(void) { return (int64_t)(1024 + 1) * 256 * 8; }
+
+int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
+                      int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
+                      hipStream_t st) {
+  int blocks = (R + 1) / 2;
+  if (blocks > 1024) blocks = 1024;
+  double *partial = (double *)ws;
+  double *totals = partial + (size_t)1024 * 256;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, dy, z, stats, R, partial);
+  VRP_CHECK_LAUNCH("bn_bwd_reduce");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, dgamma,
+                     dbeta, totals, accumulate);
+  VRP_CHECK_LAUNCH("bn_bwd_finalize");
+  const size_t n = (size_t)R * 128;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, z,
+                     stats, gamma, totals, R, dz);
+  VRP_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int vrp_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
+                          int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
+                          void *stream) {
+  return vrp_launch_bn_bwd(dy, z, stats, gamma, R, dz, dgamma, dbeta, accumulate, ws,
+                           (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ encoder attention backward
+// Per (graph, head): P = softmax(Q K^T / 4), O = P V.  Given dO:
+//   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - rowsum(dP o P)),  dQ = dS K / 4,  dK = dS^T Q / 4
+// One wave per (graph, head).  Pass A (lane = query row i): row max, row sum, D_i and dQ_i.
+// Pass B (lane = key row j): dK_j, dV_j with P recomputed from the row statistics in LDS.
+__global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float *__restrict__ qkv,
+                                                                    const float *__restrict__ dO,
+                                                                    float *__restrict__ dqkv,
+                                                                    int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  // per wave: Q,K,V,dO (N x 16 each), row max / inverse sum / D (N each)
+  float *Qs = smem + (size_t)wave * N * 67;
+  float *Ks = Qs + N * 16, *Vs = Ks + N * 16, *Gs = Vs + N * 16;
+  float *mx = Gs + N * 16, *isum = mx + N, *Dv = isum + N;
+  const float *base = qkv + (size_t)b * N * 384;
+  const float *gbase = dO + (size_t)b * N * 128;
+  for (int idx = lane; idx < N * 4; idx += 64) {
+    const int j = idx >> 2, q4 = (idx & 3) * 4;
+    *reinterpret_cast<float4 *>(Qs + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + h * 16 + q4);
+    *reinterpret_cast<float4 *>(Ks + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * 16 + q4);
+    *reinterpret_cast<float4 *>(Vs + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * 16 + q4);
+    *reinterpret_cast<float4 *>(Gs + j * 16 + q4) =
+        *reinterpret_cast<const float4 *>(gbase + (size_t)j * 128 + h * 16 + q4);
+  }
+  __syncthreads();
+  // ---- pass A: lane = i
+  for (int i = lane; i < N; i += 64) {
+    float q[16], g[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { q[d] = Qs[i * 16 + d] * 0.25f; g[d] = Gs[i * 16 + d]; }
+    float m = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      m = fmaxf(m, s);
+    }
+    float l = 0.f, Dacc = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], Ks[j * 16 + d], s); dp = fmaf(g[d], Vs[j * 16 + d], dp); }
+      const float p = expf(s - m);
+      l += p;
+      Dacc = fmaf(p, dp, Dacc);
+    }
+    const float inv = 1.f / l;
+    const float Di = Dacc * inv;  // sum_j P_ij dP_ij
+    float dq[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) dq[d] = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], Ks[j * 16 + d], s); dp = fmaf(g[d], Vs[j * 16 + d], dp); }
+      const float ds = expf(s - m) * inv * (dp - Di);
+#pragma unroll
+      for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds, Ks[j * 16 + d], dq[d]);
+    }
+    mx[i] = m; isum[i] = inv; Dv[i] = Di;
+    float *dst = dqkv + ((size_t)b * N + i) * 384 + h * 16;
+#pragma unroll
+    for (int d = 0; d < 16; d += 4)
+      *reinterpret_cast<float4 *>(dst + d) = make_float4(dq[d] * 0.25f, dq[d + 1] * 0.25f,
+                                                         dq[d + 2] * 0.25f, dq[d + 3] * 0.25f);
+  }
+  __syncthreads();
+  // ---- pass B: lane = j
+  for (int j = lane; j < N; j += 64) {
+    float k[16], v[16], dk[16], dv[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) { k[d] = Ks[j * 16 + d]; v[d] = Vs[j * 16 + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < N; ++i) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) { s = fmaf(Qs[i * 16 + d] * 0.25f, k[d], s); dp = fmaf(Gs[i * 16 + d], v[d], dp); }
+      const float p = expf(s - mx[i]) * isum[i];
+      const float ds = p * (dp - Dv[i]);
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        dv[d] = fmaf(p, Gs[i * 16 + d], dv[d]);
+        dk[d] = fmaf(ds, Qs[i * 16 + d] * 0.25f, dk[d]);
+      }
+    }
+    float *dst = dqkv + ((size_t)b * N + j) * 384 + h * 16;
+#pragma unroll
+    for (int d = 0; d < 16; d += 4) {
+      *reinterpret_cast<float4 *>(dst + 128 + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+      *reinterpret_cast<float4 *>(dst + 256 + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+    }
+  }
+}
+
+int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
+                             hipStream_t st) {
+  const size_t lds = (size_t)4 * N * 67 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      vrp_set_error("attention_bwd: cannot raise dynamic LDS");
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(encoder_attention_bwd_kernel, dim3(B, 2), dim3(256), lds, st, qkv, dO, dqkv, N);
+  VRP_CHECK_LAUNCH("encoder_attention_bwd");
+  return 0;
+}
+
+extern "C" int vrp_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
+                                 void *stream) {
+  return vrp_launch_attention_bwd(qkv, dO, dqkv, B, N, (hipStream_t)stream);
+}

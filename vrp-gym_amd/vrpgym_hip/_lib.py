@@ -77,6 +77,12 @@ def _declare(lib):
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                     i32, i32, vp]),
         "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "vrp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
+        "vrp_gemm_tn": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]),
+        "vrp_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp]),
+        "vrp_bn_bwd_workspace_bytes": (i64, []),
+        "vrp_bn_bwd": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp]),
+        "vrp_attention_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
