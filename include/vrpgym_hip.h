@@ -198,10 +198,39 @@ int vrp_bn_bwd(const float *dy, const float *z, const float *stats, const float 
  * qkv (B*N,384) forward projections, dO (B*N,128) -> dqkv (B*N,384). */
 int vrp_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N, void *stream);
 
+/* Parameter-gradient views (same names as the state_dict; every buffer is overwritten). */
+typedef struct vrp_encoder_layer_grads {
+  float *in_proj_weight, *in_proj_bias, *out_proj_weight, *out_proj_bias;
+  float *bn1_weight, *bn1_bias, *ff0_weight, *ff0_bias, *ff2_weight, *ff2_bias;
+  float *bn2_weight, *bn2_bias;
+} vrp_encoder_layer_grads;
+typedef struct vrp_encoder_grads {
+  float *node_embed_weight, *node_embed_bias, *depot_embed_weight, *depot_embed_bias;
+  vrp_encoder_layer_grads layer[8];
+} vrp_encoder_grads;
+
+/* N1-N3 in train mode with every intermediate kept on a tape (for the backward pass):
+ * same arithmetic as vrp_encoder_forward(train=1); update_running = 0 leaves the
+ * BatchNorm running statistics untouched (a recompute of an already counted pass). */
+int64_t vrp_encoder_tape_bytes(int B, int N, int hidden, int num_layers);
+int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int N, const float *x,
+                             const uint8_t *depot_mask, float *emb, void *tape,
+                             int update_running, void *stream);
+/* Backward of the encoder: d_emb (B,N,128) -> gradients of every encoder parameter. */
+int64_t vrp_encoder_backward_workspace_bytes(int B, int N, int hidden);
+int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_encoder_grads *g, int B, int N,
+                         const float *x, const uint8_t *depot_mask, const void *tape,
+                         const float *d_emb, void *workspace, void *stream);
+
 /* Building blocks exported for tests and profiling. */
 int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                 const float *residual, int ldr, float *C, int ldc, int M, int N, int K,
                 int relu, void *stream);
+
+/* C = (A W^T + residual) with entries zeroed where gate <= 0 (ReLU backward). */
+int vrp_gemm_nt_gated(const float *A, int lda, const float *W, int ldw, const float *residual,
+                      int ldr, const float *gate, float *C, int ldc, int M, int N, int K,
+                      void *stream);
 
 const char *vrp_last_error(void);
 int vrp_abi_version(void);

@@ -84,3 +84,67 @@ def test_attention_backward():
         hip.check(lib.vrp_attention_bwd(qkv.detach().data_ptr(), dO.data_ptr(), dqkv.data_ptr(),
                                         B, N, st))
         assert (dqkv - qkv.grad).abs().max().item() < 5e-5, (B, N)
+
+
+@pytest.mark.parametrize("kind,B,N", [(0, 7, 9), (1, 16, 20), (2, 5, 33), (1, 40, 40), (0, 5, 33), (2, 16, 20), (2, 5, 32), (1, 5, 33)])
+def test_encoder_backward_against_oracle_autograd(kind, B, N):
+    """Taped train-mode forward == regular train forward; encoder parameter gradients of
+    sum(emb * G) == autograd through the CPU oracle's explicit-math encoder."""
+    import agents
+    from agents import runtime
+    from oracle import policy as opol
+    Agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
+    agent = Agent(seed=69)
+    enc = agent.model.encoder
+    enc.train()
+    g = torch.Generator().manual_seed(B * N + kind)
+    x = torch.rand(B, N, 3, generator=g)
+    dm = torch.zeros(B, N, dtype=torch.bool)
+    dm[torch.arange(B), torch.randint(0, N, (B,), generator=g)] = True
+    G = torch.randn(B, N, 128, generator=g)
+    # oracle (CPU autograd), once in fp64 (the reference value) and once in fp32: the ReLU
+    # gates make the gradient discontinuous, a pre-activation within rounding of zero flips a
+    # whole row of ff.0 — the fp32-vs-fp64 gap of the oracle itself measures that noise.
+    def oracle_grads(dtype):
+        sd, _ = opol.init_state_dicts(kind, 69)
+        psd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        psd = {k: v.requires_grad_(v.is_floating_point() and "running" not in k)
+               for k, v in psd.items()}
+        xin = (x if kind == 2 else x[:, :, :2]).to(dtype)
+        o = opol.encoder_forward(psd, xin, None if kind == 0 else dm, train=True)
+        (o * G.to(dtype)).sum().backward()
+        return o.detach(), psd
+    oemb, psd = oracle_grads(torch.float32)
+    _, psd64 = oracle_grads(torch.float64)
+    # HIP
+    x3 = x.clone()
+    if kind != 2:
+        x3[:, :, 2] = 0
+    x3 = x3.cuda().contiguous()
+    dmu = None if kind == 0 else dm.to(torch.uint8).cuda().contiguous()
+    emb, tape = runtime.encoder_forward_tape(enc, x3, dmu, update_running=True)
+    assert (emb.cpu() - oemb.detach()).abs().max().item() < 2e-5
+    params, grads = runtime.encoder_backward(enc, x3, dmu, tape, G.cuda())
+    names = {id(p): n for n, p in enc.named_parameters()}
+    # Biases added right before a train-mode BatchNorm (out_proj.bias, ff.2.bias) and the key
+    # bias have an exactly-zero true gradient: both sides only produce rounding noise there,
+    # so errors are judged against the tensor's own scale PLUS a floor tied to the typical
+    # gradient magnitude of the layer stack.
+    wants = [None if p is None else psd64["encoder." + names[id(p)]].grad for p in params]
+    noise = [None if p is None else
+             (psd["encoder." + names[id(p)]].grad.double() - w).abs().max().item()
+             for p, w in zip(params, wants)]
+    floor = 1e-5 * float(np.max([w.abs().max().item() for w in wants if w is not None]))
+    checked, report = 0, []
+    for p, gr, want, nz in zip(params, grads, wants, noise):
+        if p is None:
+            continue
+        err = (gr.cpu().double() - want).abs().max().item()
+        tol = 2e-4 * want.abs().max().item() + max(floor, 2e-5) + 4.0 * nz
+        report.append((err / tol, names[id(p)], err, want.abs().max().item()))
+        checked += 1
+    report.sort(reverse=True)
+    assert report[0][0] < 1.0, report[:5]
+    assert checked == (2 if kind == 0 else 4) + 12 * 3
+    nb = enc.attention_layers[0].bn1.norm.num_batches_tracked.item()
+    assert nb == 1

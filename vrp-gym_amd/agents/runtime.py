@@ -453,3 +453,56 @@ def attach_grad(model, env, res):
     lives in agents/backward.py."""
     from . import backward
     return backward.logp_with_grad(model, env, res)
+
+
+# ------------------------------------------------------------------ backward pass (K4)
+def encoder_param_list(enc):
+    """Encoder parameters in the order of the vrp_encoder_grads struct."""
+    out = [enc.node_embed.weight, enc.node_embed.bias]
+    dep = getattr(enc, "depot_embed", None)
+    out += [dep.weight, dep.bias] if dep is not None else [None, None]
+    for layer in enc.attention_layers:
+        att = layer.attention_layer
+        out += [att.in_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias,
+                layer.bn1.norm.weight, layer.bn1.norm.bias, layer.ff[0].weight, layer.ff[0].bias,
+                layer.ff[2].weight, layer.ff[2].bias, layer.bn2.norm.weight, layer.bn2.norm.bias]
+    return out
+
+
+def encoder_forward_tape(enc, x3, depot_mask_u8, update_running):
+    """Train-mode encoder forward keeping every intermediate (vrp_encoder_forward_tape)."""
+    dev = _require_cuda(enc)
+    lib = hip.lib()
+    w = encoder_struct(enc)
+    B, N, _ = x3.shape
+    emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
+    tape = torch.empty(int(lib.vrp_encoder_tape_bytes(B, N, w.hidden, w.num_layers)),
+                       dtype=torch.uint8, device=dev)
+    hip.check(lib.vrp_encoder_forward_tape(C.byref(w), B, N, x3.data_ptr(), hip.ptr(depot_mask_u8),
+                                           emb.data_ptr(), tape.data_ptr(),
+                                           int(bool(update_running)), hip.current_stream(dev)))
+    return emb, tape
+
+
+def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb):
+    """Gradients of every encoder parameter given d_emb; list aligned with encoder_param_list."""
+    dev = _require_cuda(enc)
+    lib = hip.lib()
+    w = encoder_struct(enc)
+    B, N, _ = x3.shape
+    params = encoder_param_list(enc)
+    grads = [None if p is None else torch.empty_like(p) for p in params]
+    g = hip.EncoderGrads()
+    ptrs = [hip.ptr(t) for t in grads]
+    g.node_embed_weight, g.node_embed_bias, g.depot_embed_weight, g.depot_embed_bias = ptrs[:4]
+    names = [n for n, _ in hip._lib.EncoderLayerGrads._fields_]
+    for l in range(w.num_layers):
+        for k, n in enumerate(names):
+            setattr(g.layer[l], n, ptrs[4 + 12 * l + k])
+    ws = torch.empty(int(lib.vrp_encoder_backward_workspace_bytes(B, N, w.hidden)),
+                     dtype=torch.uint8, device=dev)
+    d_emb = d_emb.contiguous()
+    hip.check(lib.vrp_encoder_backward(C.byref(w), C.byref(g), B, N, x3.data_ptr(),
+                                       hip.ptr(depot_mask_u8), tape.data_ptr(), d_emb.data_ptr(),
+                                       ws.data_ptr(), hip.current_stream(dev)))
+    return params, grads

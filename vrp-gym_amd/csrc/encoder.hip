@@ -12,6 +12,21 @@ int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const f
 int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, const float *bias,
                           const float *R, int ldr, const float *norm, float *C, int ldc, int M,
                           int N, int K, int relu, hipStream_t stream);
+int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, const float *bias,
+                            const float *R, int ldr, const float *norm, const float *gate, float *C,
+                            int ldc, int M, int N, int K, int relu, hipStream_t stream);
+int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
+                       int N2, int accumulate, void *slab_ws, hipStream_t st);
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+                      hipStream_t st);
+int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *dst, hipStream_t st);
+int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
+                      int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
+                      hipStream_t st);
+int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
+                             hipStream_t st);
+extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);
+extern "C" int64_t vrp_bn_bwd_workspace_bytes(void);
 
 // ---- embedding: node_embed / depot_embed select (graph_encoder.py:54, 110-132) -----
 __global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x,
@@ -432,5 +447,269 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
     vrp_set_error("encoder: internal buffer parity error");
     return 3;
   }
+  return 0;
+}
+
+
+// =========================================================================================
+// Train-mode forward with a tape, and the backward pass of the encoder (K4).
+// =========================================================================================
+
+// out-of-place train-mode BatchNorm: y = (z - mean) * invstd * gamma + beta with the batch
+// statistics in `sums`; writes stats = [mean | invstd] for the backward pass
+__global__ __launch_bounds__(256) void bn_train_apply_oop_kernel(
+    const float *__restrict__ z, float *__restrict__ y, size_t n4,
+    const double *__restrict__ sums, int rows, const float *__restrict__ weight,
+    const float *__restrict__ bias, float *__restrict__ stats, float *running_mean,
+    float *running_var, int64_t *num_batches_tracked, int update_running) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    const double m = sums[c] / rows;
+    double v = sums[128 + c] / rows - m * m;
+    if (v < 0.0) v = 0.0;
+    stats[c] = (float)m;
+    stats[128 + c] = 1.f / sqrtf((float)v + 1e-5f);
+    if (update_running) {
+      const float unbiased = (float)(v * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
+      running_mean[c] = 0.9f * running_mean[c] + 0.1f * (float)m;
+      running_var[c] = 0.9f * running_var[c] + 0.1f * unbiased;
+      if (c == 0) *num_batches_tracked += 1;
+    }
+  }
+  if (i >= n4) return;
+  const int c0 = (int)(i & 31) * 4;
+  const float4 v = reinterpret_cast<const float4 *>(z)[i];
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const double m = sums[c] / rows;
+    double var = sums[128 + c] / rows - m * m;
+    if (var < 0.0) var = 0.0;
+    o[j] = (o[j] - (float)m) * (weight[c] / sqrtf((float)var + 1e-5f)) + bias[c];
+  }
+  reinterpret_cast<float4 *>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+struct LayerTape {
+  float *X, *QKV, *ATT, *Z1, *Y1, *H, *Z2, *stats1, *stats2;
+};
+struct EncTape {
+  LayerTape layer[8];
+  float *OUT;      // output of the last layer = emb copy is NOT kept; X of layer l+1 = out of l
+  double *sums;    // 256 doubles: batch-statistic scratch
+};
+
+static size_t layer_tape_floats(size_t R, int hidden) {
+  return R * (128 + 384 + 128 + 128 + 128 + (size_t)hidden + 128) + 512;
+}
+
+extern "C" int64_t vrp_encoder_tape_bytes(int B, int N, int hidden, int num_layers) {
+  const size_t R = (size_t)B * N;
+  return (int64_t)(num_layers * vrp_align_up(layer_tape_floats(R, hidden) * 4) + vrp_align_up(256 * 8));
+}
+
+static EncTape carve_tape(void *tape, int B, int N, int hidden, int num_layers) {
+  const size_t R = (size_t)B * N;
+  EncTape t;
+  char *p = (char *)tape;
+  for (int l = 0; l < num_layers; ++l) {
+    float *f = (float *)p;
+    LayerTape &L = t.layer[l];
+    L.X = f;    f += R * 128;
+    L.QKV = f;  f += R * 384;
+    L.ATT = f;  f += R * 128;
+    L.Z1 = f;   f += R * 128;
+    L.Y1 = f;   f += R * 128;
+    L.H = f;    f += R * (size_t)hidden;
+    L.Z2 = f;   f += R * 128;
+    L.stats1 = f; f += 256;
+    L.stats2 = f; f += 256;
+    p += vrp_align_up(layer_tape_floats(R, hidden) * 4);
+  }
+  t.sums = (double *)p;
+  t.OUT = nullptr;
+  return t;
+}
+
+static int bn_train_taped(const float *z, float *y, int rows, const float *w, const float *b,
+                          float *stats, float *rm, float *rv, int64_t *nbt, int update,
+                          double *sums, hipStream_t st) {
+  hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, sums);
+  VRP_CHECK_LAUNCH("bn_zero_stats");
+  int blocks = (rows + 1) / 2;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, z, rows, sums);
+  VRP_CHECK_LAUNCH("bn_stats");
+  const size_t n4 = (size_t)rows * 32;
+  hipLaunchKernelGGL(bn_train_apply_oop_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                     z, y, n4, sums, rows, w, b, stats, rm, rv, nbt, update);
+  VRP_CHECK_LAUNCH("bn_train_apply_oop");
+  return 0;
+}
+
+extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int N, const float *x,
+                                        const uint8_t *depot_mask, float *emb, void *tape,
+                                        int update_running, void *stream) {
+  VRP_REQUIRE(w && x && emb && tape, "encoder_tape: NULL argument");
+  VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder_tape: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8 && w->hidden % 128 == 0,
+              "encoder_tape: unsupported architecture");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = B * N, L_ = w->num_layers;
+  EncTape t = carve_tape(tape, B, N, w->hidden, L_);
+  hipLaunchKernelGGL(embed_kernel, dim3((R + 1) / 2), dim3(256), 0, st, x, depot_mask,
+                     w->node_embed_weight, w->node_embed_bias, w->node_dim,
+                     w->depot_embed_weight, w->depot_embed_bias, w->depot_dim, t.layer[0].X, R);
+  VRP_CHECK_LAUNCH("embed");
+  for (int l = 0; l < L_; ++l) {
+    const vrp_encoder_layer &P = w->layer[l];
+    const LayerTape &T = t.layer[l];
+    float *out = (l + 1 < L_) ? t.layer[l + 1].X : emb;
+    if (int r = vrp_launch_gemm_nt(T.X, 128, P.in_proj_weight, 128, P.in_proj_bias, nullptr, 0,
+                                   T.QKV, 384, R, 384, 128, 0, st)) return r;
+    const size_t lds = (size_t)4 * N * 32 * sizeof(float);
+    hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, T.QKV, T.ATT, N);
+    VRP_CHECK_LAUNCH("encoder_attention");
+    if (int r = vrp_launch_gemm_nt(T.ATT, 128, P.out_proj_weight, 128, P.out_proj_bias, T.X, 128,
+                                   T.Z1, 128, R, 128, 128, 0, st)) return r;
+    if (int r = bn_train_taped(T.Z1, T.Y1, R, P.bn1_weight, P.bn1_bias, T.stats1,
+                               P.bn1_running_mean, P.bn1_running_var, P.bn1_num_batches_tracked,
+                               update_running, t.sums, st)) return r;
+    if (int r = vrp_launch_gemm_nt(T.Y1, 128, P.ff0_weight, 128, P.ff0_bias, nullptr, 0, T.H,
+                                   w->hidden, R, w->hidden, 128, 1, st)) return r;
+    if (int r = vrp_launch_gemm_nt(T.H, w->hidden, P.ff2_weight, w->hidden, P.ff2_bias, T.Y1, 128,
+                                   T.Z2, 128, R, 128, w->hidden, 0, st)) return r;
+    if (int r = bn_train_taped(T.Z2, out, R, P.bn2_weight, P.bn2_bias, T.stats2,
+                               P.bn2_running_mean, P.bn2_running_var, P.bn2_num_batches_tracked,
+                               update_running, t.sums, st)) return r;
+  }
+  return 0;
+}
+
+// node/depot embedding gradients: column c of dX0 against [x0, x1, x2, 1], split by the depot
+// flag.  out[c][0..3] node (d0,d1,d2,bias), out[c][4..6] depot (d0,d1,bias)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict__ dX0,
+                                                        const float *__restrict__ x,
+                                                        const uint8_t *__restrict__ depot_mask,
+                                                        int rows, float *__restrict__ out) {
+  __shared__ double sh[2][128][7];
+  const int c = threadIdx.x & 127, par = threadIdx.x >> 7;
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int r = par; r < rows; r += 2) {
+    const double g = (double)dX0[(size_t)r * 128 + c];
+    const float *xr = x + (size_t)r * 3;
+    if (depot_mask && depot_mask[r]) {
+      a[4] += g * xr[0]; a[5] += g * xr[1]; a[6] += g;
+    } else {
+      a[0] += g * xr[0]; a[1] += g * xr[1]; a[2] += g * xr[2]; a[3] += g;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) sh[par][c][k] = a[k];
+  __syncthreads();
+  if (par == 0)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) out[c * 7 + k] = (float)(sh[0][c][k] + sh[1][c][k]);
+}
+
+__global__ void embed_bwd_scatter_kernel(const float *__restrict__ acc, int node_dim, int depot_dim,
+                                         float *dWn, float *dbn, float *dWd, float *dbd) {
+  const int c = threadIdx.x;
+  for (int d = 0; d < node_dim; ++d) dWn[c * node_dim + d] = acc[c * 7 + d];
+  dbn[c] = acc[c * 7 + 3];
+  if (dWd) {
+    for (int d = 0; d < depot_dim; ++d) dWd[c * depot_dim + d] = acc[c * 7 + 4 + d];
+    dbd[c] = acc[c * 7 + 6];
+  }
+}
+
+struct EncBwdWs {
+  float *gA, *gB, *gC, *gQKV, *gH, *WT, *embacc;
+  void *slab, *bnws;
+};
+
+extern "C" int64_t vrp_encoder_backward_workspace_bytes(int B, int N, int hidden) {
+  const size_t R = (size_t)B * N;
+  const int big = hidden > 384 ? hidden : 384;
+  return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
+                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up((size_t)big * 128 * 4) +
+                   vrp_align_up(128 * 7 * 4) +
+                   vrp_align_up((size_t)vrp_gemm_tn_workspace_bytes((int)R, big, big)) +
+                   vrp_align_up((size_t)vrp_bn_bwd_workspace_bytes()));
+}
+
+static EncBwdWs carve_enc_bwd(void *ws, int B, int N, int hidden) {
+  const size_t R = (size_t)B * N;
+  const int big = hidden > 384 ? hidden : 384;
+  char *p = (char *)ws;
+  EncBwdWs w;
+  w.gA = (float *)p;   p += vrp_align_up(R * 128 * 4);
+  w.gB = (float *)p;   p += vrp_align_up(R * 128 * 4);
+  w.gC = (float *)p;   p += vrp_align_up(R * 128 * 4);
+  w.gQKV = (float *)p; p += vrp_align_up(R * 384 * 4);
+  w.gH = (float *)p;   p += vrp_align_up(R * (size_t)hidden * 4);
+  w.WT = (float *)p;   p += vrp_align_up((size_t)big * 128 * 4);
+  w.embacc = (float *)p; p += vrp_align_up(128 * 7 * 4);
+  w.slab = p;          p += vrp_align_up((size_t)vrp_gemm_tn_workspace_bytes((int)R, big, big));
+  w.bnws = p;
+  return w;
+}
+
+extern "C" int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_encoder_grads *g, int B,
+                                    int N, const float *x, const uint8_t *depot_mask,
+                                    const void *tape, const float *d_emb, void *workspace,
+                                    void *stream) {
+  VRP_REQUIRE(w && g && x && tape && d_emb && workspace, "encoder_backward: NULL argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = B * N, L_ = w->num_layers, Hd = w->hidden;
+  EncTape t = carve_tape(const_cast<void *>(tape), B, N, Hd, L_);
+  EncBwdWs s = carve_enc_bwd(workspace, B, N, Hd);
+  const float *dout = d_emb;  // gradient w.r.t. the layer's output
+  for (int l = L_ - 1; l >= 0; --l) {
+    const vrp_encoder_layer &P = w->layer[l];
+    const vrp_encoder_layer_grads &G = g->layer[l];
+    const LayerTape &T = t.layer[l];
+    // out = BN2(Z2),  Z2 = Y1 + relu(Y1 W1^T + b1) W2^T + b2
+    if (int r = vrp_launch_bn_bwd(dout, T.Z2, T.stats2, P.bn2_weight, R, s.gB, G.bn2_weight,
+                                  G.bn2_bias, 0, s.bnws, st)) return r;          // gB = dZ2
+    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.ff2_bias, 0, st)) return r;
+    if (int r = vrp_launch_gemm_tn(s.gB, 128, T.H, Hd, G.ff2_weight, R, 128, Hd, 0, s.slab, st))
+      return r;                                                                  // dW2 (128,Hd)
+    if (int r = vrp_launch_transpose(P.ff2_weight, 128, Hd, Hd, s.WT, st)) return r;   // (Hd,128)
+    if (int r = vrp_launch_gemm_nt_full(s.gB, 128, s.WT, 128, nullptr, nullptr, 0, nullptr, T.H,
+                                        s.gH, Hd, R, Hd, 128, 0, st)) return r;  // gH = dH (gated)
+    if (int r = vrp_launch_colsum(s.gH, Hd, R, Hd, G.ff0_bias, 0, st)) return r;
+    if (int r = vrp_launch_gemm_tn(s.gH, Hd, T.Y1, 128, G.ff0_weight, R, Hd, 128, 0, s.slab, st))
+      return r;                                                                  // dW1 (Hd,128)
+    if (int r = vrp_launch_transpose(P.ff0_weight, Hd, 128, 128, s.WT, st)) return r;  // (128,Hd)
+    if (int r = vrp_launch_gemm_nt(s.gH, Hd, s.WT, Hd, nullptr, s.gB, 128, s.gA, 128, R, 128, Hd,
+                                   0, st)) return r;                             // gA = dY1
+    // Y1 = BN1(Z1),  Z1 = X + ATT Wo^T + bo
+    if (int r = vrp_launch_bn_bwd(s.gA, T.Z1, T.stats1, P.bn1_weight, R, s.gB, G.bn1_weight,
+                                  G.bn1_bias, 0, s.bnws, st)) return r;          // gB = dZ1
+    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.out_proj_bias, 0, st)) return r;
+    if (int r = vrp_launch_gemm_tn(s.gB, 128, T.ATT, 128, G.out_proj_weight, R, 128, 128, 0,
+                                   s.slab, st)) return r;
+    if (int r = vrp_launch_transpose(P.out_proj_weight, 128, 128, 128, s.WT, st)) return r;
+    if (int r = vrp_launch_gemm_nt(s.gB, 128, s.WT, 128, nullptr, nullptr, 0, s.gC, 128, R, 128,
+                                   128, 0, st)) return r;                        // gC = dATT
+    if (int r = vrp_launch_attention_bwd(T.QKV, s.gC, s.gQKV, B, N, st)) return r;
+    if (int r = vrp_launch_colsum(s.gQKV, 384, R, 384, G.in_proj_bias, 0, st)) return r;
+    if (int r = vrp_launch_gemm_tn(s.gQKV, 384, T.X, 128, G.in_proj_weight, R, 384, 128, 0, s.slab,
+                                   st)) return r;                                // dWin (384,128)
+    if (int r = vrp_launch_transpose(P.in_proj_weight, 384, 128, 128, s.WT, st)) return r;  // (128,384)
+    if (int r = vrp_launch_gemm_nt(s.gQKV, 384, s.WT, 384, nullptr, s.gB, 128, s.gA, 128, R, 128,
+                                   384, 0, st)) return r;                        // gA = dX
+    dout = s.gA;
+  }
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(1), dim3(256), 0, st, dout, x, depot_mask, R, s.embacc);
+  VRP_CHECK_LAUNCH("embed_bwd");
+  hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(1), dim3(128), 0, st, s.embacc, w->node_dim,
+                     w->depot_dim, g->node_embed_weight, g->node_embed_bias,
+                     w->depot_embed_weight ? g->depot_embed_weight : nullptr,
+                     g->depot_embed_bias);
+  VRP_CHECK_LAUNCH("embed_bwd_scatter");
   return 0;
 }

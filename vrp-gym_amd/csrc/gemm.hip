@@ -11,7 +11,7 @@
 // registers while the current one feeds the MFMAs and staged into the other buffer,
 // one barrier per K-tile.
 // Epilogue (fused, in this order): + bias, + residual, BatchNorm affine
-// ((v - mean) * mult + beta, eval mode), ReLU.
+// ((v - mean) * mult + beta, eval mode), ReLU, gate (v := 0 where gate <= 0: ReLU backward).
 #include <stdlib.h>
 #include "common.h"
 
@@ -56,8 +56,8 @@ template <int BM, int BK>
 __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm_nt_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
     const float *__restrict__ bias, const float *__restrict__ R, int ldr,
-    const float *__restrict__ norm, float *__restrict__ C, int ldc, int M, int N, int K,
-    int relu) {
+    const float *__restrict__ norm, const float *__restrict__ gate, float *__restrict__ C,
+    int ldc, int M, int N, int K, int relu) {
   constexpr int MI = BM / 64;   // 32-row MFMA tiles per wave along M
   constexpr int KQ = BK / 4;    // float4 along k per row
   constexpr int RS = 256 / KQ;  // rows staged per pass of the workgroup
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm
           if (R) v += R[(size_t)m * ldr + n];
           if (norm) v = (v - mean) * mult + beta;
           if (relu) v = fmaxf(v, 0.f);
+          if (gate && !(gate[(size_t)m * ldc + n] > 0.f)) v = 0.f;  // ReLU backward
           C[(size_t)m * ldc + n] = v;
         }
       }
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm
 }
 
 // norm: optional BatchNorm affine (only for N == 128): [mean | mult | beta]
-int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, const float *bias,
-                          const float *R, int ldr, const float *norm, float *C, int ldc, int M,
-                          int N, int K, int relu, hipStream_t stream) {
+int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, const float *bias,
+                            const float *R, int ldr, const float *norm, const float *gate, float *C,
+                            int ldc, int M, int N, int K, int relu, hipStream_t stream) {
   VRP_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   VRP_REQUIRE(N % BN == 0 && K % 64 == 0, "gemm: N=%d must be a multiple of %d and K=%d of 64",
               N, BN, K);
@@ -157,25 +158,25 @@ int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, cons
     dim3 grid(N / BN, (M + 63) / 64);
     if (force[3] == '3')
       hipLaunchKernelGGL((gemm_nt_kernel<64, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw,
-                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+                         bias, R, ldr, norm, gate, C, ldc, M, N, K, relu);
     else
       hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, lda, W, ldw,
-                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+                         bias, R, ldr, norm, gate, C, ldc, M, N, K, relu);
   } else if (force && force[0] == 's') {
     dim3 grid(N / BN, (M + 63) / 64);
     hipLaunchKernelGGL((gemm_nt_kernel<64, 16>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
-                       ldr, norm, C, ldc, M, N, K, relu);
+                       ldr, norm, gate, C, ldc, M, N, K, relu);
   } else if (force && force[0] == '1') {
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
-                       ldr, norm, C, ldc, M, N, K, relu);
+                       ldr, norm, gate, C, ldc, M, N, K, relu);
   } else if (tiles128 >= 512) {
     // at least two workgroups per CU: 128x128x16 tiles, 32 KB of LDS
     // and 114 VGPRs -> 4 workgroups per CU overlap each other's barriers and load latency
     // (measured 89-108 TFLOP/s at M = 327680 vs 76-102 for the 128x128x32 tile at 2 per CU)
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 16>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
-                       ldr, norm, C, ldc, M, N, K, relu);
+                       ldr, norm, gate, C, ldc, M, N, K, relu);
   } else {
     // few workgroups: a workgroup's own latency is the kernel's duration.  Measured on
     // MI355X at M = 10240 (tools/gemm_probe.py): K = 128 -> 64x128x32 tiles (3 workgroups
@@ -183,13 +184,20 @@ int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, cons
     dim3 grid(N / BN, (M + 63) / 64);
     if (K >= 512)
       hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, stream, A, lda, W, ldw,
-                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+                         bias, R, ldr, norm, gate, C, ldc, M, N, K, relu);
     else
       hipLaunchKernelGGL((gemm_nt_kernel<64, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw,
-                         bias, R, ldr, norm, C, ldc, M, N, K, relu);
+                         bias, R, ldr, norm, gate, C, ldc, M, N, K, relu);
   }
   VRP_CHECK_LAUNCH("gemm_nt");
   return 0;
+}
+
+int vrp_launch_gemm_nt_ex(const float *A, int lda, const float *W, int ldw, const float *bias,
+                          const float *R, int ldr, const float *norm, float *C, int ldc, int M,
+                          int N, int K, int relu, hipStream_t stream) {
+  return vrp_launch_gemm_nt_full(A, lda, W, ldw, bias, R, ldr, norm, nullptr, C, ldc, M, N, K, relu,
+                                 stream);
 }
 
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
@@ -197,6 +205,13 @@ int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const f
                        int relu, hipStream_t stream) {
   return vrp_launch_gemm_nt_ex(A, lda, W, ldw, bias, R, ldr, nullptr, C, ldc, M, N, K, relu,
                                stream);
+}
+
+extern "C" int vrp_gemm_nt_gated(const float *A, int lda, const float *W, int ldw,
+                                 const float *residual, int ldr, const float *gate, float *C,
+                                 int ldc, int M, int N, int K, void *stream) {
+  return vrp_launch_gemm_nt_full(A, lda, W, ldw, nullptr, residual, ldr, nullptr, gate, C, ldc, M, N,
+                                 K, 0, (hipStream_t)stream);
 }
 
 extern "C" int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,

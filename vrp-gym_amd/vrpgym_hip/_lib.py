@@ -38,6 +38,21 @@ class EncoderWeights(C.Structure):
                 ("layer", EncoderLayer * 8)]
 
 
+class EncoderLayerGrads(C.Structure):
+    """struct vrp_encoder_layer_grads"""
+    _fields_ = [(n, c_vp) for n in (
+        "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
+        "bn1_weight", "bn1_bias", "ff0_weight", "ff0_bias", "ff2_weight", "ff2_bias",
+        "bn2_weight", "bn2_bias")]
+
+
+class EncoderGrads(C.Structure):
+    """struct vrp_encoder_grads"""
+    _fields_ = [("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
+                ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
+                ("layer", EncoderLayerGrads * 8)]
+
+
 class DecoderWeights(C.Structure):
     """struct vrp_decoder_weights"""
     _fields_ = [(n, c_vp) for n in (
@@ -77,12 +92,18 @@ def _declare(lib):
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                     i32, i32, vp]),
         "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "vrp_encoder_tape_bytes": (i64, [i32, i32, i32, i32]),
+        "vrp_encoder_forward_tape": (i32, [P(EncoderWeights), i32, i32, vp, vp, vp, vp, i32, vp]),
+        "vrp_encoder_backward_workspace_bytes": (i64, [i32, i32, i32]),
+        "vrp_encoder_backward": (i32, [P(EncoderWeights), P(EncoderGrads), i32, i32, vp, vp, vp,
+                                       vp, vp, vp]),
         "vrp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
         "vrp_gemm_tn": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]),
         "vrp_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp]),
         "vrp_bn_bwd_workspace_bytes": (i64, []),
         "vrp_bn_bwd": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp]),
         "vrp_attention_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+        "vrp_gemm_nt_gated": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
