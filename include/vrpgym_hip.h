@@ -125,6 +125,8 @@ typedef struct vrp_rollout_io {
   const float *noise;     /* (max_steps,B,N) Exp(1) noise for sampling, or NULL=greedy   */
   float *logits;          /* (max_steps,B,N) masked logits u, or NULL (debug/tests)      */
   float *step_logp;       /* (max_steps,B) per-step log-prob, or NULL                    */
+  uint8_t *mask_trace;    /* (max_steps,B,N) the mask column step t decoded with, or NULL */
+  float *load_trace;      /* (max_steps,B) IRP vehicle load fed to step t, or NULL        */
 } vrp_rollout_io;
 
 /* D2  Per-episode constants of GraphDecoder.forward (agents/graph_decoder.py:75-83):
@@ -221,6 +223,26 @@ int64_t vrp_encoder_backward_workspace_bytes(int B, int N, int hidden);
 int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_encoder_grads *g, int B, int N,
                          const float *x, const uint8_t *depot_mask, const void *tape,
                          const float *d_emb, void *workspace, void *stream);
+
+/* Decoder parameter gradients (same names as vrp_decoder_weights; all overwritten). */
+typedef struct vrp_decoder_grads {
+  float *first_node, *last_node;
+  float *q_proj_weight, *k_proj_weight, *v_proj_weight, *in_proj_bias;
+  float *out_proj_weight, *out_proj_bias, *kp_weight, *att_output_weight;
+  float *context_proj_weight;                     /* (384,257) IRP only, else NULL */
+} vrp_decoder_grads;
+
+/* Backward of T recorded decoder steps (GraphDecoder.forward agents/graph_decoder.py:51-115
+ * applied T times by TSPModel.forward graph_tsp_agent.py:78-88): gradient of
+ * sum_b d_logp[b] * sum_t log p(actions[t,b]) w.r.t. the decoder parameters and the node
+ * embeddings.  actions (T,B), masks (T,B,N) = io.mask_trace, loads (T,B) = io.load_trace
+ * (IRP, else NULL).  d_emb (B,N,128) is overwritten; step_logp (T,B) optionally receives
+ * the recomputed per-step log-probabilities. */
+int64_t vrp_decoder_backward_workspace_bytes(int kind, int B, int N, int T);
+int vrp_decoder_backward(int kind, const vrp_decoder_weights *w, const vrp_decoder_grads *g,
+                         int B, int N, int T, const float *emb, const int64_t *actions,
+                         const uint8_t *masks, const float *loads, const float *d_logp,
+                         float *d_emb, float *step_logp, void *workspace, void *stream);
 
 /* Building blocks exported for tests and profiling. */
 int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,

@@ -148,3 +148,82 @@ def test_encoder_backward_against_oracle_autograd(kind, B, N):
     assert checked == (2 if kind == 0 else 4) + 12 * 3
     nb = enc.attention_layers[0].bn1.norm.num_batches_tracked.item()
     assert nb == 1
+
+
+def _decoder_oracle_grads(kind, dtype, sd, emb, acts, masks, loads, wgt):
+    """Autograd through the CPU oracle's DecoderEpisode, teacher-forced on the recorded
+    actions / masks / loads: gradient of sum_b w_b sum_t log p(a_t)."""
+    from oracle import policy as opol
+    psd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    psd = {k: v.requires_grad_(v.is_floating_point() and k.startswith("decoder."))
+           for k, v in psd.items()}
+    e = emb.to(dtype).clone().requires_grad_(True)
+    ep = opol.DecoderEpisode(psd, e)
+    total, lps = 0.0, []
+    for t in range(acts.shape[0]):
+        load = None if loads is None else loads[t].to(dtype)
+        u = ep.logits(masks[t].to(dtype), load)
+        lp = (u - u.logsumexp(-1, keepdim=True)).gather(1, acts[t][:, None])[:, 0]
+        lps.append(lp.detach())
+        total = total + (wgt.to(dtype) * lp).sum()
+        ep.advance(acts[t])
+    total.backward()
+    return psd, e.grad, torch.stack(lps)
+
+
+@pytest.mark.parametrize("kind,B,N", [(0, 8, 10), (1, 8, 10), (2, 8, 10), (0, 64, 20), (1, 33, 21),
+                                      (2, 16, 40), (1, 5, 100), (0, 3, 70), (2, 1, 7)])
+def test_decoder_backward_against_oracle_autograd(kind, B, N):
+    """vrp_decoder_backward on an episode recorded by the HIP rollout == autograd through
+    the oracle decoder (fp64), for parameters and node embeddings; the re-run per-step
+    log-probabilities equal the rollout's own."""
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import IRPEnv, TSPEnv, VRPEnv
+    Agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
+    agent = Agent(seed=69)
+    model = agent.model
+    model.eval()
+    env = (TSPEnv, VRPEnv, IRPEnv)[kind](N, B, 1, 11 + kind)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        res = runtime.rollout(model, env, greedy=False, train=False, trace=True, record=True)
+    T = res.T
+    acts = res.actions[:T].contiguous()
+    masks = res.mask_trace[:T].contiguous()
+    loads = None if kind != 2 else res.load_trace[:T].contiguous()
+    # recorded masks == the -inf pattern of the recorded logits
+    assert torch.equal(masks.bool(), torch.isinf(res.logits[:T]))
+    g = torch.Generator().manual_seed(B * N)
+    wgt = torch.randn(B, generator=g)
+    params, grads, d_emb, step_logp = runtime.decoder_backward(
+        model.decoder, kind, res.emb, acts, masks, loads, wgt.cuda(), T, want_logp=True)
+    assert (step_logp - res.step_logp[:T]).abs().max().item() < 2e-5
+    assert (step_logp.sum(0) - res.acc_logp).abs().max().item() < 1e-4
+
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    args = (sd, res.emb.cpu(), acts.cpu(), masks.cpu(), None if loads is None else loads.cpu(), wgt)
+    p64, e64, lp64 = _decoder_oracle_grads(kind, torch.float64, *args)
+    p32, e32, _ = _decoder_oracle_grads(kind, torch.float32, *args)
+    assert (step_logp.cpu().double() - lp64).abs().max().item() < 2e-5
+    names = {id(p): n for n, p in model.decoder.named_parameters()}
+    report = []
+
+    def judge(name, got, want, noise):
+        err = (got.double() - want).abs().max().item()
+        tol = 2e-4 * want.abs().max().item() + 2e-5 + 4.0 * noise
+        report.append((err / tol, name, err, want.abs().max().item()))
+
+    judge("d_emb", d_emb.cpu(), e64, (e32.double() - e64).abs().max().item())
+    checked = 0
+    for p, gr in zip(params, grads):
+        if p is None:
+            continue
+        key = "decoder." + names[id(p)]
+        want = p64[key].grad
+        assert want is not None, key
+        judge(key, gr.cpu(), want, (p32[key].grad.double() - want).abs().max().item())
+        checked += 1
+    assert checked == 10
+    report.sort(reverse=True)
+    assert report[0][0] < 1.0, report[:5]

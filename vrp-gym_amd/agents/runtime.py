@@ -229,9 +229,11 @@ class RolloutResult:
     """Device tensors of one episode.  `T` (number of env steps until the batch-wide
     `done`, tsp.py:95) is read back lazily because it needs a stream sync."""
 
-    def __init__(self, acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps):
+    def __init__(self, acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps,
+                 mask_trace=None, load_trace=None):
         self.acc_loss, self.acc_logp, self.notdone = acc_loss, acc_logp, notdone
         self.actions, self.logits, self.step_logp, self.emb = actions, logits, step_logp, emb
+        self.mask_trace, self.load_trace = mask_trace, load_trace
         self.max_steps = max_steps
         self._T = None
 
@@ -359,12 +361,12 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
 
 
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
-            noise_mode="device", tile_kernel=False, use_graph=None):
+            noise_mode="device", tile_kernel=False, use_graph=None, record=False):
     """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU."""
     dev = _require_cuda(model)
     if use_graph is None:
         use_graph = USE_GRAPHS
-    if (use_graph and forced is None and noise is None and not trace
+    if (use_graph and forced is None and noise is None and not trace and not record
             and (greedy or noise_mode == "device")):
         if str(env._device) != str(dev):
             raise RuntimeError(f"env is on {env._device} but the model on {dev}")
@@ -394,8 +396,15 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     notdone = torch.empty((max_steps + 1,), dtype=torch.int32, device=dev)
     io = hip.RolloutIO()
     io.acc_loss, io.acc_logp, io.notdone = acc_loss.data_ptr(), acc_logp.data_ptr(), notdone.data_ptr()
-    actions = logits = step_logp = None
-    if trace or forced is not None:
+    actions = logits = step_logp = mask_trace = load_trace = None
+    if record:
+        # what the backward pass needs to re-run the episode: actions, masks, IRP loads
+        mask_trace = torch.empty((max_steps, B, N), dtype=torch.uint8, device=dev)
+        io.mask_trace = mask_trace.data_ptr()
+        if kind == hip.KIND_IRP:
+            load_trace = torch.empty((max_steps, B), dtype=torch.float32, device=dev)
+            io.load_trace = load_trace.data_ptr()
+    if trace or record or forced is not None:
         actions = torch.zeros((max_steps, B), dtype=torch.int64, device=dev)
         io.actions = actions.data_ptr()
     if trace:
@@ -436,7 +445,8 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
                               enc_ws.data_ptr(), dec_ws.data_ptr(), C.byref(io), max_steps,
                               stream))
     env._mask_fresh = False  # final mask sits in buffer T&1; recompute lazily into buffer 0
-    res = RolloutResult(acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps)
+    res = RolloutResult(acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps,
+                        mask_trace, load_trace)
     res._keep = keep
     if gen_state is not None:
         # leave the CPU generator where the reference would: it draws only T steps
@@ -506,3 +516,39 @@ def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb):
                                        hip.ptr(depot_mask_u8), tape.data_ptr(), d_emb.data_ptr(),
                                        ws.data_ptr(), hip.current_stream(dev)))
     return params, grads
+
+
+def decoder_param_list(dec, kind):
+    """Decoder parameters in the order of the vrp_decoder_grads struct (None = not used by
+    this env kind: no gradient, like torch autograd's None)."""
+    att = dec.attention
+    irp = kind == hip.KIND_IRP
+    return [None if irp else dec._first_node, dec._last_node, att.q_proj_weight, att.k_proj_weight,
+            att.v_proj_weight, att.in_proj_bias, att.out_proj.weight, att.out_proj.bias,
+            dec._kp.weight, dec._att_output.weight, dec._context_proj.weight if irp else None]
+
+
+def decoder_backward(dec, kind, emb, actions, masks, loads, d_logp, T, want_logp=False):
+    """vrp_decoder_backward over the first T recorded steps.  Returns (params, grads, d_emb
+    [, step_logp]); grads aligned with decoder_param_list."""
+    dev = _require_cuda(dec)
+    lib = hip.lib()
+    w = decoder_struct(dec)
+    B, N, _ = emb.shape
+    params = decoder_param_list(dec, kind)
+    grads = [None if p is None else torch.empty_like(p) for p in params]
+    g = hip.DecoderGrads()
+    for (name, _), t in zip(hip.DecoderGrads._fields_, grads):
+        setattr(g, name, hip.ptr(t))
+    d_emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
+    step_logp = torch.empty((T, B), dtype=torch.float32, device=dev) if want_logp else None
+    ws = _buf("dec_bwd", dev, lib.vrp_decoder_backward_workspace_bytes(kind, B, N, T))
+    assert actions.dtype == torch.int64 and masks.dtype == torch.uint8
+    assert actions.is_contiguous() and masks.is_contiguous() and emb.is_contiguous()
+    d_logp = d_logp.to(torch.float32).contiguous()
+    hip.check(lib.vrp_decoder_backward(kind, C.byref(w), C.byref(g), B, N, T, emb.data_ptr(),
+                                       actions.data_ptr(), masks.data_ptr(), hip.ptr(loads),
+                                       d_logp.data_ptr(), d_emb.data_ptr(), hip.ptr(step_logp),
+                                       ws.data_ptr(), hip.current_stream(dev)))
+    out = (params, grads, d_emb)
+    return out + (step_logp,) if want_logp else out

@@ -12,7 +12,7 @@ void vrp_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *vrp_last_error(void) { return g_err; }
-extern "C" int vrp_abi_version(void) { return 1; }
+extern "C" int vrp_abi_version(void) { return 2; }
 
 // x (B,N,3) fp32 and is_depot (B,N) u8 live at the tail of the encoder workspace.
 static void feature_scratch(void *enc_ws, int B, int N, int hidden, float **x, uint8_t **isd) {

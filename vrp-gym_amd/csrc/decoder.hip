@@ -611,6 +611,16 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
     for (int i = 0; i < NPL; ++i)
       if (lane + 64 * i < N) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
   }
+  if (active && p.io.mask_trace) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+      if (lane + 64 * i < N)
+        p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] =
+            mask_in[(size_t)b * N + lane + 64 * i];
+  }
+  if (active && p.io.load_trace && lane == 0)
+    p.io.load_trace[(size_t)p.t * B + b] =
+        (p.kind == VRP_KIND_IRP) ? (float)p.env.load[b] : 1.f;
 
   // ---- action: greedy argmax (lowest index on ties) or argmax(softmax(u)/q) -----------
   int idx;
@@ -888,7 +898,11 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
       u[i] = 10.f * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
     if (active && p.io.logits && inN[i])
       p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
+    if (active && p.io.mask_trace && inN[i])
+      p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] = (uint8_t)own_mask[i];
   }
+  if (active && p.io.load_trace && lane == 0)
+    p.io.load_trace[(size_t)p.t * B + b] = (float)load0;
 
   // lowest node index among the maxima (torch CPU argmax): slot 0 holds nodes < 64
   auto argmax_nodes = [&](const float (&v)[NPL]) {

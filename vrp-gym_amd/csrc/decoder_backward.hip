@@ -1,0 +1,648 @@
+// Backward of the pointer-attention decoder over a whole recorded episode (K4 of
+// SURVEY.md 7.1): d/d(theta, emb) of  sum_b w_b * sum_t log p(a_{t,b})  -- the REINFORCE
+// surrogate of agents/graph_tsp_agent.py:178-186 -- for GraphDecoder.forward
+// (agents/graph_decoder.py:51-115) applied T times.
+//
+// The decoder has no recurrent state: step t depends on earlier steps only through the
+// recorded indices (first / last node, mask, load).  So all T steps are re-run at once in
+// the reference's own (un-folded) form as batched fp32 MFMA GEMMs over the T*B "step rows"
+// plus three per-graph kernels, every intermediate stays in HBM, and the backward walks the
+// same chain in reverse:
+//
+//   K|V|KP = emb Wk^T+bk | emb Wv^T+bv | emb Wkp^T          (B*N rows)   graph_decoder.py:82-83
+//   ctx    = [g | first | last]   (IRP: [g | last | load] Wc^T)           :75-91
+//   Q      = ctx Wq^T + bq                                   (T*B rows)   :93 (in_proj)
+//   a,O    = softmax(Q_h K_h^T/sqrt(48) + scrambled mask) V_h             :93-94 (QUIRK D3)
+//   O2     = O Wo^T + bo ;  Q2 = O2 Watt^T                                :93,95
+//   u      = 10 tanh(Q2 KP^T / sqrt(128)), own mask -> -inf, log-softmax  :96-100
+//
+// Reductions over steps run in a fixed order (no float atomics): gradients are bitwise
+// reproducible.  Layouts: step row r = t*B + b; node row = b*N + n.
+#include "common.h"
+
+int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
+                       const float *R, int ldr, float *C, int ldc, int M, int N, int K,
+                       int relu, hipStream_t stream);
+int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
+                       int N2, int accumulate, void *slab_ws, hipStream_t st);
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+                      hipStream_t st);
+int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *dst, hipStream_t st);
+
+#define DB_E 128
+#define DB_C48 0.14433756729740643f   // 1/sqrt(48)   head dim of the 8-head glimpse
+#define DB_C128 0.08838834764831845f  // 1/sqrt(128)  graph_decoder.py:97
+
+// ------------------------------------------------------------------ small helpers
+__global__ __launch_bounds__(128) void db_graph_mean_kernel(const float *__restrict__ emb, int N,
+                                                            float *__restrict__ g) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const float *e = emb + (size_t)b * N * DB_E + c;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += e[(size_t)n * DB_E];
+  g[(size_t)b * DB_E + c] = s / (float)N;
+}
+
+// dst (rows, ldd) := src (rows, lds)[:, :cols], columns >= cols zeroed up to `width`
+__global__ void db_pad_copy_kernel(const float *__restrict__ src, int lds, int cols,
+                                   float *__restrict__ dst, int ldd, int width, int rows) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * width) return;
+  const int r = idx / width, c = idx - r * width;
+  dst[(size_t)r * ldd + c] = c < cols ? src[(size_t)r * lds + c] : 0.f;
+}
+
+// Context rows (graph_decoder.py:75-91).  TSP/VRP: [g | first | last]; IRP: [g | last |
+// load | 0...] (the input of _context_proj, zero-padded from 257 to 384 columns).
+__global__ __launch_bounds__(128) void db_ctx_kernel(int kind, int B, int N, int T,
+                                                     const float *__restrict__ emb,
+                                                     const float *__restrict__ g,
+                                                     const float *__restrict__ first_node,
+                                                     const float *__restrict__ last_node,
+                                                     const int64_t *__restrict__ actions,
+                                                     const float *__restrict__ loads,
+                                                     float *__restrict__ ctx) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  const int t = r / B, b = r - t * B;
+  float *row = ctx + (size_t)r * VRP_D;
+  const float gv = g[(size_t)b * DB_E + c];
+  float lastv;
+  if (t == 0) lastv = last_node[c];
+  else lastv = emb[((size_t)b * N + (int)actions[(size_t)(t - 1) * B + b]) * DB_E + c];
+  row[c] = gv;
+  if (kind != VRP_KIND_IRP) {
+    float firstv;
+    if (t == 0) firstv = first_node[c];
+    else firstv = emb[((size_t)b * N + (int)actions[b]) * DB_E + c];
+    row[128 + c] = firstv;
+    row[256 + c] = lastv;
+  } else {
+    row[128 + c] = lastv;
+    row[256 + c] = (c == 0) ? loads[r] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ glimpse attention, forward
+// One workgroup per (graph, head); K_h and V_h (N x 48) staged once in LDS and reused by all
+// T steps; wave w handles steps w, w+4, ...  lane = node for the scores, lane = d for o.
+template <int NPL>
+__global__ __launch_bounds__(256) void db_attn_fwd_kernel(int B, int N, int T,
+                                                          const float *__restrict__ Q,
+                                                          const float *__restrict__ Kb,
+                                                          const float *__restrict__ Vb,
+                                                          const uint8_t *__restrict__ masks,
+                                                          float *__restrict__ A,
+                                                          float *__restrict__ O) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *K_s = smem;                 // [N][49]
+  float *V_s = K_s + N * 49;         // [N][48]
+  float *q_s = V_s + N * 48;         // [4][48]
+  float *a_s = q_s + 4 * 48;         // [4][64*NPL]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, h = blockIdx.y;
+  for (int idx = tid; idx < N * 48; idx += 256) {
+    const int n = idx / 48, d = idx - n * 48;
+    const size_t src = ((size_t)b * N + n) * VRP_D + h * VRP_HD + d;
+    K_s[n * 49 + d] = Kb[src];
+    V_s[n * 48 + d] = Vb[src];
+  }
+  __syncthreads();
+  const int mrow = (b * 8 + h) % B;  // QUIRK D3: head h of graph b reads this graph's mask
+  for (int t0 = 0; t0 < T; t0 += 4) {
+    const int t = t0 + wave;
+    const bool on = t < T;
+    const size_t r = (size_t)(on ? t : 0) * B + b;
+    if (lane < 48) q_s[wave * 48 + lane] = Q[r * VRP_D + h * VRP_HD + lane];
+    __syncthreads();
+    float s[NPL], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      s[i] = -INFINITY;
+      if (n < N) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 48; ++d) acc = fmaf(q_s[wave * 48 + d], K_s[n * 49 + d], acc);
+        s[i] = acc * DB_C48 + (float)masks[((size_t)(on ? t : 0) * B + mrow) * N + n];
+      }
+      mx = fmaxf(mx, s[i]);
+    }
+    const float m = wave_max(mx);
+    float e[NPL], es = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { e[i] = (lane + 64 * i < N) ? expf(s[i] - m) : 0.f; es += e[i]; }
+    const float sum = wave_sum(es);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      if (n < N) {
+        const float a = e[i] / sum;
+        a_s[wave * 64 * NPL + n] = a;
+        if (on) A[(r * 8 + h) * N + n] = a;
+      }
+    }
+    __syncthreads();
+    if (lane < 48 && on) {
+      float o = 0.f;
+      for (int n = 0; n < N; ++n) o = fmaf(a_s[wave * 64 * NPL + n], V_s[n * 48 + lane], o);
+      O[r * VRP_D + h * VRP_HD + lane] = o;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ glimpse attention, backward
+// Same decomposition.  Per step: da = dO_h V_h^T, ds = a (da - <a,da>), dQ_h = ds K_h / sqrt(48).
+// dK_h += ds^T Q_h / sqrt(48) and dV_h += a^T dO_h are accumulated over the wave's steps in
+// registers (lane = node, 48 values each) and the four waves are summed in order at the end.
+template <int NPL>
+__global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
+                                                          const float *__restrict__ Q,
+                                                          const float *__restrict__ Kb,
+                                                          const float *__restrict__ Vb,
+                                                          const float *__restrict__ A,
+                                                          const float *__restrict__ dO,
+                                                          float *__restrict__ dQ,
+                                                          float *__restrict__ dK,
+                                                          float *__restrict__ dV) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *K_s = smem;                  // [N][49]
+  float *V_s = K_s + N * 49;          // [N][49]
+  float *q_s = V_s + N * 49;          // [4][48]
+  float *do_s = q_s + 4 * 48;         // [4][48]
+  float *ds_s = do_s + 4 * 48;        // [4][64*NPL]
+  float *red_s = ds_s + 4 * 64 * NPL; // [N][49]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, h = blockIdx.y;
+  for (int idx = tid; idx < N * 48; idx += 256) {
+    const int n = idx / 48, d = idx - n * 48;
+    const size_t src = ((size_t)b * N + n) * VRP_D + h * VRP_HD + d;
+    K_s[n * 49 + d] = Kb[src];
+    V_s[n * 49 + d] = Vb[src];
+  }
+  float dKa[NPL][48], dVa[NPL][48];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int d = 0; d < 48; ++d) { dKa[i][d] = 0.f; dVa[i][d] = 0.f; }
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 4) {
+    const int t = t0 + wave;
+    const bool on = t < T;
+    const size_t r = (size_t)(on ? t : 0) * B + b;
+    if (lane < 48) {
+      q_s[wave * 48 + lane] = Q[r * VRP_D + h * VRP_HD + lane];
+      do_s[wave * 48 + lane] = on ? dO[r * VRP_D + h * VRP_HD + lane] : 0.f;
+    }
+    __syncthreads();
+    float a[NPL], da[NPL], part = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      a[i] = 0.f; da[i] = 0.f;
+      if (n < N && on) {
+        a[i] = A[(r * 8 + h) * N + n];
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 48; ++d) acc = fmaf(do_s[wave * 48 + d], V_s[n * 49 + d], acc);
+        da[i] = acc;
+      }
+      part = fmaf(a[i], da[i], part);
+    }
+    const float dot = wave_sum(part);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      const float ds = a[i] * (da[i] - dot);
+      if (n < N) ds_s[wave * 64 * NPL + n] = ds;
+      const float dsc = ds * DB_C48;
+#pragma unroll
+      for (int d = 0; d < 48; ++d) {
+        dKa[i][d] = fmaf(dsc, q_s[wave * 48 + d], dKa[i][d]);
+        dVa[i][d] = fmaf(a[i], do_s[wave * 48 + d], dVa[i][d]);
+      }
+    }
+    __syncthreads();
+    if (lane < 48 && on) {
+      float dq = 0.f;
+      for (int n = 0; n < N; ++n) dq = fmaf(ds_s[wave * 64 * NPL + n], K_s[n * 49 + lane], dq);
+      dQ[r * VRP_D + h * VRP_HD + lane] = dq * DB_C48;
+    }
+    __syncthreads();
+  }
+  // ordered sum over the four waves: wave 0 + wave 1 + wave 2 + wave 3
+  for (int pass = 0; pass < 2; ++pass) {
+    float (&acc)[NPL][48] = pass == 0 ? dKa : dVa;
+    for (int w = 1; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const int n = lane + 64 * i;
+          if (n < N) {
+#pragma unroll
+            for (int d = 0; d < 48; ++d) red_s[n * 49 + d] = acc[i][d];
+          }
+        }
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          const int n = lane + 64 * i;
+          if (n < N) {
+#pragma unroll
+            for (int d = 0; d < 48; ++d) acc[i][d] += red_s[n * 49 + d];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+      float *dst = pass == 0 ? dK : dV;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+#pragma unroll
+          for (int d = 0; d < 48; ++d) red_s[n * 49 + d] = acc[i][d];
+        }
+      }
+    }
+    __syncthreads();
+    {
+      float *dst = pass == 0 ? dK : dV;
+      for (int idx = tid; idx < N * 48; idx += 256) {
+        const int n = idx / 48, d = idx - n * 48;
+        dst[((size_t)b * N + n) * VRP_D + h * VRP_HD + d] = red_s[n * 49 + d];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ pointer logits + log-softmax
+// One workgroup per graph, KP_b (N x 128) in LDS.  Forward u = 10 tanh(Q2.KP_n/sqrt(128)),
+// own mask -> -inf, log p = u - logsumexp(u) (graph_decoder.py:96-100, graph_tsp_agent.py:86);
+// backward of  w_b * log p(a_t):  du = w_b (onehot(a_t) - p), dz = du 10 (1 - tanh^2)/sqrt(128),
+// dQ2 = dz KP,  dKP += dz^T Q2 (registers, lane = node; waves summed in order).
+template <int NPL>
+__global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
+                                                       const float *__restrict__ Q2,
+                                                       const float *__restrict__ KP,
+                                                       const uint8_t *__restrict__ masks,
+                                                       const int64_t *__restrict__ actions,
+                                                       const float *__restrict__ d_logp,
+                                                       float *__restrict__ dQ2,
+                                                       float *__restrict__ dKP,
+                                                       float *__restrict__ step_logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *KP_s = smem;                  // [N][129]
+  float *q_s = KP_s + N * 129;         // [4][128]
+  float *dz_s = q_s + 4 * 128;         // [4][64*NPL]
+  float *red_s = dz_s + 4 * 64 * NPL;  // [N][129]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  for (int idx = tid; idx < N * 128; idx += 256) {
+    const int n = idx >> 7, k = idx & 127;
+    KP_s[n * 129 + k] = KP[((size_t)b * N + n) * DB_E + k];
+  }
+  float acc[NPL][128];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int k = 0; k < 128; ++k) acc[i][k] = 0.f;
+  const float wgt = d_logp[b];
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 4) {
+    const int t = t0 + wave;
+    const bool on = t < T;
+    const size_t r = (size_t)(on ? t : 0) * B + b;
+    q_s[wave * 128 + lane] = Q2[r * DB_E + lane];
+    q_s[wave * 128 + 64 + lane] = Q2[r * DB_E + 64 + lane];
+    __syncthreads();
+    const int act = (int)actions[r];
+    float u[NPL], th[NPL], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      u[i] = -INFINITY; th[i] = 0.f;
+      if (n < N && !masks[r * N + n]) {
+        float z = 0.f;
+#pragma unroll 16
+        for (int k = 0; k < 128; ++k) z = fmaf(q_s[wave * 128 + k], KP_s[n * 129 + k], z);
+        th[i] = tanhf(z * DB_C128);
+        u[i] = 10.f * th[i];
+      }
+      mx = fmaxf(mx, u[i]);
+    }
+    const float m = wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) se += expf(u[i] - m);
+    se = wave_sum(se);
+    const float lse = m + logf(se);
+    float lp_part = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      const float p = expf(u[i] - lse);  // 0 for masked nodes
+      float dz = 0.f;
+      if (n < N && u[i] > -INFINITY && on) {
+        const float du = wgt * ((n == act ? 1.f : 0.f) - p);
+        dz = du * 10.f * (1.f - th[i] * th[i]) * DB_C128;
+      }
+      if (n == act) lp_part += u[i] - lse;
+      if (n < N) dz_s[wave * 64 * NPL + n] = dz;
+#pragma unroll
+      for (int k = 0; k < 128; ++k) acc[i][k] = fmaf(dz, q_s[wave * 128 + k], acc[i][k]);
+    }
+    const float lp = wave_sum(lp_part);
+    if (step_logp && on && lane == 0) step_logp[r] = lp;
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = lane + 64 * j;
+        float dq = 0.f;
+        for (int n = 0; n < N; ++n) dq = fmaf(dz_s[wave * 64 * NPL + n], KP_s[n * 129 + k], dq);
+        dQ2[r * DB_E + k] = dq;
+      }
+    }
+    __syncthreads();
+  }
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+#pragma unroll
+          for (int k = 0; k < 128; ++k) red_s[n * 129 + k] = acc[i][k];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (n < N) {
+#pragma unroll
+          for (int k = 0; k < 128; ++k) acc[i][k] += red_s[n * 129 + k];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int n = lane + 64 * i;
+      if (n < N) {
+#pragma unroll
+        for (int k = 0; k < 128; ++k) red_s[n * 129 + k] = acc[i][k];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < N * 128; idx += 256) {
+    const int n = idx >> 7, k = idx & 127;
+    dKP[((size_t)b * N + n) * DB_E + k] = red_s[n * 129 + k];
+  }
+}
+
+// ------------------------------------------------------------------ context rows -> d_emb
+// D (T*B,384) = gradient of the context rows ([dg | dfirst | dlast], IRP: [dg | dlast | ..]).
+// One workgroup per graph, thread = embedding column, steps visited in order:
+//   d_emb[b][n] = (sum_t dg)/N ;  d_emb[b][first] += sum_{t>=1} dfirst ;  d_emb[b][last_t] += dlast_t
+__global__ __launch_bounds__(128) void db_scatter_kernel(int kind, int B, int N, int T,
+                                                         const float *__restrict__ D,
+                                                         const int64_t *__restrict__ actions,
+                                                         float *__restrict__ d_emb) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  const int lastoff = (kind == VRP_KIND_IRP) ? 128 : 256;
+  float sg = 0.f, sf = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float *row = D + ((size_t)t * B + b) * VRP_D;
+    sg += row[c];
+    if (kind != VRP_KIND_IRP && t >= 1) sf += row[128 + c];
+  }
+  float *e = d_emb + (size_t)b * N * DB_E + c;
+  const float gm = sg / (float)N;
+  for (int n = 0; n < N; ++n) e[(size_t)n * DB_E] = gm;
+  if (kind != VRP_KIND_IRP && T > 1) e[(size_t)(int)actions[b] * DB_E] += sf;
+  for (int t = 1; t < T; ++t) {
+    const int last = (int)actions[(size_t)(t - 1) * B + b];
+    e[(size_t)last * DB_E] += D[((size_t)t * B + b) * VRP_D + lastoff + c];
+  }
+}
+
+// ------------------------------------------------------------------ workspace
+struct DecBwdWs {
+  float *g, *Kb, *Vb, *KPb, *dKb, *dVb, *dKPb;        // node-row buffers
+  float *ctx, *cin, *Q, *O, *O2, *Q2, *A;             // step-row tape
+  float *dQ2, *dO2, *dO, *dQ, *dctx, *dcin;           // step-row gradients
+  float *WT, *Wcp, *dWcp, *tmp;                       // transposed weight, padded Wc, its grad
+  void *slab;
+};
+
+static size_t db_slab_bytes(int R, int RB) {
+  const int big = R > RB ? R : RB;
+  return (size_t)vrp_gemm_tn_workspace_bytes(big, VRP_D, VRP_D);
+}
+
+static DecBwdWs carve_dec_bwd(int kind, void *ws, int B, int N, int T, size_t *total) {
+  char *p = (char *)ws;
+  DecBwdWs w;
+  const size_t R = (size_t)T * B, RB = (size_t)B * N;
+  auto take = [&](size_t floats) { float *q = (float *)p; p += vrp_align_up(floats * 4); return q; };
+  w.g = take((size_t)B * DB_E);
+  w.Kb = take(RB * VRP_D); w.Vb = take(RB * VRP_D); w.KPb = take(RB * DB_E);
+  w.dKb = take(RB * VRP_D); w.dVb = take(RB * VRP_D); w.dKPb = take(RB * DB_E);
+  w.ctx = take(R * VRP_D);
+  w.cin = (kind == VRP_KIND_IRP) ? take(R * VRP_D) : nullptr;
+  w.Q = take(R * VRP_D); w.O = take(R * VRP_D); w.O2 = take(R * VRP_D);
+  w.Q2 = take(R * DB_E); w.A = take(R * 8 * N);
+  w.dQ2 = take(R * DB_E); w.dO2 = take(R * VRP_D); w.dO = take(R * VRP_D);
+  w.dQ = take(R * VRP_D); w.dctx = take(R * VRP_D);
+  w.dcin = (kind == VRP_KIND_IRP) ? take(R * VRP_D) : nullptr;
+  w.WT = take((size_t)VRP_D * VRP_D);
+  w.Wcp = take((size_t)VRP_D * VRP_D);
+  w.dWcp = take((size_t)VRP_D * VRP_D);
+  w.tmp = take(512);
+  w.slab = p;
+  p += vrp_align_up(db_slab_bytes((int)R, (int)RB));
+  if (total) *total = (size_t)(p - (char *)ws);
+  return w;
+}
+
+extern "C" int64_t vrp_decoder_backward_workspace_bytes(int kind, int B, int N, int T) {
+  size_t total = 0;
+  carve_dec_bwd(kind, nullptr, B, N, T, &total);
+  return (int64_t)total;
+}
+
+template <typename Kern>
+static int db_raise_lds(Kern kern, size_t lds, const char *name) {
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    vrp_set_error("%s: cannot raise dynamic LDS to %zu bytes", name, lds);
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
+                                    const vrp_decoder_grads *gr, int B, int N, int T,
+                                    const float *emb, const int64_t *actions,
+                                    const uint8_t *masks, const float *loads, const float *d_logp,
+                                    float *d_emb, float *step_logp, void *workspace,
+                                    void *stream) {
+  VRP_REQUIRE(w && gr && emb && actions && masks && d_logp && d_emb && workspace,
+              "decoder_backward: NULL argument");
+  VRP_REQUIRE(kind >= 0 && kind <= 2, "decoder_backward: kind=%d", kind);
+  VRP_REQUIRE(B > 0 && N >= 2 && N <= 128 && T > 0, "decoder_backward: bad shape B=%d N=%d T=%d", B,
+              N, T);
+  VRP_REQUIRE(kind != VRP_KIND_IRP || (loads && w->context_proj_weight && gr->context_proj_weight),
+              "decoder_backward: IRP needs loads and _context_proj");
+  hipStream_t st = (hipStream_t)stream;
+  DecBwdWs s = carve_dec_bwd(kind, workspace, B, N, T, nullptr);
+  const int R = T * B, RB = B * N;
+  const float *bias = w->in_proj_bias;
+  const int npl = N <= 64 ? 1 : 2;
+
+  // ---- forward re-run, everything kept ----------------------------------------------
+  hipLaunchKernelGGL(db_graph_mean_kernel, dim3(B), dim3(128), 0, st, emb, N, s.g);
+  VRP_CHECK_LAUNCH("db_graph_mean");
+  if (int r = vrp_launch_gemm_nt(emb, 128, w->k_proj_weight, 128, bias + 384, nullptr, 0, s.Kb, 384,
+                                 RB, 384, 128, 0, st)) return r;
+  if (int r = vrp_launch_gemm_nt(emb, 128, w->v_proj_weight, 128, bias + 768, nullptr, 0, s.Vb, 384,
+                                 RB, 384, 128, 0, st)) return r;
+  if (int r = vrp_launch_gemm_nt(emb, 128, w->kp_weight, 128, nullptr, nullptr, 0, s.KPb, 128, RB,
+                                 128, 128, 0, st)) return r;
+  float *ctx_in = (kind == VRP_KIND_IRP) ? s.cin : s.ctx;
+  hipLaunchKernelGGL(db_ctx_kernel, dim3(R), dim3(128), 0, st, kind, B, N, T, emb, s.g,
+                     w->first_node, w->last_node, actions, loads, ctx_in);
+  VRP_CHECK_LAUNCH("db_ctx");
+  if (kind == VRP_KIND_IRP) {
+    hipLaunchKernelGGL(db_pad_copy_kernel, dim3((384 * 384 + 255) / 256), dim3(256), 0, st,
+                       w->context_proj_weight, 257, 257, s.Wcp, 384, 384, 384);
+    VRP_CHECK_LAUNCH("db_pad_copy");
+    if (int r = vrp_launch_gemm_nt(s.cin, 384, s.Wcp, 384, nullptr, nullptr, 0, s.ctx, 384, R, 384,
+                                   384, 0, st)) return r;
+  }
+  if (int r = vrp_launch_gemm_nt(s.ctx, 384, w->q_proj_weight, 384, bias, nullptr, 0, s.Q, 384, R,
+                                 384, 384, 0, st)) return r;
+  {
+    const size_t lds = sizeof(float) * ((size_t)N * 49 + N * 48 + 4 * 48 + 4 * 64 * npl);
+    if (npl == 1) {
+      if (db_raise_lds(db_attn_fwd_kernel<1>, lds, "db_attn_fwd")) return 1;
+      hipLaunchKernelGGL(db_attn_fwd_kernel<1>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
+                         s.Vb, masks, s.A, s.O);
+    } else {
+      if (db_raise_lds(db_attn_fwd_kernel<2>, lds, "db_attn_fwd")) return 1;
+      hipLaunchKernelGGL(db_attn_fwd_kernel<2>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
+                         s.Vb, masks, s.A, s.O);
+    }
+    VRP_CHECK_LAUNCH("db_attn_fwd");
+  }
+  if (int r = vrp_launch_gemm_nt(s.O, 384, w->out_proj_weight, 384, w->out_proj_bias, nullptr, 0,
+                                 s.O2, 384, R, 384, 384, 0, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.O2, 384, w->att_output_weight, 384, nullptr, nullptr, 0, s.Q2,
+                                 128, R, 128, 384, 0, st)) return r;
+
+  // ---- backward ------------------------------------------------------------------------
+  {
+    const size_t lds = sizeof(float) * ((size_t)2 * N * 129 + 4 * 128 + 4 * 64 * npl);
+    if (npl == 1) {
+      if (db_raise_lds(db_logit_kernel<1>, lds, "db_logit")) return 1;
+      hipLaunchKernelGGL(db_logit_kernel<1>, dim3(B), dim3(256), lds, st, B, N, T, s.Q2, s.KPb,
+                         masks, actions, d_logp, s.dQ2, s.dKPb, step_logp);
+    } else {
+      if (db_raise_lds(db_logit_kernel<2>, lds, "db_logit")) return 1;
+      hipLaunchKernelGGL(db_logit_kernel<2>, dim3(B), dim3(256), lds, st, B, N, T, s.Q2, s.KPb,
+                         masks, actions, d_logp, s.dQ2, s.dKPb, step_logp);
+    }
+    VRP_CHECK_LAUNCH("db_logit");
+  }
+  // Q2 = O2 Watt^T
+  if (int r = vrp_launch_gemm_tn(s.dQ2, 128, s.O2, 384, gr->att_output_weight, R, 128, 384, 0,
+                                 s.slab, st)) return r;
+  if (int r = vrp_launch_transpose(w->att_output_weight, 128, 384, 384, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dQ2, 128, s.WT, 128, nullptr, nullptr, 0, s.dO2, 384, R, 384, 128,
+                                 0, st)) return r;
+  // O2 = O Wo^T + bo
+  if (int r = vrp_launch_colsum(s.dO2, 384, R, 384, gr->out_proj_bias, 0, st)) return r;
+  if (int r = vrp_launch_gemm_tn(s.dO2, 384, s.O, 384, gr->out_proj_weight, R, 384, 384, 0, s.slab,
+                                 st)) return r;
+  if (int r = vrp_launch_transpose(w->out_proj_weight, 384, 384, 384, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dO2, 384, s.WT, 384, nullptr, nullptr, 0, s.dO, 384, R, 384, 384,
+                                 0, st)) return r;
+  {
+    const size_t lds = sizeof(float) * ((size_t)3 * N * 49 + 8 * 48 + 4 * 64 * npl);
+    if (npl == 1) {
+      if (db_raise_lds(db_attn_bwd_kernel<1>, lds, "db_attn_bwd")) return 1;
+      hipLaunchKernelGGL(db_attn_bwd_kernel<1>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
+                         s.Vb, s.A, s.dO, s.dQ, s.dKb, s.dVb);
+    } else {
+      if (db_raise_lds(db_attn_bwd_kernel<2>, lds, "db_attn_bwd")) return 1;
+      hipLaunchKernelGGL(db_attn_bwd_kernel<2>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
+                         s.Vb, s.A, s.dO, s.dQ, s.dKb, s.dVb);
+    }
+    VRP_CHECK_LAUNCH("db_attn_bwd");
+  }
+  // Q = ctx Wq^T + bq;  K = emb Wk^T + bk;  V = emb Wv^T + bv
+  if (int r = vrp_launch_colsum(s.dQ, 384, R, 384, gr->in_proj_bias, 0, st)) return r;
+  if (int r = vrp_launch_colsum(s.dKb, 384, RB, 384, gr->in_proj_bias + 384, 0, st)) return r;
+  if (int r = vrp_launch_colsum(s.dVb, 384, RB, 384, gr->in_proj_bias + 768, 0, st)) return r;
+  if (int r = vrp_launch_gemm_tn(s.dQ, 384, s.ctx, 384, gr->q_proj_weight, R, 384, 384, 0, s.slab,
+                                 st)) return r;
+  if (int r = vrp_launch_transpose(w->q_proj_weight, 384, 384, 384, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dQ, 384, s.WT, 384, nullptr, nullptr, 0, s.dctx, 384, R, 384, 384,
+                                 0, st)) return r;
+  const float *D = s.dctx;
+  if (kind == VRP_KIND_IRP) {
+    // ctx = cin Wc^T  (Wc zero-padded to 384 columns)
+    if (int r = vrp_launch_gemm_tn(s.dctx, 384, s.cin, 384, s.dWcp, R, 384, 384, 0, s.slab, st))
+      return r;
+    hipLaunchKernelGGL(db_pad_copy_kernel, dim3((384 * 257 + 255) / 256), dim3(256), 0, st, s.dWcp,
+                       384, 257, gr->context_proj_weight, 257, 257, 384);
+    VRP_CHECK_LAUNCH("db_pad_copy");
+    if (int r = vrp_launch_transpose(s.Wcp, 384, 384, 384, s.WT, st)) return r;
+    if (int r = vrp_launch_gemm_nt(s.dctx, 384, s.WT, 384, nullptr, nullptr, 0, s.dcin, 384, R, 384,
+                                   384, 0, st)) return r;
+    D = s.dcin;
+  }
+  // placeholders: the step-0 rows of the context gradient (graph_decoder.py:79-81)
+  if (kind != VRP_KIND_IRP) {
+    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->first_node, 0, st)) return r;
+    if (int r = vrp_launch_colsum(D + 256, 384, B, 128, gr->last_node, 0, st)) return r;
+  } else {
+    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->last_node, 0, st)) return r;
+    if (gr->first_node) {
+      hipLaunchKernelGGL(db_pad_copy_kernel, dim3(1), dim3(256), 0, st, D, 0, 0, gr->first_node, 128,
+                         128, 1);
+      VRP_CHECK_LAUNCH("db_pad_copy");
+    }
+  }
+  hipLaunchKernelGGL(db_scatter_kernel, dim3(B), dim3(128), 0, st, kind, B, N, T, D, actions, d_emb);
+  VRP_CHECK_LAUNCH("db_scatter");
+  // node-row projections: weight gradients, then d_emb += dK Wk + dV Wv + dKP Wkp
+  if (int r = vrp_launch_gemm_tn(s.dKb, 384, emb, 128, gr->k_proj_weight, RB, 384, 128, 0, s.slab,
+                                 st)) return r;
+  if (int r = vrp_launch_gemm_tn(s.dVb, 384, emb, 128, gr->v_proj_weight, RB, 384, 128, 0, s.slab,
+                                 st)) return r;
+  if (int r = vrp_launch_gemm_tn(s.dKPb, 128, emb, 128, gr->kp_weight, RB, 128, 128, 0, s.slab, st))
+    return r;
+  if (int r = vrp_launch_transpose(w->k_proj_weight, 384, 128, 128, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dKb, 384, s.WT, 384, nullptr, d_emb, 128, d_emb, 128, RB, 128, 384,
+                                 0, st)) return r;
+  if (int r = vrp_launch_transpose(w->v_proj_weight, 384, 128, 128, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dVb, 384, s.WT, 384, nullptr, d_emb, 128, d_emb, 128, RB, 128, 384,
+                                 0, st)) return r;
+  if (int r = vrp_launch_transpose(w->kp_weight, 128, 128, 128, s.WT, st)) return r;
+  if (int r = vrp_launch_gemm_nt(s.dKPb, 128, s.WT, 128, nullptr, d_emb, 128, d_emb, 128, RB, 128, 128,
+                                 0, st)) return r;
+  return 0;
+}

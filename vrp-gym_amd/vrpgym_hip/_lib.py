@@ -64,7 +64,16 @@ class DecoderWeights(C.Structure):
 class RolloutIO(C.Structure):
     """struct vrp_rollout_io"""
     _fields_ = [(n, c_vp) for n in ("acc_loss", "acc_logp", "notdone", "actions", "forced",
-                                    "noise", "logits", "step_logp")]
+                                    "noise", "logits", "step_logp", "mask_trace",
+                                    "load_trace")]
+
+
+class DecoderGrads(C.Structure):
+    """struct vrp_decoder_grads"""
+    _fields_ = [(n, c_vp) for n in (
+        "first_node", "last_node", "q_proj_weight", "k_proj_weight", "v_proj_weight",
+        "in_proj_bias", "out_proj_weight", "out_proj_bias", "kp_weight",
+        "att_output_weight", "context_proj_weight")]
 
 
 def library_path():
@@ -97,6 +106,9 @@ def _declare(lib):
         "vrp_encoder_backward_workspace_bytes": (i64, [i32, i32, i32]),
         "vrp_encoder_backward": (i32, [P(EncoderWeights), P(EncoderGrads), i32, i32, vp, vp, vp,
                                        vp, vp, vp]),
+        "vrp_decoder_backward_workspace_bytes": (i64, [i32, i32, i32, i32]),
+        "vrp_decoder_backward": (i32, [i32, P(DecoderWeights), P(DecoderGrads), i32, i32, i32, vp,
+                                       vp, vp, vp, vp, vp, vp, vp, vp]),
         "vrp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
         "vrp_gemm_tn": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]),
         "vrp_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp]),
