@@ -49,13 +49,13 @@ class TSPModel(nn.Module):
         rollout=True: greedy; False: sampled (Categorical)."""
         if env.KIND not in self.ENV_KINDS:
             raise TypeError(f"{type(self).__name__} cannot drive a {type(env).__name__}")
-        grad = self.training and torch.is_grad_enabled()
+        grad = self.training and torch.is_grad_enabled() and not rollout
         res = runtime.rollout(self, env, greedy=bool(rollout), train=self.training,
-                              noise_mode=self.sampling_noise, trace=grad)
+                              noise_mode=self.sampling_noise, record=grad)
         self.last_rollout = res
         self.decoder.reset()
         logp = res.acc_logp
-        if grad and not rollout:
+        if grad:
             logp = runtime.attach_grad(self, env, res)
         return res.acc_loss, logp
 

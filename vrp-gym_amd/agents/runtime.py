@@ -234,6 +234,7 @@ class RolloutResult:
         self.acc_loss, self.acc_logp, self.notdone = acc_loss, acc_logp, notdone
         self.actions, self.logits, self.step_logp, self.emb = actions, logits, step_logp, emb
         self.mask_trace, self.load_trace = mask_trace, load_trace
+        self.tape = self.x3 = self.depot_mask = None  # encoder tape of a recording train rollout
         self.max_steps = max_steps
         self._T = None
 
@@ -439,15 +440,38 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._sync_positions()
     env._parity = 0
     cenv = env._cenv()
-    hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), derived.data_ptr(), C.byref(cenv),
-                              int(bool(train)), int(not greedy) | (4 if tile_kernel else 0),
-                              emb.data_ptr(),
-                              enc_ws.data_ptr(), dec_ws.data_ptr(), C.byref(io), max_steps,
-                              stream))
+    flags = int(not greedy) | (4 if tile_kernel else 0)
+    tape = x3 = dmask = None
+    if record and train:
+        # the pieces of vrp_rollout with the taped encoder: the backward pass reuses the
+        # intermediates instead of re-running the encoder
+        hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        x3 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        isd = torch.empty((B, N), dtype=torch.uint8, device=dev)
+        hip.check(lib.vrp_env_features(C.byref(cenv), x3.data_ptr(), isd.data_ptr(), stream))
+        if kind == hip.KIND_VRP:      # QUIRK graph_vrp_agent.py:67: depot_mask := mask column
+            dmask = env._mask[0].clone()
+        elif kind == hip.KIND_IRP:    # graph_irp_agent.py:77-79
+            dmask = isd
+        tape = torch.empty(int(lib.vrp_encoder_tape_bytes(B, N, ew.hidden, ew.num_layers)),
+                           dtype=torch.uint8, device=dev)
+        hip.check(lib.vrp_encoder_forward_tape(C.byref(ew), B, N, x3.data_ptr(), hip.ptr(dmask),
+                                               emb.data_ptr(), tape.data_ptr(), 1, stream))
+        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, emb.data_ptr(),
+                                          dec_ws.data_ptr(), stream))
+        hip.check(lib.vrp_rollout_steps(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
+                                        emb.data_ptr(), dec_ws.data_ptr(), C.byref(io),
+                                        max_steps, flags, stream))
+    else:
+        hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), derived.data_ptr(),
+                                  C.byref(cenv), int(bool(train)), flags, emb.data_ptr(),
+                                  enc_ws.data_ptr(), dec_ws.data_ptr(), C.byref(io), max_steps,
+                                  stream))
     env._mask_fresh = False  # final mask sits in buffer T&1; recompute lazily into buffer 0
     res = RolloutResult(acc_loss, acc_logp, notdone, actions, logits, step_logp, emb, max_steps,
                         mask_trace, load_trace)
     res._keep = keep
+    res.tape, res.x3, res.depot_mask = tape, x3, dmask
     if gen_state is not None:
         # leave the CPU generator where the reference would: it draws only T steps
         T = res.T
@@ -459,8 +483,8 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
 
 def attach_grad(model, env, res):
     """Differentiable log-probability of the sampled tour (REINFORCE needs
-    d sum_t log p(a_t) / d theta).  The hand-written backward (K4 in SURVEY.md 7.1)
-    lives in agents/backward.py."""
+    d sum_t log p(a_t) / d theta): an autograd node over the HIP backward pass
+    (agents/backward.py -> vrp_decoder_backward, vrp_encoder_backward)."""
     from . import backward
     return backward.logp_with_grad(model, env, res)
 
