@@ -189,8 +189,10 @@ int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
 int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);
 int vrp_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1, int N2,
                 int accumulate, void *slab_ws, void *stream);
-/* out (N) (+)= column sums of Y (R,N). */
-int vrp_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *stream);
+/* out (N) (+)= column sums of Y (R,N); deterministic two-stage reduction. */
+int64_t vrp_colsum_workspace_bytes(int R, int N);
+int vrp_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *ws,
+               void *stream);
 /* BatchNorm1d(128) backward with batch statistics (agents/graph_encoder.py:141-154 in
  * train mode): stats = [mean | invstd], z = pre-normalisation input. */
 int64_t vrp_bn_bwd_workspace_bytes(void);

@@ -35,7 +35,9 @@ def test_gemm_tn_and_colsum():
                                   ws.data_ptr(), st))
         assert (C2.double() - 2 * want).abs().max().item() < 4e-5 * scale
         out = torch.full((N1,), 3.0, device="cuda")
-        hip.check(lib.vrp_colsum(X.data_ptr(), N1, R, N1, out.data_ptr(), 1, st))
+        cws = torch.empty(int(lib.vrp_colsum_workspace_bytes(R, N1)), dtype=torch.uint8,
+                          device="cuda")
+        hip.check(lib.vrp_colsum(X.data_ptr(), N1, R, N1, out.data_ptr(), 1, cws.data_ptr(), st))
         assert (out.double() - (3.0 + X.double().sum(0))).abs().max().item() < 1e-4 * max(1, R ** 0.5)
         # bitwise reproducible
         C3 = torch.empty_like(C)

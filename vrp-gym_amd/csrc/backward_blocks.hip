@@ -90,24 +90,35 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = accumulate ? C[i] : 0.f;
+#pragma unroll 8
   for (int k = 0; k < nsplit; ++k) s += slabs[(size_t)k * n + i];
   C[i] = s;
 }
 
-extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2) {
-  int nsplit = (R + 2047) / 2048;
+// Splits over rows: enough workgroups to fill the chip (~2 per CU) while a split keeps at
+// least 64 rows; the partial tiles (slabs) are summed in split order.
+static int tn_splits(int R, int N1, int N2) {
+  const int tiles = (N1 / 128) * (N2 / 128);
+  int nsplit = (512 + tiles - 1) / tiles;
+  const int max_by_rows = (R + 63) / 64;
+  if (nsplit > max_by_rows) nsplit = max_by_rows;
   if (nsplit > 128) nsplit = 128;
-  return (int64_t)nsplit * N1 * N2 * sizeof(float);
+  if (nsplit < 1) nsplit = 1;
+  return nsplit;
+}
+
+extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2) {
+  return (int64_t)tn_splits(R, N1, N2) * N1 * N2 * sizeof(float);
 }
 
 int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
                        int N2, int accumulate, void *slab_ws, hipStream_t st) {
   VRP_REQUIRE(R > 0 && N1 % 128 == 0 && N2 % 128 == 0, "gemm_tn: bad shape R=%d N1=%d N2=%d", R,
               N1, N2);
-  int nsplit = (R + 2047) / 2048;
-  if (nsplit > 128) nsplit = 128;
+  int nsplit = tn_splits(R, N1, N2);
   int rps = (R + nsplit - 1) / nsplit;
   rps = (rps + TN_BR - 1) / TN_BR * TN_BR;
+  nsplit = (R + rps - 1) / rps;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 128, N2 / 128, nsplit), dim3(256), 0, st, X, ldx, Y,
                      ldy, (float *)slab_ws, R, N1, N2, rps);
   VRP_CHECK_LAUNCH("gemm_tn");
@@ -124,34 +135,65 @@ extern "C" int vrp_gemm_tn(const float *X, int ldx, const float *Y, int ldy, flo
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
-// out[c] (+)= sum_r Y[r][c]; one workgroup per 64 columns, fp64 accumulation, fixed order.
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ Y, int ldy, int R,
-                                                     int N, float *__restrict__ out,
-                                                     int accumulate) {
-  __shared__ double sh[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  double s = 0.0;
-  if (c < N)
-    for (int r = part; r < R; r += 4) s += (double)Y[(size_t)r * ldy + c];
-  sh[part][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (part == 0 && c < N) {
-    const double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-    out[c] = (accumulate ? out[c] : 0.f) + (float)t;
-  }
+// out[c] (+)= sum_r Y[r][c].  Stage 1: workgroup (64 columns, row chunk) -> fp64 partial;
+// stage 2: one thread per column sums the chunk partials in order (deterministic).
+#define CS_MAX_CHUNKS 512
+static int cs_chunks(int R) {
+  int s = (R + 63) / 64;
+  return s > CS_MAX_CHUNKS ? CS_MAX_CHUNKS : (s < 1 ? 1 : s);
 }
 
-int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ Y, int ldy,
+                                                             int R, int N, int rows_per_chunk,
+                                                             double *__restrict__ partial) {
+  __shared__ double sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  double s = 0.0;
+  if (c < N) {
+#pragma unroll 4
+    for (int r = r0 + part; r < r1; r += 4) s += (double)Y[(size_t)r * ldy + c];
+  }
+  sh[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && c < N)
+    partial[(size_t)blockIdx.y * N + c] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void colsum_final_kernel(const double *__restrict__ partial,
+                                                          int chunks, int N,
+                                                          float *__restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= N) return;
+  double s = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * N + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+extern "C" int64_t vrp_colsum_workspace_bytes(int R, int N) {
+  return (int64_t)cs_chunks(R) * N * sizeof(double);
+}
+
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *ws,
                       hipStream_t st) {
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, st, Y, ldy, R, N, out,
-                     accumulate);
-  VRP_CHECK_LAUNCH("colsum");
+  const int chunks = cs_chunks(R);
+  const int rpc = (R + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, Y, ldy, R,
+                     N, rpc, (double *)ws);
+  VRP_CHECK_LAUNCH("colsum_partial");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, st,
+                     (const double *)ws, chunks, N, out, accumulate);
+  VRP_CHECK_LAUNCH("colsum_final");
   return 0;
 }
 
 extern "C" int vrp_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
-                          void *stream) {
-  return vrp_launch_colsum(Y, ldy, R, N, out, accumulate, (hipStream_t)stream);
+                          void *ws, void *stream) {
+  VRP_REQUIRE(Y && out && ws && R > 0 && N > 0, "colsum: bad argument");
+  return vrp_launch_colsum(Y, ldy, R, N, out, accumulate, ws, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ transpose (small weights)
@@ -203,6 +245,7 @@ __global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int n
                                        double *__restrict__ totals, int accumulate) {
   const int c = threadIdx.x;  // 0..255
   double s = 0.0;
+#pragma unroll 8
   for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 256 + c];
   totals[c] = s;
   if (c < 128) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
@@ -229,8 +272,8 @@ extern "C" int64_t vrp_bn_bwd_workspace_bytes(void) { return (int64_t)(1024 + 1)
 int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
                       int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
                       hipStream_t st) {
-  int blocks = (R + 1) / 2;
-  if (blocks > 1024) blocks = 1024;
+  int blocks = (R + 15) / 16;  // >= 8 rows per half-block; 512 workgroups fill the chip
+  if (blocks > 512) blocks = 512;
   double *partial = (double *)ws;
   double *totals = partial + (size_t)1024 * 256;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, dy, z, stats, R, partial);

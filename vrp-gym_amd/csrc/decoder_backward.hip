@@ -25,7 +25,8 @@ int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const f
                        int relu, hipStream_t stream);
 int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
                        int N2, int accumulate, void *slab_ws, hipStream_t st);
-int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+extern "C" int64_t vrp_colsum_workspace_bytes(int R, int N);
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *ws,
                       hipStream_t st);
 int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *dst, hipStream_t st);
 
@@ -258,7 +259,6 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
       __syncthreads();
     }
     if (wave == 0) {
-      float *dst = pass == 0 ? dK : dV;
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         const int n = lane + 64 * i;
@@ -443,7 +443,7 @@ struct DecBwdWs {
   float *ctx, *cin, *Q, *O, *O2, *Q2, *A;             // step-row tape
   float *dQ2, *dO2, *dO, *dQ, *dctx, *dcin;           // step-row gradients
   float *WT, *Wcp, *dWcp, *tmp;                       // transposed weight, padded Wc, its grad
-  void *slab;
+  void *slab, *csws;
 };
 
 static size_t db_slab_bytes(int R, int RB) {
@@ -472,6 +472,8 @@ static DecBwdWs carve_dec_bwd(int kind, void *ws, int B, int N, int T, size_t *t
   w.tmp = take(512);
   w.slab = p;
   p += vrp_align_up(db_slab_bytes((int)R, (int)RB));
+  w.csws = p;
+  p += vrp_align_up((size_t)vrp_colsum_workspace_bytes((int)(R > RB ? R : RB), VRP_D));
   if (total) *total = (size_t)(p - (char *)ws);
   return w;
 }
@@ -573,7 +575,7 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   if (int r = vrp_launch_gemm_nt(s.dQ2, 128, s.WT, 128, nullptr, nullptr, 0, s.dO2, 384, R, 384, 128,
                                  0, st)) return r;
   // O2 = O Wo^T + bo
-  if (int r = vrp_launch_colsum(s.dO2, 384, R, 384, gr->out_proj_bias, 0, st)) return r;
+  if (int r = vrp_launch_colsum(s.dO2, 384, R, 384, gr->out_proj_bias, 0, s.csws, st)) return r;
   if (int r = vrp_launch_gemm_tn(s.dO2, 384, s.O, 384, gr->out_proj_weight, R, 384, 384, 0, s.slab,
                                  st)) return r;
   if (int r = vrp_launch_transpose(w->out_proj_weight, 384, 384, 384, s.WT, st)) return r;
@@ -593,9 +595,9 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
     VRP_CHECK_LAUNCH("db_attn_bwd");
   }
   // Q = ctx Wq^T + bq;  K = emb Wk^T + bk;  V = emb Wv^T + bv
-  if (int r = vrp_launch_colsum(s.dQ, 384, R, 384, gr->in_proj_bias, 0, st)) return r;
-  if (int r = vrp_launch_colsum(s.dKb, 384, RB, 384, gr->in_proj_bias + 384, 0, st)) return r;
-  if (int r = vrp_launch_colsum(s.dVb, 384, RB, 384, gr->in_proj_bias + 768, 0, st)) return r;
+  if (int r = vrp_launch_colsum(s.dQ, 384, R, 384, gr->in_proj_bias, 0, s.csws, st)) return r;
+  if (int r = vrp_launch_colsum(s.dKb, 384, RB, 384, gr->in_proj_bias + 384, 0, s.csws, st)) return r;
+  if (int r = vrp_launch_colsum(s.dVb, 384, RB, 384, gr->in_proj_bias + 768, 0, s.csws, st)) return r;
   if (int r = vrp_launch_gemm_tn(s.dQ, 384, s.ctx, 384, gr->q_proj_weight, R, 384, 384, 0, s.slab,
                                  st)) return r;
   if (int r = vrp_launch_transpose(w->q_proj_weight, 384, 384, 384, s.WT, st)) return r;
@@ -616,10 +618,10 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   }
   // placeholders: the step-0 rows of the context gradient (graph_decoder.py:79-81)
   if (kind != VRP_KIND_IRP) {
-    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->first_node, 0, st)) return r;
-    if (int r = vrp_launch_colsum(D + 256, 384, B, 128, gr->last_node, 0, st)) return r;
+    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->first_node, 0, s.csws, st)) return r;
+    if (int r = vrp_launch_colsum(D + 256, 384, B, 128, gr->last_node, 0, s.csws, st)) return r;
   } else {
-    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->last_node, 0, st)) return r;
+    if (int r = vrp_launch_colsum(D + 128, 384, B, 128, gr->last_node, 0, s.csws, st)) return r;
     if (gr->first_node) {
       hipLaunchKernelGGL(db_pad_copy_kernel, dim3(1), dim3(256), 0, st, D, 0, 0, gr->first_node, 128,
                          128, 1);

@@ -17,7 +17,8 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
                             int ldc, int M, int N, int K, int relu, hipStream_t stream);
 int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
                        int N2, int accumulate, void *slab_ws, hipStream_t st);
-int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate,
+extern "C" int64_t vrp_colsum_workspace_bytes(int R, int N);
+int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int accumulate, void *ws,
                       hipStream_t st);
 int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *dst, hipStream_t st);
 int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
@@ -593,11 +594,13 @@ extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict__ dX0,
                                                         const float *__restrict__ x,
                                                         const uint8_t *__restrict__ depot_mask,
-                                                        int rows, float *__restrict__ out) {
+                                                        int rows, int rows_per_block,
+                                                        double *__restrict__ partial) {
   __shared__ double sh[2][128][7];
   const int c = threadIdx.x & 127, par = threadIdx.x >> 7;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   double a[7] = {0, 0, 0, 0, 0, 0, 0};
-  for (int r = par; r < rows; r += 2) {
+  for (int r = r0 + par; r < r1; r += 2) {
     const double g = (double)dX0[(size_t)r * 128 + c];
     const float *xr = x + (size_t)r * 3;
     if (depot_mask && depot_mask[r]) {
@@ -611,23 +614,32 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float *__restrict_
   __syncthreads();
   if (par == 0)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) out[c * 7 + k] = (float)(sh[0][c][k] + sh[1][c][k]);
+    for (int k = 0; k < 7; ++k)
+      partial[((size_t)blockIdx.x * 128 + c) * 7 + k] = sh[0][c][k] + sh[1][c][k];
 }
 
-__global__ void embed_bwd_scatter_kernel(const float *__restrict__ acc, int node_dim, int depot_dim,
-                                         float *dWn, float *dbn, float *dWd, float *dbd) {
+// ordered sum of the per-block partials, then the (128, 7) table is split into the parameters
+__global__ void embed_bwd_scatter_kernel(const double *__restrict__ partial, int nblocks,
+                                         int node_dim, int depot_dim, float *dWn, float *dbn,
+                                         float *dWd, float *dbd) {
   const int c = threadIdx.x;
-  for (int d = 0; d < node_dim; ++d) dWn[c * node_dim + d] = acc[c * 7 + d];
-  dbn[c] = acc[c * 7 + 3];
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nblocks; ++b)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] += partial[((size_t)b * 128 + c) * 7 + k];
+  for (int d = 0; d < node_dim; ++d) dWn[c * node_dim + d] = (float)acc[d];
+  dbn[c] = (float)acc[3];
   if (dWd) {
-    for (int d = 0; d < depot_dim; ++d) dWd[c * depot_dim + d] = acc[c * 7 + 4 + d];
-    dbd[c] = acc[c * 7 + 6];
+    for (int d = 0; d < depot_dim; ++d) dWd[c * depot_dim + d] = (float)acc[4 + d];
+    dbd[c] = (float)acc[6];
   }
 }
 
+#define EMB_BWD_BLOCKS 128
 struct EncBwdWs {
-  float *gA, *gB, *gC, *gQKV, *gH, *WT, *embacc;
-  void *slab, *bnws;
+  float *gA, *gB, *gC, *gQKV, *gH, *WT;
+  double *embacc;
+  void *slab, *bnws, *csws;
 };
 
 extern "C" int64_t vrp_encoder_backward_workspace_bytes(int B, int N, int hidden) {
@@ -635,9 +647,10 @@ extern "C" int64_t vrp_encoder_backward_workspace_bytes(int B, int N, int hidden
   const int big = hidden > 384 ? hidden : 384;
   return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
                    vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up((size_t)big * 128 * 4) +
-                   vrp_align_up(128 * 7 * 4) +
+                   vrp_align_up((size_t)EMB_BWD_BLOCKS * 128 * 7 * 8) +
                    vrp_align_up((size_t)vrp_gemm_tn_workspace_bytes((int)R, big, big)) +
-                   vrp_align_up((size_t)vrp_bn_bwd_workspace_bytes()));
+                   vrp_align_up((size_t)vrp_bn_bwd_workspace_bytes()) +
+                   vrp_align_up((size_t)vrp_colsum_workspace_bytes((int)R, big)));
 }
 
 static EncBwdWs carve_enc_bwd(void *ws, int B, int N, int hidden) {
@@ -651,9 +664,10 @@ static EncBwdWs carve_enc_bwd(void *ws, int B, int N, int hidden) {
   w.gQKV = (float *)p; p += vrp_align_up(R * 384 * 4);
   w.gH = (float *)p;   p += vrp_align_up(R * (size_t)hidden * 4);
   w.WT = (float *)p;   p += vrp_align_up((size_t)big * 128 * 4);
-  w.embacc = (float *)p; p += vrp_align_up(128 * 7 * 4);
+  w.embacc = (double *)p; p += vrp_align_up((size_t)EMB_BWD_BLOCKS * 128 * 7 * 8);
   w.slab = p;          p += vrp_align_up((size_t)vrp_gemm_tn_workspace_bytes((int)R, big, big));
-  w.bnws = p;
+  w.bnws = p;          p += vrp_align_up((size_t)vrp_bn_bwd_workspace_bytes());
+  w.csws = p;
   return w;
 }
 
@@ -674,13 +688,13 @@ extern "C" int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_enco
     // out = BN2(Z2),  Z2 = Y1 + relu(Y1 W1^T + b1) W2^T + b2
     if (int r = vrp_launch_bn_bwd(dout, T.Z2, T.stats2, P.bn2_weight, R, s.gB, G.bn2_weight,
                                   G.bn2_bias, 0, s.bnws, st)) return r;          // gB = dZ2
-    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.ff2_bias, 0, st)) return r;
+    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.ff2_bias, 0, s.csws, st)) return r;
     if (int r = vrp_launch_gemm_tn(s.gB, 128, T.H, Hd, G.ff2_weight, R, 128, Hd, 0, s.slab, st))
       return r;                                                                  // dW2 (128,Hd)
     if (int r = vrp_launch_transpose(P.ff2_weight, 128, Hd, Hd, s.WT, st)) return r;   // (Hd,128)
     if (int r = vrp_launch_gemm_nt_full(s.gB, 128, s.WT, 128, nullptr, nullptr, 0, nullptr, T.H,
                                         s.gH, Hd, R, Hd, 128, 0, st)) return r;  // gH = dH (gated)
-    if (int r = vrp_launch_colsum(s.gH, Hd, R, Hd, G.ff0_bias, 0, st)) return r;
+    if (int r = vrp_launch_colsum(s.gH, Hd, R, Hd, G.ff0_bias, 0, s.csws, st)) return r;
     if (int r = vrp_launch_gemm_tn(s.gH, Hd, T.Y1, 128, G.ff0_weight, R, Hd, 128, 0, s.slab, st))
       return r;                                                                  // dW1 (Hd,128)
     if (int r = vrp_launch_transpose(P.ff0_weight, Hd, 128, 128, s.WT, st)) return r;  // (128,Hd)
@@ -689,14 +703,14 @@ extern "C" int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_enco
     // Y1 = BN1(Z1),  Z1 = X + ATT Wo^T + bo
     if (int r = vrp_launch_bn_bwd(s.gA, T.Z1, T.stats1, P.bn1_weight, R, s.gB, G.bn1_weight,
                                   G.bn1_bias, 0, s.bnws, st)) return r;          // gB = dZ1
-    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.out_proj_bias, 0, st)) return r;
+    if (int r = vrp_launch_colsum(s.gB, 128, R, 128, G.out_proj_bias, 0, s.csws, st)) return r;
     if (int r = vrp_launch_gemm_tn(s.gB, 128, T.ATT, 128, G.out_proj_weight, R, 128, 128, 0,
                                    s.slab, st)) return r;
     if (int r = vrp_launch_transpose(P.out_proj_weight, 128, 128, 128, s.WT, st)) return r;
     if (int r = vrp_launch_gemm_nt(s.gB, 128, s.WT, 128, nullptr, nullptr, 0, s.gC, 128, R, 128,
                                    128, 0, st)) return r;                        // gC = dATT
     if (int r = vrp_launch_attention_bwd(T.QKV, s.gC, s.gQKV, B, N, st)) return r;
-    if (int r = vrp_launch_colsum(s.gQKV, 384, R, 384, G.in_proj_bias, 0, st)) return r;
+    if (int r = vrp_launch_colsum(s.gQKV, 384, R, 384, G.in_proj_bias, 0, s.csws, st)) return r;
     if (int r = vrp_launch_gemm_tn(s.gQKV, 384, T.X, 128, G.in_proj_weight, R, 384, 128, 0, s.slab,
                                    st)) return r;                                // dWin (384,128)
     if (int r = vrp_launch_transpose(P.in_proj_weight, 384, 128, 128, s.WT, st)) return r;  // (128,384)
@@ -704,9 +718,14 @@ extern "C" int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_enco
                                    384, 0, st)) return r;                        // gA = dX
     dout = s.gA;
   }
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(1), dim3(256), 0, st, dout, x, depot_mask, R, s.embacc);
+  int eb = (R + 31) / 32;
+  if (eb > EMB_BWD_BLOCKS) eb = EMB_BWD_BLOCKS;
+  const int erpb = (R + eb - 1) / eb;
+  eb = (R + erpb - 1) / erpb;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(eb), dim3(256), 0, st, dout, x, depot_mask, R, erpb,
+                     s.embacc);
   VRP_CHECK_LAUNCH("embed_bwd");
-  hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(1), dim3(128), 0, st, s.embacc, w->node_dim,
+  hipLaunchKernelGGL(embed_bwd_scatter_kernel, dim3(1), dim3(128), 0, st, s.embacc, eb, w->node_dim,
                      w->depot_dim, g->node_embed_weight, g->node_embed_bias,
                      w->depot_embed_weight ? g->depot_embed_weight : nullptr,
                      g->depot_embed_bias);

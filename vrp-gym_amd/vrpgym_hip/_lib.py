@@ -111,7 +111,8 @@ def _declare(lib):
                                        vp, vp, vp, vp, vp, vp, vp, vp]),
         "vrp_gemm_tn_workspace_bytes": (i64, [i32, i32, i32]),
         "vrp_gemm_tn": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]),
-        "vrp_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp]),
+        "vrp_colsum_workspace_bytes": (i64, [i32, i32]),
+        "vrp_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, vp]),
         "vrp_bn_bwd_workspace_bytes": (i64, []),
         "vrp_bn_bwd": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp]),
         "vrp_attention_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
