@@ -240,13 +240,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblocks,
-                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                       double *__restrict__ totals, int accumulate) {
-  const int c = threadIdx.x;  // 0..255
+// 1024 threads: column c = tid & 255, quarter q = tid >> 8 of the block partials; quarters
+// are combined in order, so the result does not depend on scheduling
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double *__restrict__ partial,
+                                                               int nblocks,
+                                                               float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta,
+                                                               double *__restrict__ totals,
+                                                               int accumulate) {
+  __shared__ double sh[4][256];
+  const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int per = (nblocks + 3) / 4;
+  const int b0 = q * per, b1 = min(nblocks, b0 + per);
   double s = 0.0;
 #pragma unroll 8
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 256 + c];
+  for (int b = b0; b < b1; ++b) s += partial[(size_t)b * 256 + c];
+  sh[q][c] = s;
+  __syncthreads();
+  if (q != 0) return;
+  s = ((sh[0][c] + sh[1][c]) + sh[2][c]) + sh[3][c];
   totals[c] = s;
   if (c < 128) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s;
   else dgamma[c - 128] = (accumulate ? dgamma[c - 128] : 0.f) + (float)s;
@@ -272,13 +284,13 @@ extern "C" int64_t vrp_bn_bwd_workspace_bytes(void) { return (int64_t)(1024 + 1)
 int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const float *gamma,
                       int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
                       hipStream_t st) {
-  int blocks = (R + 15) / 16;  // >= 8 rows per half-block; 512 workgroups fill the chip
+  int blocks = (R + 31) / 32;
   if (blocks > 512) blocks = 512;
   double *partial = (double *)ws;
   double *totals = partial + (size_t)1024 * 256;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, st, dy, z, stats, R, partial);
   VRP_CHECK_LAUNCH("bn_bwd_reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, blocks, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, blocks, dgamma,
                      dbeta, totals, accumulate);
   VRP_CHECK_LAUNCH("bn_bwd_finalize");
   const size_t n = (size_t)R * 128;

@@ -369,8 +369,10 @@ static int batchnorm_train(float *x, int rows, const float *w, const float *b, f
                            float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
   hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, ws.stats);
   VRP_CHECK_LAUNCH("bn_zero_stats");
-  int blocks = (rows + 1) / 2;
-  if (blocks > 2048) blocks = 2048;
+  // every block ends with 256 same-address fp64 atomics (~11 ns each, serialised per
+  // address): keep the block count low enough that they stay below the streaming time
+  int blocks = (rows + 31) / 32;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);
   VRP_CHECK_LAUNCH("bn_stats");
   const size_t n4 = (size_t)rows * 32;
@@ -539,8 +541,10 @@ static int bn_train_taped(const float *z, float *y, int rows, const float *w, co
                           double *sums, hipStream_t st) {
   hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, sums);
   VRP_CHECK_LAUNCH("bn_zero_stats");
-  int blocks = (rows + 1) / 2;
-  if (blocks > 2048) blocks = 2048;
+  // every block ends with 256 same-address fp64 atomics (~11 ns each, serialised per
+  // address): keep the block count low enough that they stay below the streaming time
+  int blocks = (rows + 31) / 32;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, z, rows, sums);
   VRP_CHECK_LAUNCH("bn_stats");
   const size_t n4 = (size_t)rows * 32;
