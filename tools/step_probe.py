@@ -18,4 +18,4 @@ if len(sys.argv) > 1:
 dev = torch.device("cuda", 0)
 for kind, N, B in shapes:
     r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3)
-    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "loop_us_per_launch", "achieved", "frac")}))
+    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "event_pair_per_launch_us", "c_loop_per_launch_us", "achieved", "frac")}))

@@ -8,11 +8,12 @@
 //     the keys K_n = Wk*e_n + bk are per-episode constants, so the glimpse score
 //     q_h.K_{h,n}/sqrt(48) splits into per-episode tables
 //        SG[b][h][n]        graph-embedding + bias part
-//        base1[b][h][n]     SG + "first node" part, one row built after step 0 (TSP/VRP)
-//        SL[b][m][h][n]     "last node  = m" part
+//        C0[b][h][n]        step-0 placeholders _first_node/_last_node;  row0 = SG + C0
+//        SL[b][m][h][n]     "last node = m" part PLUS everything constant after step 0
+//                           (SG, and for TSP/VRP the "first node" part, known after step 0)
 //        SLD[b][h][n]       load coefficient           (IRP)
-//        C0[b][h][n]        step-0 placeholders _first_node/_last_node
-//     built once per episode (vrp_decode_prologue); a step only gathers rows.
+//     built once per episode (vrp_decode_prologue / vrp_decode_first_row); a step reads ONE
+//     table row: row0 at t = 0, SL[b][last] afterwards.
 //   * sum_n a_n (Wv e_n + bv) = Wv (sum_n a_n e_n) + bv, and _kp/_att_output/out_proj
 //     fold into one 128x384 matrix M, so a step reads only the RAW (N,128)
 //     embedding tile, once, and keeps it in registers for both the glimpse
@@ -162,8 +163,8 @@ struct DecWs {
   float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
   float *QG;     // (B,384)     Wq_g g + bq
   float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
-  float *SG, *C0, *SLD, *base1, *curs;  // (B,8,N) each
-  float *SL;                     // (B,N,8,N)
+  float *SG, *C0, *SLD, *row0;   // (B,8,N) each
+  float *SL;                     // (B,N,8,N)  complete score row of every later step
   float *Efirst, *QF1;           // (B,128) (B,384): first chosen node and its query part
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:] (N <= 64)
   float *cvec;                   // (B,N)                e_m . mb
@@ -190,8 +191,7 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
   w.SG = (float *)p;    p += vrp_align_up(hn);
   w.C0 = (float *)p;    p += vrp_align_up(hn);
   w.SLD = (float *)p;   p += vrp_align_up(hn);
-  w.base1 = (float *)p; p += vrp_align_up(hn);
-  w.curs = (float *)p;  p += vrp_align_up(hn);
+  w.row0 = (float *)p;  p += vrp_align_up(hn);
   w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
   w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
@@ -205,7 +205,7 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
 extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
   return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
-                   vrp_align_up(R * proj_width(kind, N) * 4) + 5 * vrp_align_up(hn) +
+                   vrp_align_up(R * proj_width(kind, N) * 4) + 4 * vrp_align_up(hn) +
                    vrp_align_up(tb) + vrp_align_up((size_t)B * 128 * 4) +
                    vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(rtable_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
@@ -258,22 +258,28 @@ __device__ __forceinline__ void load_rows12(float (&dst)[12], const float *row_p
   }
 }
 
-template <int NTMAX>  // 16-column tiles per row: ceil(N/16) <= NTMAX
+// PHASE 0 (prologue): score rows SG / C0 / SLD, the step-0 row `row0` = SG + C0, the
+//   pointer-logit table RT and -- IRP only, whose context has no first-node term -- the
+//   last-node table with the constant row folded in: SL[m] = QL_m KK^T/sqrt(48) + SG.
+// PHASE 1 (TSP/VRP, right after step 0, when first_ is known, graph_decoder.py:111-113):
+//   base1 = SG + (Wq_first e_first).KK/sqrt(48), and SL[m] = QL_m KK^T/sqrt(48) + base1.
+// Either way a later step's complete glimpse score row is the single table row SL[b][last].
+template <int NTMAX, int PHASE>  // 16-column tiles per row: ceil(N/16) <= NTMAX
 __global__ __launch_bounds__(256) void pair_tables_kernel(
     int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
-    const float *__restrict__ qc0, const float *__restrict__ wload, float *__restrict__ SG,
-    float *__restrict__ C0, float *__restrict__ SLD, float *__restrict__ SL,
-    float *__restrict__ curs, float *__restrict__ RT) {
+    const float *__restrict__ qc0, const float *__restrict__ wload, const float *__restrict__ QF1,
+    float *__restrict__ SG, float *__restrict__ C0, float *__restrict__ SLD,
+    float *__restrict__ SL, float *__restrict__ row0, float *__restrict__ RT) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
   const int i16 = lane & 15, q = lane >> 4;
   const int NT = (N + 15) >> 4;
-  (void)kind;
   const int qloff = 0, kkoff = 384, kmoff = 768, vvoff = 1152;
   const int hq = h * VRP_HD + 12 * q;
   const float c = 0.14433756729740643f;  // 1/sqrt(48)
   const float *rows = PROJ + (size_t)b * N * P;
+  const size_t hn = ((size_t)b * 8 + h) * N;
 
   float bf[NTMAX][12];
   auto load_b = [&](int off) {
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
       load_rows12<NTMAX>(bf[nt], rows + (size_t)(n < N ? n : 0) * P + off + hq, nt < NT && n < N);
     }
   };
-  // one 16-row tile of A against every column tile; store(row, col, value)
+  // one 16-row tile of A against every column tile; store(row, column tile, column, value)
   auto tile_rows = [&](const float (&af)[12], auto &&store) {
 #pragma unroll
     for (int nt = 0; nt < NTMAX; ++nt) {
@@ -293,51 +299,90 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
         for (int s_ = 0; s_ < 12; ++s_)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], bf[nt][s_], acc, 0, 0, 0);
         const int n = nt * 16 + i16;  // D: col = lane&15, row = (lane>>4)*4 + reg
-        if (n < N) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) store(q * 4 + r, n, acc[r]);
-        }
+        for (int r = 0; r < 4; ++r) store(q * 4 + r, nt, n, acc[r]);
       }
     }
   };
 
   // ---- glimpse score tables: B operand = projected keys -----------------------------
   load_b(kkoff);
+  float base[NTMAX];  // constant part of every later score row, column nt*16 + i16
+#pragma unroll
+  for (int nt = 0; nt < NTMAX; ++nt) base[nt] = 0.f;
   {
     float af[12];
-    // three extra query rows: 0 = graph embedding + bq, 1 = step-0 placeholders, 2 = load
-    const float *src = (i16 == 0) ? QG + (size_t)b * VRP_D : (i16 == 1 ? qc0 : wload);
-    load_rows12<NTMAX>(af, src + hq, i16 < 3);
-    const size_t hn = ((size_t)b * 8 + h) * N;
-    float sg_keep[NTMAX];  // rows 0/1 live in lanes q == 0, regs 0/1
-    tile_rows(af, [&](int r, int n, float v) {
+    if (PHASE == 0) {
+      // three extra query rows: 0 = graph embedding + bq, 1 = step-0 placeholders, 2 = load
+      const float *src = (i16 == 0) ? QG + (size_t)b * VRP_D : (i16 == 1 ? qc0 : wload);
+      load_rows12<NTMAX>(af, src + hq, i16 < 3);
+    } else {
+      load_rows12<NTMAX>(af, QF1 + (size_t)b * VRP_D + hq, i16 == 0);  // row 0 = first-node query
+    }
+    float keep[NTMAX];  // row 0 of the tile lives in lanes q == 0, reg 0
+    tile_rows(af, [&](int r, int nt, int n, float v) {
       v *= c;
-      if (r == 0) { SG[hn + n] = v; sg_keep[0] = v; }
-      if (r == 1) { C0[hn + n] = v; curs[hn + n] = sg_keep[0] + v; }  // step-0 score row
-      if (r == 2) SLD[hn + n] = v;
+      if (r == 0) keep[nt] = v;
+      if (PHASE == 0 && n < N) {
+        if (r == 0) SG[hn + n] = v;
+        if (r == 1) { C0[hn + n] = v; row0[hn + n] = keep[nt] + v; }  // step-0 score row
+        if (r == 2) SLD[hn + n] = v;
+      }
     });
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) {
+      if (nt < NT) {
+        float v = keep[nt];  // meaningful in lanes q == 0 only
+        if (PHASE == 1) {
+          const int n = nt * 16 + i16;
+          v += (n < N) ? SG[hn + n] : 0.f;
+        }
+        base[nt] = __shfl(v, i16, 64);  // lane i16 (q == 0) holds column i16 of this tile
+      }
+    }
   }
-  for (int mt = 0; mt < NT; ++mt) {
-    const int m = mt * 16 + i16;
-    const float *rp = rows + (size_t)(m < N ? m : 0) * P;
-    float af[12];
-    load_rows12<NTMAX>(af, rp + qloff + hq, m < N);
-    tile_rows(af, [&](int r, int n, float v) {
-      const int mm = mt * 16 + r;
-      if (mm < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = v * c;
-    });
+  if (PHASE == 1 || kind == VRP_KIND_IRP) {
+    for (int mt = 0; mt < NT; ++mt) {
+      const int m = mt * 16 + i16;
+      const float *rp = rows + (size_t)(m < N ? m : 0) * P;
+      float af[12];
+      load_rows12<NTMAX>(af, rp + qloff + hq, m < N);
+      tile_rows(af, [&](int r, int nt, int n, float v) {
+        const int mm = mt * 16 + r;
+        if (mm < N && n < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = fmaf(v, c, base[nt]);
+      });
+    }
   }
+  if (PHASE == 1) return;
   // ---- pointer-logit table: B operand = projected values ------------------------------
   load_b(vvoff);
   for (int mt = 0; mt < NT; ++mt) {
     const int m = mt * 16 + i16;
     float af[12];
     load_rows12<NTMAX>(af, rows + (size_t)(m < N ? m : 0) * P + kmoff + hq, m < N);
-    tile_rows(af, [&](int r, int n, float v) {
+    tile_rows(af, [&](int r, int nt, int n, float v) {
       const int mm = mt * 16 + r;
-      if (mm < N) RT[(((size_t)b * N + mm) * 8 + h) * N + n] = v;
+      if (mm < N && n < N) RT[(((size_t)b * N + mm) * 8 + h) * N + n] = v;
     });
   }
+}
+
+template <int PHASE>
+static int launch_pair_tables(int kind, int B, int N, int P, const float *PROJ, const float *QG,
+                              const float *qc0, const float *wload, const float *QF1, float *SG,
+                              float *C0, float *SLD, float *SL, float *row0, float *RT,
+                              hipStream_t st) {
+  if (N <= 32)
+    hipLaunchKernelGGL((pair_tables_kernel<2, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
+                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+  else if (N <= 64)
+    hipLaunchKernelGGL((pair_tables_kernel<4, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
+                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+  else
+    hipLaunchKernelGGL((pair_tables_kernel<8, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
+                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+  VRP_CHECK_LAUNCH("pair_tables");
+  return 0;
 }
 
 extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
@@ -355,16 +400,8 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
                                  128, 0, st)) return r;
   VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
-  if (N <= 32)
-    hipLaunchKernelGGL(pair_tables_kernel<2>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
-  else if (N <= 64)
-    hipLaunchKernelGGL(pair_tables_kernel<4>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
-  else
-    hipLaunchKernelGGL(pair_tables_kernel<8>, dim3(B, 2), dim3(256), 0, st, kind, N, P, w.PROJ,
-                       w.QG, d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.curs, w.RT);
-  VRP_CHECK_LAUNCH("pair_tables");
+  if (int r = launch_pair_tables<0>(kind, B, N, P, w.PROJ, w.QG, d.qc0, d.wload, nullptr, w.SG, w.C0,
+                                    w.SLD, w.SL, w.row0, w.RT, st)) return r;
   hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
                      w.cvec);
   VRP_CHECK_LAUNCH("cvec");
@@ -382,9 +419,9 @@ __device__ __forceinline__ void flag_notdone(int32_t *flag) {
 
 // After the first step of a TSP/VRP episode first_ := embedding of the first chosen node
 // (graph_decoder.py:111-113) and stays fixed: its query part is folded ONCE into the
-// per-graph score row  base1 = SG + (Wq_first e_first) . K / sqrt(48)  instead of keeping
-// an (N,8,N) table for every possible first node.  Three small launches after step 0:
-// gather e_first, QF1 = e_first Wq_first^T (MFMA GEMM), this kernel.
+// last-node table (pair_tables_kernel PHASE 1) instead of keeping an (N,8,N) table for every
+// possible first node.  Three launches after step 0: gather e_first,
+// QF1 = e_first Wq_first^T (MFMA GEMM), the table build.
 __global__ __launch_bounds__(128) void gather_first_kernel(const float *__restrict__ emb,
                                                            const int32_t *__restrict__ first,
                                                            int N, float *__restrict__ out) {
@@ -392,46 +429,11 @@ __global__ __launch_bounds__(128) void gather_first_kernel(const float *__restri
   out[(size_t)b * VRP_EMB + c] = emb[((size_t)b * N + first[b]) * VRP_EMB + c];
 }
 
-template <int NPL>
-__global__ __launch_bounds__(256) void first_row_kernel(int N, int P, const float *__restrict__ PROJ,
-                                                        const float *__restrict__ QF1,
-                                                        const float *__restrict__ SG,
-                                                        const float *__restrict__ SL,
-                                                        const int32_t *__restrict__ first,
-                                                        float *__restrict__ base1,
-                                                        float *__restrict__ curs) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x;
-  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  const float c = 0.14433756729740643f;  // 1/sqrt(48)
-  const float *q = QF1 + (size_t)b * VRP_D + h * VRP_HD;
-  const size_t hn = ((size_t)b * 8 + h) * N;
-  const size_t sl = (((size_t)b * N + first[b]) * 8 + h) * N;
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int n = lane + 64 * i;
-    if (n < N) {
-      const float *kp = PROJ + ((size_t)b * N + n) * P + 384 + h * VRP_HD;
-      float s = 0.f;
-#pragma unroll
-      for (int d = 0; d < VRP_HD; d += 4) {
-        const float4 k4 = *reinterpret_cast<const float4 *>(kp + d);
-        s = fmaf(q[d], k4.x, s); s = fmaf(q[d + 1], k4.y, s);
-        s = fmaf(q[d + 2], k4.z, s); s = fmaf(q[d + 3], k4.w, s);
-      }
-      const float b1 = SG[hn + n] + s * c;
-      base1[hn + n] = b1;
-      curs[hn + n] = b1 + SL[sl + n];
-    }
-  }
-}
-
 // ------------------------------------------------------------------ the step kernel
 struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only, fence;
   const float *emb;
-  const float *SG, *C0, *SLD, *SL;
-  float *base1, *curs;
+  const float *row0, *SLD, *SL;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
   const float *RT, *cvec;
@@ -478,9 +480,8 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
   {
     const float loadf = (p.kind == VRP_KIND_IRP) ? (float)p.env.load[b] : 0.f;
     const int last = (p.t > 0) ? p.last[b] : 0;
-    const float *basep = (p.t == 0 ? p.SG : p.base1) + (size_t)b * 8 * N;
-    const float *c0p = p.C0 + (size_t)b * 8 * N;
-    const float *slp = p.SL + ((size_t)b * N + last) * 8 * N;
+    const float *srow = (p.t == 0) ? p.row0 + (size_t)b * 8 * N
+                                   : p.SL + ((size_t)b * N + last) * 8 * N;
     const float *sldp = p.SLD + (size_t)b * 8 * N;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
@@ -492,8 +493,7 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
         const int n = lane + 64 * i;
         s[i] = -INFINITY;
         if (n < N) {
-          float v = basep[h * N + n];
-          v += (p.t == 0) ? c0p[h * N + n] : slp[h * N + n];
+          float v = srow[h * N + n];
           if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sldp[h * N + n], v);
           s[i] = v + (float)mrow[n];
         }
@@ -685,7 +685,6 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 
   // ---- environment step on the chosen node + episode accumulators ---------------------
   EnvStepOut eo = env_step_wave(p.env, b, idx, lane, mask_out);
-  // (TSP/VRP: base1 for the steps after this one is built by first_row_kernel)
   if (lane == 0) {
     p.io.acc_loss[b] += (float)(-eo.dist);  // fp32 accumulate in step order, tsp_agent:85
     p.io.acc_logp[b] += logp;
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 
 // ---------------------------------------------------------------- table-driven step (N <= 64)
 // One wave per graph, no weight matrix and no embedding tile.  Per step a graph streams
-//   3 x (8,N) glimpse score rows, 9 mask rows, its coordinate/visited/demand rows and the
+//   ONE (8,N) glimpse score row, 9 mask rows, its coordinate/visited/demand rows and the
 //   rows RT[b][m][:][:] (8N floats each) of the pointer-logit table -- ONLY for nodes m that
 //   are still selectable: masked logits are -inf whatever their value (graph_decoder.py:98),
 //   so their rows are never read.  Averaged over a TSP episode that halves the traffic.
@@ -708,9 +707,9 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 //     (incl. the first RT rows and the whole env row: lane n holds node n's
 //     coordinates/visited/demand; the action's and the current node's values are then
 //     fetched with readlane instead of dependent loads);
-//   * the only dependent global read is SL[b][action] at the end, overlapped with the
-//     env bookkeeping; it is folded into `curs` (= this graph's score row for the next
-//     step) so the next launch starts without a pointer chase;
+//   * the score row is the table row SL[b][last[b]]: one dependent load at entry (last[b]
+//     comes from the previous launch), issued together with the independent RT rows;
+//     nothing is read or written after the action is known except the env commits;
 //   * the batch-wide done flag is read with everything else and only gates the commits.
 // RT pass: lane = (row slot r = lane>>3, part q = lane&7).  The k-th selectable node
 // (k = 8*pass + r) is found by ballot/prefix; the 8 parts split its row of 2N float4;
@@ -779,8 +778,15 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
   // ---- entry: issue every action-independent load --------------------------------
   const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
   const size_t row = (size_t)b * 8 * N;
+  // this step's complete glimpse score row: row0 at t = 0, else table row SL[b][last]
+  // (one dependent load: last[b] was written by the previous launch)
+  const float *srow = p.row0 + row;
+  if (p.t > 0) {
+    const int last = __builtin_amdgcn_readfirstlane(p.last[b]);
+    srow = p.SL + ((size_t)b * N + last) * 8 * N;
+  }
   int own_mask[NPL];
-  float sc[NPL][8], brow[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
+  float sc[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
   int msk[NPL][8];
   double2 xy[NPL];
   int vis[NPL];
@@ -790,8 +796,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
     own_mask[i] = mask_in[(size_t)b * N + ln[i]];
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      sc[i][h] = p.curs[row + h * N + ln[i]];
-      brow[i][h] = (p.t == 0 ? p.SG : p.base1)[row + h * N + ln[i]];
+      sc[i][h] = srow[h * N + ln[i]];
       sld[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
       msk[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
     }
@@ -956,22 +961,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
   idx = __builtin_amdgcn_readfirstlane(idx);
   if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
 
-  // ---- the only action-dependent reads: next step's score row ------------------------
-  //   curs = base1 + SL[last = idx];  base1 = SG for IRP, and for TSP/VRP the row that
-  //   first_row_kernel builds right after step 0 (which then also writes curs)
-  if (!(p.t == 0 && p.kind != VRP_KIND_IRP)) {
-    const size_t arow = ((size_t)b * N + idx) * 8 * N;
-    float sl[NPL][8];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-#pragma unroll
-      for (int h = 0; h < 8; ++h) sl[i][h] = p.SL[arow + h * N + ln[i]];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-#pragma unroll
-      for (int h = 0; h < 8; ++h)
-        if (inN[i]) p.curs[row + h * N + lane + 64 * i] = brow[i][h] + sl[i][h];
-  }
   if (p.decode_only) {
     if (lane == 0) {
       p.last[b] = idx;
@@ -1089,9 +1078,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.decode_only = decode_only;
   { static const char *e = getenv("VRP_FENCE"); p.fence = e ? atoi(e) : 0; }
   p.emb = emb;
-  p.SG = ws.SG; p.C0 = ws.C0; p.SLD = ws.SLD; p.SL = ws.SL;
-  p.base1 = (kind == VRP_KIND_IRP) ? ws.SG : ws.base1;
-  p.curs = ws.curs;
+  p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL;
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
   p.RT = ws.RT; p.cvec = ws.cvec;
@@ -1104,11 +1091,11 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   return 0;
 }
 
-// first_ is known after step 0: fold its query part into base1 (and curs) once per episode
+// first_ is known after step 0: build the last-node table with its query part folded in
 extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
                                     void *workspace, void *stream) {
   VRP_REQUIRE(derived && emb && workspace, "decode_first_row: NULL argument");
-  if (kind == VRP_KIND_IRP) return 0;  // the IRP context has no first-node term
+  if (kind == VRP_KIND_IRP) return 0;  // no first-node term: the prologue built the table
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs ws = carve_decws(kind, workspace, B, N);
@@ -1117,14 +1104,8 @@ extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N,
   VRP_CHECK_LAUNCH("gather_first");
   if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
                                  384, 128, 0, st)) return r;
-  if (N <= 64)
-    hipLaunchKernelGGL(first_row_kernel<1>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
-                       ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
-  else
-    hipLaunchKernelGGL(first_row_kernel<2>, dim3(B, 2), dim3(256), 0, st, N, P, ws.PROJ, ws.QF1,
-                       ws.SG, ws.SL, ws.first, ws.base1, ws.curs);
-  VRP_CHECK_LAUNCH("first_row");
-  return 0;
+  return launch_pair_tables<1>(kind, B, N, P, ws.PROJ, ws.QG, d.qc0, d.wload, ws.QF1, ws.SG, ws.C0,
+                               ws.SLD, ws.SL, ws.row0, ws.RT, st);
 }
 
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
