@@ -714,7 +714,12 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 // RT pass: lane = (row slot r = lane>>3, part q = lane&7).  The k-th selectable node
 // (k = 8*pass + r) is found by ballot/prefix; the 8 parts split its row of 2N float4;
 // every wave-level load is 8 x 128 contiguous bytes.
+#ifndef RT_U
 #define RT_U 8  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
+#endif
+#ifndef RT_MINW
+#define RT_MINW 3
+#endif
 
 // lane owns float4 indices part + 8*i (i < cnt) of its row; one work item = RT_U of them
 __device__ __forceinline__ void rt_load(float4 (&r)[RT_U], const float4 *rt, int i0, int cnt,
@@ -737,6 +742,16 @@ __device__ __forceinline__ float rt_dot(float acc, const float4 (&r)[RT_U], cons
   }
   return acc;
 }
+// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
+// error carried into a first-order correction; ~1 ulp, no range handling needed
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147180559945f, e);
+}
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const long long x = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)x, l);
@@ -753,7 +768,7 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
 // kernel is latency-bound and single-wave workgroups spread over more CUs and never wait
 // for a sibling wave at the two barriers.
 template <int NPL, int WPG>  // nodes per lane: 1 (N <= 64) or 2 (N <= 128); node = lane + 64*i
-__global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_kernel(StepParams p) {
+__global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_step_rt_kernel(StepParams p) {
   constexpr int NMAXL = 64 * NPL;
   __shared__ __attribute__((aligned(16))) float a_s[WPG][8 * NMAXL];  // a[h][n], hn order
   __shared__ __attribute__((aligned(16))) float u_s[WPG][NMAXL];
@@ -842,26 +857,48 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? 3 : 2)) void decode_step_rt_k
   rt_load(ra, rtb + (size_t)(m_a < 0 ? 0 : m_a) * n4, 0, cnt, m_a >= 0);
 
   // ---- glimpse attention weights (lane = n) -----------------------------------------
+  // softmax_n(s_h) is invariant to the shift, so ONE wave-wide maximum over all eight
+  // heads replaces eight per-head ones (exp arguments stay <= 0); exp is a compensated
+  // exp2 and the normalisation a multiplication by a Newton-refined reciprocal.  This
+  // phase is VALU-bound (every wave of the chip runs it at the same time, before any
+  // row of the logit table can be consumed): ~23 instead of ~92 instructions per head.
+  // Should a head lie so far below the global maximum that its sum underflows, the wave
+  // redoes that head with its own maximum.
   {
     const float loadf = (float)load0;
+    float s[NPL][8], mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float v = sc[i][h];
+        if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sld[i][h], v);
+        v = inN[i] ? v + (float)msk[i][h] : -INFINITY;
+        s[i][h] = v;
+        mx = fmaxf(mx, v);
+      }
+    const float M = wave_max(mx);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      float s[NPL], mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        s[i] = sc[i][h];
-        if (p.kind == VRP_KIND_IRP) s[i] = fmaf(loadf, sld[i][h], s[i]);
-        s[i] = inN[i] ? s[i] + (float)msk[i][h] : -INFINITY;
-        mx = fmaxf(mx, s[i]);
-      }
-      const float m = wave_max(mx);
       float e[NPL], es = 0.f;
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? expf(s[i] - m) : 0.f; es += e[i]; }
-      const float sum = wave_sum(es);
+      for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? exp_nonpos(s[i][h] - M) : 0.f; es += e[i]; }
+      float sum = wave_sum(es);
+      if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+        float hm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) hm = fmaxf(hm, s[i][h]);
+        hm = wave_max(hm);
+        es = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? exp_nonpos(s[i][h] - hm) : 0.f; es += e[i]; }
+        sum = wave_sum(es);
+      }
+      float r = __builtin_amdgcn_rcpf(sum);
+      r = fmaf(fmaf(-sum, r, 1.f), r, r);
 #pragma unroll
       for (int i = 0; i < NPL; ++i)
-        if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i] / sum;
+        if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i] * r;
     }
   }
   __syncthreads();
