@@ -144,11 +144,14 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
  *        io->actions / io->step_logp / io->logits);
  *        VRP_STEP_TILE_KERNEL = use the raw-embedding-tile kernel instead of the
  *        table-driven one;
- *        VRP_STEP_NO_FIRST_ROW = do not append vrp_decode_first_row to step 0. */
+ *        VRP_STEP_NO_FIRST_ROW = do not append vrp_decode_first_row to step 0;
+ *        VRP_STEP_THROUGHPUT_KERNEL = large-batch variant of the table kernel at any B. */
 #define VRP_STEP_SAMPLE 1
 #define VRP_STEP_DECODE_ONLY 2
 #define VRP_STEP_TILE_KERNEL 4 /* use the raw-embedding-tile kernel (N <= 104) */
 #define VRP_STEP_NO_FIRST_ROW 8 /* t == 0: the caller runs vrp_decode_first_row itself */
+#define VRP_STEP_THROUGHPUT_KERNEL 16 /* B <= 2048: use the large-batch variant (4 graphs per
+                                         workgroup, score row read by pointer chase) anyway */
 int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     const vrp_env *env, const float *emb, void *workspace,
                     const vrp_rollout_io *io, int t, int max_steps, int flags,
@@ -165,7 +168,8 @@ int vrp_decode_first_row(int kind, const void *derived, int B, int N, const floa
  * graph_vrp_agent.py:52-83, graph_irp_agent.py:54-105): mask init, features,
  * encoder, prologue and max_steps decode+env steps, all on `stream`.
  * emb (B,N,128) receives the node embeddings.  max_steps >= 2(N-1) (N-1 for TSP).
- * `sample` carries the step flags VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL. */
+ * `sample` carries the step flags VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL |
+ * VRP_STEP_THROUGHPUT_KERNEL. */
 int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
                 void *derived, const vrp_env *env, int train, int sample,
                 float *emb, void *enc_workspace, void *dec_workspace,

@@ -239,7 +239,8 @@ def test_decoder_teacher_forced(name, path):
 
 # ------------------------------------------------------------------ R1: rollouts
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
-                     ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False):
+                     ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
+                     throughput_kernel=False):
     """HIP rollout vs oracle (and vs reference outputs when given)."""
     from oracle import envs as oenv
     from oracle import policy as opol
@@ -258,7 +259,8 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     torch.manual_seed(torch_seed)
     with torch.no_grad():
         res = runtime.rollout(model, deepcopy(env), greedy, train=train, trace=True,
-                              noise_mode="host", tile_kernel=tile_kernel)
+                              noise_mode="host", tile_kernel=tile_kernel,
+                              throughput_kernel=throughput_kernel)
     T = res.T
     acts = res.actions[:T].cpu().numpy()
 
@@ -320,14 +322,18 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     return res, exempt
 
 
-@pytest.mark.parametrize("tile_kernel", [False, True], ids=["table", "tile"])
+@pytest.mark.parametrize("tile_kernel", [False, True, "wide"], ids=["table", "tile", "table_wide"])
 @pytest.mark.parametrize("name,path", _load("rollout_*.npz"))
 def test_rollout_against_reference(name, path, tile_kernel):
-    """Both step kernels (table-driven, default for N <= 64; raw-tile, default above)."""
+    """All step kernels: table-driven in its latency mode (default up to B = 2048) and in
+    its large-batch mode (forced here), and the raw-tile formulation."""
+    wide = tile_kernel == "wide"
+    tile_kernel = tile_kernel is True
     z = np.load(path)
     _compare_rollout(int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"]), 69, 69,
                      int(z["torch_seed"]), ref_actions=z["actions"], ref_loss=z["acc_loss"],
-                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=tile_kernel)
+                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=tile_kernel,
+                     throughput_kernel=wide)
 
 
 @pytest.mark.parametrize("kind,B,N,greedy,train", [
@@ -342,6 +348,7 @@ def test_rollout_against_reference(name, path, tile_kernel):
 ])
 def test_rollout_against_oracle(kind, B, N, greedy, train):
     _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train)
+    _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, throughput_kernel=True)
     if N <= 104:  # the raw-tile kernel (opt-in flag) stays covered at every size it supports
         _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
 

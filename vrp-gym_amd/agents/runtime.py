@@ -362,13 +362,14 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
 
 
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
-            noise_mode="device", tile_kernel=False, use_graph=None, record=False):
+            noise_mode="device", tile_kernel=False, use_graph=None, record=False,
+            throughput_kernel=False):
     """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU."""
     dev = _require_cuda(model)
     if use_graph is None:
         use_graph = USE_GRAPHS
     if (use_graph and forced is None and noise is None and not trace and not record
-            and (greedy or noise_mode == "device")):
+            and not throughput_kernel and (greedy or noise_mode == "device")):
         if str(env._device) != str(dev):
             raise RuntimeError(f"env is on {env._device} but the model on {dev}")
         env._sync_positions()
@@ -440,7 +441,7 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._sync_positions()
     env._parity = 0
     cenv = env._cenv()
-    flags = int(not greedy) | (4 if tile_kernel else 0)
+    flags = int(not greedy) | (4 if tile_kernel else 0) | (16 if throughput_kernel else 0)
     tape = x3 = dmask = None
     if record and train:
         # the pieces of vrp_rollout with the taped encoder: the backward pass reuses the

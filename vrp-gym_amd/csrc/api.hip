@@ -72,7 +72,8 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
   const uint8_t *dm = (kind == VRP_KIND_TSP) ? nullptr : (kind == VRP_KIND_VRP ? env->mask : isd);
   if (int r = vrp_encoder_forward(ew, train, B, N, x, dm, emb, enc_workspace, stream)) return r;
   if (int r = vrp_decode_prologue(kind, derived, B, N, emb, dec_workspace, stream)) return r;
-  // `sample` doubles as the step flags (bit 0 = VRP_STEP_SAMPLE, bit 2 = VRP_STEP_TILE_KERNEL)
+  // `sample` doubles as the step flags
   return vrp_rollout_steps(kind, derived, dw, env, emb, dec_workspace, io, max_steps,
-                           sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL), stream);
+                           sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL | VRP_STEP_THROUGHPUT_KERNEL),
+                           stream);
 }

@@ -163,7 +163,7 @@ struct DecWs {
   float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
   float *QG;     // (B,384)     Wq_g g + bq
   float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
-  float *SG, *C0, *SLD, *row0;   // (B,8,N) each
+  float *SG, *C0, *SLD, *row0, *curs;  // (B,8,N) each; curs = next step's row (latency mode)
   float *SL;                     // (B,N,8,N)  complete score row of every later step
   float *Efirst, *QF1;           // (B,128) (B,384): first chosen node and its query part
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:] (N <= 64)
@@ -192,6 +192,7 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
   w.C0 = (float *)p;    p += vrp_align_up(hn);
   w.SLD = (float *)p;   p += vrp_align_up(hn);
   w.row0 = (float *)p;  p += vrp_align_up(hn);
+  w.curs = (float *)p;  p += vrp_align_up(hn);
   w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
   w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
@@ -205,7 +206,7 @@ static DecWs carve_decws(int kind, void *ws, int B, int N) {
 extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
   return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
-                   vrp_align_up(R * proj_width(kind, N) * 4) + 4 * vrp_align_up(hn) +
+                   vrp_align_up(R * proj_width(kind, N) * 4) + 5 * vrp_align_up(hn) +
                    vrp_align_up(tb) + vrp_align_up((size_t)B * 128 * 4) +
                    vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(rtable_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
@@ -268,8 +269,9 @@ template <int NTMAX, int PHASE>  // 16-column tiles per row: ceil(N/16) <= NTMAX
 __global__ __launch_bounds__(256) void pair_tables_kernel(
     int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
     const float *__restrict__ qc0, const float *__restrict__ wload, const float *__restrict__ QF1,
-    float *__restrict__ SG, float *__restrict__ C0, float *__restrict__ SLD,
-    float *__restrict__ SL, float *__restrict__ row0, float *__restrict__ RT) {
+    const int32_t *__restrict__ first, float *__restrict__ SG, float *__restrict__ C0,
+    float *__restrict__ SLD, float *__restrict__ SL, float *__restrict__ row0,
+    float *__restrict__ curs, float *__restrict__ RT) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x;
   const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -342,6 +344,8 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
     }
   }
   if (PHASE == 1 || kind == VRP_KIND_IRP) {
+    // PHASE 1 also hands step 1 its row (last = first) for the latency-mode step kernel
+    const int fb = (PHASE == 1) ? first[b] : -1;
     for (int mt = 0; mt < NT; ++mt) {
       const int m = mt * 16 + i16;
       const float *rp = rows + (size_t)(m < N ? m : 0) * P;
@@ -349,7 +353,11 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
       load_rows12<NTMAX>(af, rp + qloff + hq, m < N);
       tile_rows(af, [&](int r, int nt, int n, float v) {
         const int mm = mt * 16 + r;
-        if (mm < N && n < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = fmaf(v, c, base[nt]);
+        if (mm < N && n < N) {
+          const float val = fmaf(v, c, base[nt]);
+          SL[(((size_t)b * N + mm) * 8 + h) * N + n] = val;
+          if (mm == fb) curs[hn + n] = val;
+        }
       });
     }
   }
@@ -369,18 +377,18 @@ __global__ __launch_bounds__(256) void pair_tables_kernel(
 
 template <int PHASE>
 static int launch_pair_tables(int kind, int B, int N, int P, const float *PROJ, const float *QG,
-                              const float *qc0, const float *wload, const float *QF1, float *SG,
-                              float *C0, float *SLD, float *SL, float *row0, float *RT,
-                              hipStream_t st) {
+                              const float *qc0, const float *wload, const float *QF1,
+                              const int32_t *first, float *SG, float *C0, float *SLD, float *SL,
+                              float *row0, float *curs, float *RT, hipStream_t st) {
   if (N <= 32)
     hipLaunchKernelGGL((pair_tables_kernel<2, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
   else if (N <= 64)
     hipLaunchKernelGGL((pair_tables_kernel<4, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
   else
     hipLaunchKernelGGL((pair_tables_kernel<8, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, SG, C0, SLD, SL, row0, RT);
+                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
   VRP_CHECK_LAUNCH("pair_tables");
   return 0;
 }
@@ -400,8 +408,8 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
                                  128, 0, st)) return r;
   VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
-  if (int r = launch_pair_tables<0>(kind, B, N, P, w.PROJ, w.QG, d.qc0, d.wload, nullptr, w.SG, w.C0,
-                                    w.SLD, w.SL, w.row0, w.RT, st)) return r;
+  if (int r = launch_pair_tables<0>(kind, B, N, P, w.PROJ, w.QG, d.qc0, d.wload, nullptr, nullptr,
+                                    w.SG, w.C0, w.SLD, w.SL, w.row0, w.curs, w.RT, st)) return r;
   hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
                      w.cvec);
   VRP_CHECK_LAUNCH("cvec");
@@ -434,6 +442,7 @@ struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only, fence;
   const float *emb;
   const float *row0, *SLD, *SL;
+  float *curs;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
   const float *RT, *cvec;
@@ -715,7 +724,10 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 // (k = 8*pass + r) is found by ballot/prefix; the 8 parts split its row of 2N float4;
 // every wave-level load is 8 x 128 contiguous bytes.
 #ifndef RT_U
-#define RT_U 8  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
+#define RT_U 5  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
+#endif
+#ifndef RT_NB
+#define RT_NB 3  // work items in flight per wave, large-batch mode (114 VGPRs: four waves per SIMD)
 #endif
 #ifndef RT_MINW
 #define RT_MINW 3
@@ -789,16 +801,23 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
 
-  if (p.fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (p.fence & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
   // ---- entry: issue every action-independent load --------------------------------
   const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
   const size_t row = (size_t)b * 8 * N;
   // this step's complete glimpse score row: row0 at t = 0, else table row SL[b][last]
   // (one dependent load: last[b] was written by the previous launch)
+  // WPG == 1 is the latency mode of small batches: there the previous launch already copied
+  // its table row into `curs`, so no launch starts with a pointer chase.
   const float *srow = p.row0 + row;
   if (p.t > 0) {
-    const int last = __builtin_amdgcn_readfirstlane(p.last[b]);
-    srow = p.SL + ((size_t)b * N + last) * 8 * N;
+    if (WPG == 1) {
+      srow = p.curs + row;
+    } else {
+      const int last = __builtin_amdgcn_readfirstlane(p.last[b]);
+      srow = p.SL + ((size_t)b * N + last) * 8 * N;
+    }
   }
   int own_mask[NPL];
   float sc[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
@@ -846,15 +865,32 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
   const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
-  float4 ra[RT_U], rb[RT_U];
+  // measured (tools/step_probe.py): three items in flight are best at 8192 graphs, two in
+  // the latency mode (512..2048 graphs)
+  constexpr int NB = (WPG == 1) ? 2 : RT_NB;
+  float4 rbuf[NB][RT_U];
+  int mrow[NB];
   int m_first = -1;  // pass 0 rows (k = rsl < 8)
   if (rsl < nsel) {
     const int c0 = __popcll(sel[0]);
     m_first = (NPL == 1 || rsl < c0) ? kth_set_bit(sel[0], rsl)
                                      : 64 + kth_set_bit(sel[NPL - 1], rsl - c0);
   }
-  int m_a = m_first, m_b = -1;
-  rt_load(ra, rtb + (size_t)(m_a < 0 ? 0 : m_a) * n4, 0, cnt, m_a >= 0);
+  // the first NB work items (up to 12 selectable rows at N = 40) are in flight while the wave
+  // computes the glimpse softmax below: a wave's life is a chain of memory round trips,
+  // and the kernel's duration is that chain times the number of wave rounds per SIMD
+  auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
+    const int pass = w / nchunk, ch = w - pass * nchunk;
+    const int k = 8 * pass + rsl;
+    const int m = (pass == 0) ? m_first : (k < nsel ? sel_s[wave][k] : -1);
+    m_out = m;
+    rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
+  };
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    mrow[j] = -1;
+    if (j < total) load_item(rbuf[j], j, mrow[j]);
+  }
 
   // ---- glimpse attention weights (lane = n) -----------------------------------------
   // softmax_n(s_h) is invariant to the shift, so ONE wave-wide maximum over all eight
@@ -907,13 +943,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   {
     const float4 *aw = reinterpret_cast<const float4 *>(a_s[wave]) + part;
     float acc = 0.f;
-    auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
-      const int pass = w / nchunk, ch = w - pass * nchunk;
-      const int k = 8 * pass + rsl;
-      const int m = (pass == 0) ? m_first : (k < nsel ? sel_s[wave][k] : -1);
-      m_out = m;
-      rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
-    };
     auto consume = [&](const float4 (&r)[RT_U], int w, int m) {
       const int ch = w % nchunk;
       acc = rt_dot(acc, r, aw, ch * RT_U, m >= 0 ? cnt : 0);
@@ -923,11 +952,14 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
         acc = 0.f;
       }
     };
-    for (int w = 0; w < total; w += 2) {
-      if (w + 1 < total) load_item(rb, w + 1, m_b);
-      consume(ra, w, m_a);
-      if (w + 2 < total) load_item(ra, w + 2, m_a);
-      if (w + 1 < total) consume(rb, w + 1, m_b);
+    for (int w = 0; w < total; w += NB) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (w + j < total) {
+          consume(rbuf[j], w + j, mrow[j]);
+          if (w + j + NB < total) load_item(rbuf[j], w + j + NB, mrow[j]);
+        }
+      }
     }
   }
   __syncthreads();
@@ -998,6 +1030,22 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   idx = __builtin_amdgcn_readfirstlane(idx);
   if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
 
+  // latency mode: next step's score row = SL[b][idx], copied while the env step runs (after
+  // step 0 of TSP/VRP the table does not exist yet: its builder writes the row itself)
+  if (WPG == 1 && !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
+    const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;
+    float sl[NPL][8];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) sl[i][h] = arow[h * N + ln[i]];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h)
+        if (inN[i]) p.curs[row + h * N + lane + 64 * i] = sl[i][h];
+  }
+
   if (p.decode_only) {
     if (lane == 0) {
       p.last[b] = idx;
@@ -1063,7 +1111,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
     if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
   }
-  if (p.fence) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (p.fence & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 template <int NMAX>
@@ -1115,7 +1163,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   p.decode_only = decode_only;
   { static const char *e = getenv("VRP_FENCE"); p.fence = e ? atoi(e) : 0; }
   p.emb = emb;
-  p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL;
+  p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
   p.RT = ws.RT; p.cvec = ws.cvec;
@@ -1141,14 +1189,14 @@ extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N,
   VRP_CHECK_LAUNCH("gather_first");
   if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
                                  384, 128, 0, st)) return r;
-  return launch_pair_tables<1>(kind, B, N, P, ws.PROJ, ws.QG, d.qc0, d.wload, ws.QF1, ws.SG, ws.C0,
-                               ws.SLD, ws.SL, ws.row0, ws.RT, st);
+  return launch_pair_tables<1>(kind, B, N, P, ws.PROJ, ws.QG, d.qc0, d.wload, ws.QF1, ws.first, ws.SG,
+                               ws.C0, ws.SLD, ws.SL, ws.row0, ws.curs, ws.RT, st);
 }
 
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
   const int B = p.B, N = p.N;
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
-    const bool small = B <= 2048;
+    const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
     if (N <= 64 && small)
       hipLaunchKernelGGL((decode_step_rt_kernel<1, 1>), dim3(B), dim3(64), 0, st, p);
     else if (N <= 64)
