@@ -12,7 +12,8 @@ rank runs its own 512-graph batch; the value is the whole-job aggregate.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline            decode_step kernel of the benched workload vs HBM peak
-  roofline_north_star the same kernel at 8192 x 40 (the north-star target shape)
+  roofline_north_star the same kernel at 8192 x 40 (the north-star target shape), TSP;
+                      roofline_north_star_vrp: VRP at the same shape
   cpu_baseline        the CPU oracle (oracle/, a port of the reference) on this host
 """
 import argparse
@@ -258,6 +259,7 @@ def main():
         out["roofline"] = step_kernel_roofline(kind, N, B, greedy, device)
         if not a.no_north_star and world == 1 and a.workload != "tsp40_b8192":
             out["roofline_north_star"] = step_kernel_roofline(0, 40, 8192, True, device)
+            out["roofline_north_star_vrp"] = step_kernel_roofline(1, 40, 8192, True, device)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, N, B, greedy)
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
