@@ -229,3 +229,42 @@ def test_decoder_backward_against_oracle_autograd(kind, B, N):
     assert checked == 10
     report.sort(reverse=True)
     assert report[0][0] < 1.0, report[:5]
+
+
+def test_backward_full_size_properties():
+    """BASELINE config 3 shape (VRP N=40, B=2048, sampled): the oracle cannot run this in
+    seconds, so the HIP backward is checked through size-independent properties --
+    bitwise reproducibility (no float atomics anywhere) and linearity in d_logp."""
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import VRPEnv
+    agent = agents.VRPAgent(seed=69)
+    model = agent.model
+    model.train()
+    env = VRPEnv(40, 2048, 1, 69)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        res = runtime.rollout(model, env, greedy=False, train=True, record=True)
+    T = res.T
+    assert 40 <= T <= 78
+    g = torch.Generator().manual_seed(7)
+    w1 = torch.randn(2048, generator=g).cuda()
+    w2 = torch.randn(2048, generator=g).cuda()
+
+    def grads(w):
+        _, dg, d_emb, lp = runtime.decoder_backward(model.decoder, 1, res.emb, res.actions[:T],
+                                                    res.mask_trace[:T], None, w, T, want_logp=True)
+        _, eg = runtime.encoder_backward(model.encoder, res.x3, res.depot_mask, res.tape, d_emb)
+        return [t for t in dg + eg if t is not None] + [d_emb], lp
+
+    ga, lp = grads(w1)
+    ga2, _ = grads(w1)
+    for x, y in zip(ga, ga2):
+        assert torch.equal(x, y)
+    # the re-run of the episode reproduces the rollout's accumulated log-probability
+    assert (lp.sum(0) - res.acc_logp).abs().max().item() < 2e-4
+    gb, _ = grads(w2)
+    gs, _ = grads(w1 + w2)
+    for x, y, z in zip(ga, gb, gs):
+        scale = max(1.0, z.abs().max().item())
+        assert (x + y - z).abs().max().item() < 2e-4 * scale
