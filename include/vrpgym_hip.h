@@ -188,6 +188,14 @@ int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *
 int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
                             double *pos_out_host, int64_t *depots_host, double *demands_host);
 
+/* E1' Device-side instance sampler for throughput runs: the
+ * reference's distributions (vrp_graph.py:28-43) from a counter-based Philox4x32-10
+ * stream -- NOT the reference's numpy stream, so no instance-level parity.  Counter =
+ * (first_graph + b, node, episode, draw): a rank's shard equals the same rows of the
+ * unsharded batch.  pos (B,N,2) f64, depot (B) i32, demand (B,N) f64 (depot's = 0). */
+int vrp_draw_instances_device(uint64_t seed, uint64_t episode, int first_graph, int B, int N,
+                              double *pos, int32_t *depot, double *demand, void *stream);
+
 /* ---- backward pass (K4): building blocks, each unit-tested against torch autograd ---- */
 /* C (N1,N2) (+)= X^T Y over R rows; deterministic split-K; slab_ws from *_workspace_bytes. */
 int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);

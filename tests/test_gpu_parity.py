@@ -550,3 +550,50 @@ def test_train_loop_csv_and_checkpoints(tmp_path):
     fresh.model.load_state_dict(sd)
     loss = fresh.evaluate(VRPEnv(num_nodes=10, batch_size=8, seed=1))
     assert loss.shape == (8,) and torch.isfinite(loss).all()
+
+
+def test_device_instance_generator():
+    """generator="device" (SURVEY 8f rank 4): the reference's distributions from a Philox
+    stream on the GPU -- deterministic in (seed, episode), shard-consistent, fresh on every
+    reset, lazily visible through the host-side views, and playable."""
+    import agents
+    from gym_vrp.envs import IRPEnv, TSPEnv
+    B, N = 4096, 40
+    e1 = IRPEnv(N, B, 1, 123, generator="device")
+    e2 = IRPEnv(N, B, 1, 123, generator="device")
+    assert torch.equal(e1._pos, e2._pos) and torch.equal(e1._depot, e2._depot)
+    assert torch.equal(e1._demand, e2._demand)
+    e3 = IRPEnv(N, B, 1, 124, generator="device")
+    assert not torch.equal(e1._pos, e3._pos)
+    pos, dep, dem = e1._pos.cpu().numpy(), e1._depot.cpu().numpy(), e1._demand.cpu().numpy()
+    assert pos.min() >= 0.0 and pos.max() < 1.0
+    assert abs(pos.mean() - 0.5) < 5e-3 and abs(pos.var() - 1 / 12) < 2e-3
+    assert dep.min() >= 0 and dep.max() == N - 1
+    counts = np.bincount(dep, minlength=N)
+    assert counts.min() > 0.5 * B / N and counts.max() < 1.6 * B / N
+    scale = 0.2449 * N + 26.12
+    assert (dem[np.arange(B), dep] == 0).all()
+    others = dem[dem > 0]
+    assert others.size == B * (N - 1)
+    assert others.min() >= 1 / scale and others.max() < 10 / scale
+    assert abs(others.mean() * scale - 5.5) < 0.05
+    # all coordinates distinct draws (no counter reuse between x, y, demand, graphs)
+    assert np.unique(pos.round(12)).size > 0.999 * pos.size
+    # shards reproduce the rows of the unsharded batch
+    half = IRPEnv(N, B, 1, 123, generator="device", shard=(1, 2))
+    assert torch.equal(half._pos, e1._pos[B // 2:]) and torch.equal(half._depot, e1._depot[B // 2:])
+    # reset draws new instances; host-side views follow lazily
+    before = e1._pos.clone()
+    e1.reset()
+    assert not torch.equal(before, e1._pos)
+    assert np.array_equal(e1.depots[:, 0], e1._depot.cpu().numpy())
+    assert np.allclose(e1.sampler.get_graph_positions(), e1._pos.cpu().numpy())
+    assert np.array_equal(e1.demands[:, :, 0], e1._demand.cpu().numpy())
+    st, load = e1.get_state()
+    assert st.shape == (B, N, 5) and load.shape == (B,)
+    # and a rollout runs on them
+    agent = agents.IRPAgent(seed=69)
+    loss = agent.evaluate(e1)
+    assert torch.isfinite(loss).all() and (loss < 0).all()
+    t = TSPEnv(20, 64, 1, 5, generator="device")
+    assert torch.isfinite(agents.TSPAgent(seed=69).evaluate(t)).all()

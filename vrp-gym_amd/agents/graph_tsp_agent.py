@@ -128,8 +128,12 @@ class TSPAgent:
     def step(self, env, rollouts: Tuple[bool, bool]):
         """Reset, play model and baseline on identical instances
         (graph_tsp_agent.py:227-255).  QUIRK kept: the baseline also uses rollouts[0]."""
-        env.reset()
-        env_baseline = env.twin() if hasattr(env, "twin") else deepcopy(env)
+        if hasattr(env, "twin"):     # device-resident env: no host-side state needed
+            env.reset(return_state=False)
+            env_baseline = env.twin()
+        else:
+            env.reset()
+            env_baseline = deepcopy(env)
         loss, log_prob = self.model(env, rollouts[0])
         with torch.no_grad():
             loss_b, _ = self.target_model(env_baseline, rollouts[0])

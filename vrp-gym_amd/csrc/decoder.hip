@@ -439,7 +439,7 @@ __global__ __launch_bounds__(128) void gather_first_kernel(const float *__restri
 
 // ------------------------------------------------------------------ the step kernel
 struct StepParams {
-  int kind, B, N, t, max_steps, sample, decode_only, fence;
+  int kind, B, N, t, max_steps, sample, decode_only;
   const float *emb;
   const float *row0, *SLD, *SL;
   float *curs;
@@ -801,7 +801,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
 
-  if (p.fence & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
   // ---- entry: issue every action-independent load --------------------------------
   const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
@@ -1111,7 +1110,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
     if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
   }
-  if (p.fence & 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 template <int NMAX>
@@ -1161,7 +1159,6 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   StepParams p;
   p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps; p.sample = sample;
   p.decode_only = decode_only;
-  { static const char *e = getenv("VRP_FENCE"); p.fence = e ? atoi(e) : 0; }
   p.emb = emb;
   p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
   p.last = ws.last; p.first = ws.first;

@@ -12,20 +12,30 @@ class IRPEnv(TSPEnv):
     _PLOT_DEMAND = True
 
     def __init__(self, num_nodes: int = 32, batch_size: int = 128, num_draw: int = 6,
-                 seed: int = 69, device=None, shard=None):
+                 seed: int = 69, device=None, shard=None, generator: str = "numpy"):
         super().__init__(num_nodes=num_nodes, batch_size=batch_size, num_draw=num_draw,
-                         seed=seed, device=device, shard=shard)
+                         seed=seed, device=device, shard=shard, generator=generator)
 
     def generate_graphs(self):
         """irp.py:157-174."""
         super().generate_graphs()
-        self.demands = self.sampler.get_demands()
+        self._demands_host = None if self._generator == "device" else self.sampler.get_demands()
 
-    def reset(self):
+    @property
+    def demands(self):
+        if self._demands_host is None:
+            self._demands_host = self.sampler.get_demands()
+        return self._demands_host
+
+    @demands.setter
+    def demands(self, value):
+        self._demands_host = value
+
+    def reset(self, return_state: bool = True):
         """irp.py:176-185: load := 1 after the new instances are in place."""
         self.step_count = 0
         self.generate_graphs()
-        return self.get_state()
+        return self.get_state() if return_state else None
 
     @property
     def load(self):

@@ -24,11 +24,19 @@ class TSPEnv(GymEnv):
     _PLOT_DEMAND = False
 
     def __init__(self, num_nodes: int = 20, batch_size: int = 128, num_draw: int = 6,
-                 seed: int = 69, device=None, shard=None):
+                 seed: int = 69, device=None, shard=None, generator: str = "numpy"):
         """Same arguments as the reference (tsp.py:27-58).  Extra, optional:
         device — torch device of the state (default: current CUDA device);
         shard  — (rank, world_size): keep only this rank's slice of the
-                 seed-ordered instance stream."""
+                 seed-ordered instance stream (SURVEY.md 8e);
+        generator — "numpy": the reference's instances, bit for bit (global legacy numpy
+                 stream, replayed natively on the host); "device": the same distributions
+                 drawn on the GPU by a counter-based Philox stream (throughput runs at
+                 large batch: no host work, no upload, but NOT the reference's instances)."""
+        assert generator in ("numpy", "device"), generator
+        self._generator = generator
+        self._seed = int(seed)
+        self._episode = 0
         assert (
             num_draw <= batch_size
         ), "Num_draw needs to be equal or lower than the number of generated graphs."
@@ -105,13 +113,16 @@ class TSPEnv(GymEnv):
     def generate_graphs(self):
         """tsp.py:162-174: new instances from the global numpy stream, visited := 0,
         current_location := depots."""
-        pos, depots, demands = draw_instances(self._global_batch, self.num_nodes, 1)
-        s = self._slice
-        self.sampler = VRPNetwork(self.batch_size, self.num_nodes, 1,
-                                  plot_demand=self._PLOT_DEMAND,
-                                  _arrays=(pos[s], depots[s], demands[s]))
-        self.depots = self.sampler.get_depots()
-        self._upload_instances()
+        if self._generator == "device":
+            self._draw_on_device()
+        else:
+            pos, depots, demands = draw_instances(self._global_batch, self.num_nodes, 1)
+            s = self._slice
+            self.sampler = VRPNetwork(self.batch_size, self.num_nodes, 1,
+                                      plot_demand=self._PLOT_DEMAND,
+                                      _arrays=(pos[s], depots[s], demands[s]))
+            self._depots_host = self.sampler.get_depots()
+            self._upload_instances()
         self._visited.zero_()
         self._mask.zero_()
         self._cur.copy_(self._depot)
@@ -119,11 +130,41 @@ class TSPEnv(GymEnv):
         self._parity = 0
         self._mask_fresh = False
 
-    def reset(self) -> Union[ObsType, Tuple[ObsType, dict]]:
-        """tsp.py:150-160 (no reseed)."""
+    def _draw_on_device(self):
+        """vrp_draw_instances_device straight into the state tensors; the host-side views
+        (sampler.graphs, depots, demands) are fetched only if somebody reads them."""
+        from vrpgym_hip import check
+        check(self._lib.vrp_draw_instances_device(
+            self._seed, self._episode, self._slice.start, self.batch_size, self.num_nodes,
+            self._pos.data_ptr(), self._depot.data_ptr(), self._demand.data_ptr(),
+            self._stream()))
+        self._episode += 1
+        pos_t, dep_t, dem_t = self._pos, self._depot, self._demand
+
+        def fetch():
+            return (pos_t.cpu().numpy(), dep_t.cpu().numpy().astype(np.int64)[:, None],
+                    dem_t.cpu().numpy()[:, :, None])
+
+        self.sampler = VRPNetwork(self.batch_size, self.num_nodes, 1,
+                                  plot_demand=self._PLOT_DEMAND, _arrays=fetch)
+        self._depots_host = None
+
+    @property
+    def depots(self):
+        if self._depots_host is None:
+            self._depots_host = self.sampler.get_depots()
+        return self._depots_host
+
+    @depots.setter
+    def depots(self, value):
+        self._depots_host = value
+
+    def reset(self, return_state: bool = True) -> Union[ObsType, Tuple[ObsType, dict]]:
+        """tsp.py:150-160 (no reseed).  return_state=False skips building the host-side
+        state array (the device-resident agents never read it)."""
         self.step_count = 0
         self.generate_graphs()
-        return self.get_state()
+        return self.get_state() if return_state else None
 
     @property
     def step_count(self):
@@ -245,7 +286,7 @@ class TSPEnv(GymEnv):
             if isinstance(v, t.Tensor):
                 tw.__dict__[k].copy_(v)
             elif k not in ("_lib", "_torch", "vid"):
-                tw.__dict__[k] = v if k in ("sampler", "depots", "demands", "draw_idxs") \
+                tw.__dict__[k] = v if k in ("sampler", "_depots_host", "_demands_host", "draw_idxs") \
                     else copy.copy(v)
         return tw
 

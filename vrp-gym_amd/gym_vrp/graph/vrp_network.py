@@ -17,10 +17,30 @@ class VRPNetwork:
         self.plot_demand = plot_demand
         if _arrays is None:
             _arrays = draw_instances(num_graphs, num_nodes, num_depots)
-        self._pos, self._depots, self._demands = _arrays
+        # a callable defers the host copies until somebody looks (instances drawn on the GPU)
+        self._fetch = _arrays if callable(_arrays) else None
+        self._host = None if callable(_arrays) else tuple(_arrays)
         self._graphs = None
         self._dirty = False  # set when a caller rewrites coordinates through a view
         self._on_change = None
+
+    def _arrays(self):
+        if self._host is None:
+            self._host = tuple(self._fetch())
+            self._fetch = None
+        return self._host
+
+    @property
+    def _pos(self):
+        return self._arrays()[0]
+
+    @property
+    def _depots(self):
+        return self._arrays()[1]
+
+    @property
+    def _demands(self):
+        return self._arrays()[2]
 
     @property
     def graphs(self):
