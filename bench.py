@@ -221,13 +221,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    # test aid (one-GPU boxes): VRPGYM_BENCH_ONE_GPU=1 maps every rank to cuda:0 and the
+    # rendezvous/timing collectives run over gloo; the driver's real runs never set it
+    one_gpu = os.environ.get("VRPGYM_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
     kind, N, B, greedy = WORKLOADS[a.workload]
     env, agent = make(kind, N, B, 69 + rank, device)  # each rank its own instance stream
