@@ -102,7 +102,7 @@ def timed_rollouts(env, agent, greedy, steps, warmup, dist):
     return dt, res.T, float(-res.acc_loss.mean().item())
 
 
-def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
+def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0):
     """Average duration of ONE decode_step launch, HIP events on the launch stream
     around every launch (the stream the library launches on is torch's current one)."""
     import ctypes as C
@@ -140,7 +140,7 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
             evs[t][0].record()
             hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
                                           res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
-                                          max_steps, (0 if greedy else 1) | 8, stream))
+                                          max_steps, (0 if greedy else 1) | 8 | extra_flags, stream))
             evs[t][1].record()
             if t == 0:  # the once-per-episode first-node fold: other kernels, outside the pair
                 hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N,
@@ -162,7 +162,7 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5):
         e0.record()
         hip.check(lib.vrp_rollout_steps(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
                                         res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io),
-                                        T, 0 if greedy else 1, stream))
+                                        T, (0 if greedy else 1) | extra_flags, stream))
         e1.record()
         torch.cuda.synchronize()
         loops.append(e0.elapsed_time(e1) * 1e-3 / T)

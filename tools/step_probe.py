@@ -16,6 +16,8 @@ shapes = [(0, 20, 512), (0, 20, 2048), (0, 20, 8192), (0, 40, 2048), (0, 40, 819
 if len(sys.argv) > 1:
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 dev = torch.device("cuda", 0)
-for kind, N, B in shapes:
-    r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3)
+for shp in shapes:
+    kind, N, B = shp[:3]
+    extra = 16 if len(shp) > 3 and shp[3] else 0   # 4th field 1 = VRP_STEP_THROUGHPUT_KERNEL
+    r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3, extra_flags=extra)
     print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "event_pair_per_launch_us", "c_loop_per_launch_us", "achieved", "frac")}))

@@ -212,27 +212,26 @@ extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
                    vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
 }
 
-// graph embedding = mean over nodes (sum, then divide)   graph_decoder.py:75-77
-__global__ __launch_bounds__(128) void graph_mean_kernel(const float *__restrict__ emb, int N,
-                                                         float *__restrict__ g) {
-  const int b = blockIdx.x, c = threadIdx.x;
-  const float *e = emb + (size_t)b * N * VRP_EMB + c;
-  float s = 0.f;
-  for (int n = 0; n < N; ++n) s += e[(size_t)n * VRP_EMB];
-  g[(size_t)b * VRP_EMB + c] = s / (float)N;
-}
-
-// cvec[b][m] = e_m . mb   (one wave per node row)
-__global__ __launch_bounds__(256) void cvec_kernel(const float *__restrict__ emb,
-                                                   const float *__restrict__ mb, int rows,
-                                                   float *__restrict__ cvec) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const float2 e = reinterpret_cast<const float2 *>(emb + (size_t)r * VRP_EMB)[lane];
+// graph embedding = mean over nodes (sum, then divide; graph_decoder.py:75-77) and
+// cvec[b][m] = e_m . mb in one launch: one workgroup per graph, threads 0..127 own an
+// embedding column of the mean, each wave owns every fourth node row of cvec.
+__global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__restrict__ emb,
+                                                              const float *__restrict__ mb, int N,
+                                                              float *__restrict__ g,
+                                                              float *__restrict__ cvec) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *eb = emb + (size_t)b * N * VRP_EMB;
+  if (tid < VRP_EMB) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += eb[(size_t)n * VRP_EMB + tid];
+    g[(size_t)b * VRP_EMB + tid] = s / (float)N;
+  }
   const float2 m = reinterpret_cast<const float2 *>(mb)[lane];
-  const float s = wave_sum(fmaf(e.x, m.x, e.y * m.y));
-  if (lane == 0) cvec[r] = s;
+  for (int n = wave; n < N; n += 4) {
+    const float2 e = reinterpret_cast<const float2 *>(eb + (size_t)n * VRP_EMB)[lane];
+    const float s = wave_sum(fmaf(e.x, m.x, e.y * m.y));
+    if (lane == 0) cvec[(size_t)b * N + n] = s;
+  }
 }
 
 // ------------------------------------------------------------------ tables on the matrix cores
@@ -401,8 +400,8 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs w = carve_decws(kind, workspace, B, N);
   const int P = proj_width(kind, N);
-  hipLaunchKernelGGL(graph_mean_kernel, dim3(B), dim3(128), 0, st, emb, N, w.g);
-  VRP_CHECK_LAUNCH("graph_mean");
+  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec);
+  VRP_CHECK_LAUNCH("graph_mean_cvec");
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
                                  st)) return r;
   if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
@@ -410,9 +409,6 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
   if (int r = launch_pair_tables<0>(kind, B, N, P, w.PROJ, w.QG, d.qc0, d.wload, nullptr, nullptr,
                                     w.SG, w.C0, w.SLD, w.SL, w.row0, w.curs, w.RT, st)) return r;
-  hipLaunchKernelGGL(cvec_kernel, dim3((B * N + 3) / 4), dim3(256), 0, st, emb, d.mb, B * N,
-                     w.cvec);
-  VRP_CHECK_LAUNCH("cvec");
   return 0;
 }
 

@@ -4,7 +4,7 @@
 // Dense projections run on the matrix cores (gemm.hip); the per-graph N x N
 // attention, the batch statistics and the normalisation are small HBM-bound kernels.
 #include <stdlib.h>
-#include "common.h"
+#include "env_device.h"
 
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *R, int ldr, float *C, int ldc, int M, int N, int K,
@@ -382,20 +382,119 @@ static int batchnorm_train(float *x, int rows, const float *w, const float *b, f
   return 0;
 }
 
-extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int B, int N,
-                                   const float *x, const uint8_t *depot_mask, float *emb,
-                                   void *workspace, void *stream) {
-  VRP_REQUIRE(w && x && emb && workspace, "encoder: NULL argument");
+// Rollout set-up in ONE launch (vrp_rollout only): generate_mask on the fresh episode
+// (tsp.py:106-148 via get_state), the network inputs of E3, the node/depot embedding
+// (graph_encoder.py:54,110-132), the eval-mode BatchNorm affines and the zeroed episode
+// accumulators -- five tiny kernels otherwise, each ~5 us of dependent-launch latency.
+// One wave per graph; lane = node for the env part, lane = embedding column (x2) after.
+__global__ __launch_bounds__(256) void rollout_setup_kernel(
+    vrp_env e, vrp_encoder_weights w, int want_norms, float *__restrict__ out,
+    float *__restrict__ norms, float *__restrict__ acc_loss, float *__restrict__ acc_logp,
+    int32_t *__restrict__ notdone, int nflags, int env_blocks) {
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x >= env_blocks) {  // eval-mode BN affines, one block per (layer, bn)
+    if (!want_norms || threadIdx.x >= 128) return;
+    const int blk = blockIdx.x - env_blocks, c = threadIdx.x, l = blk >> 1, second = blk & 1;
+    const vrp_encoder_layer &L = w.layer[l];
+    const float *rm = second ? L.bn2_running_mean : L.bn1_running_mean;
+    const float *rv = second ? L.bn2_running_var : L.bn1_running_var;
+    const float *wt = second ? L.bn2_weight : L.bn1_weight;
+    const float *bs = second ? L.bn2_bias : L.bn1_bias;
+    float *o = norms + (size_t)blk * 384;
+    o[c] = rm[c];
+    o[128 + c] = wt[c] / sqrtf(rv[c] + 1e-5f);
+    o[256 + c] = bs[c];
+    return;
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < nflags) notdone[threadIdx.x] = 0;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= e.B) return;
+  const int N = e.N;
+  if (lane == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
+  // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
+  const uint8_t *vis = e.visited + (size_t)b * N;
+  int v0 = (lane < N) ? vis[lane] : 1;
+  int v1 = (lane + 64 < N) ? vis[lane + 64] : 1;
+  const double load = (e.kind == VRP_KIND_IRP) ? e.load[b] : 1.0;
+  const int dep = e.depot[b];
+  env_fixups_and_mask(e, b, lane, e.cur[b] == dep, v0, v1, load, e.mask);
+  // depot flag per node: VRP = the mask column just written (QUIRK graph_vrp_agent.py:67),
+  // IRP = the is_depot column (graph_irp_agent.py:77-79), TSP = none.  For VRP the mask
+  // equals the visited flags (no capacity overlay).
+  const unsigned long long d0 = __ballot(e.kind == VRP_KIND_VRP ? (lane < N && v0) : lane == dep);
+  const unsigned long long d1 =
+      __ballot(e.kind == VRP_KIND_VRP ? (lane + 64 < N && v1) : lane + 64 == dep);
+  // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
+  float fx[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = lane + 64 * i;
+    const size_t r = (size_t)b * N + (n < N ? n : 0);
+    fx[i][0] = (float)e.pos[2 * r];
+    fx[i][1] = (float)e.pos[2 * r + 1];
+    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
+  }
+  // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
+  float wn[2][3], bnv[2], wd[2][2], bdv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
+    bnv[j] = w.node_embed_bias[c];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
+    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
+  }
+  const bool has_depot = w.depot_embed_weight != nullptr && e.kind != VRP_KIND_TSP;
+  for (int n = 0; n < N; ++n) {
+    const int src = n & 63;
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[0][d]), src));
+      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[1][d]), src));
+      x[d] = n < 64 ? lo : hi;
+    }
+    const bool isdep = has_depot && (((n < 64 ? d0 : d1) >> src) & 1ull);
+    float *orow = out + ((size_t)b * N + n) * VRP_EMB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v;
+      if (isdep) {
+        v = bdv[j];
+        for (int d = 0; d < w.depot_dim; ++d) v = fmaf(x[d], wd[j][d], v);
+      } else {
+        v = bnv[j];
+        for (int d = 0; d < w.node_dim; ++d) v = fmaf(x[d], wn[j][d], v);
+      }
+      orow[lane + 64 * j] = v;
+    }
+  }
+}
+
+static int encoder_check(const vrp_encoder_weights *w, int B, int N) {
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder: bad shape B=%d N=%d", B, N);
   VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8, "encoder: num_layers=%d", w->num_layers);
   VRP_REQUIRE(w->hidden % 128 == 0, "encoder: hidden=%d must be a multiple of 128", w->hidden);
   VRP_REQUIRE(w->node_dim >= 1 && w->node_dim <= 3, "encoder: node_dim=%d", w->node_dim);
+  return 0;
+}
+
+static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N, float *cur,
+                          float *emb, const EncWs &ws, hipStream_t st);
+
+extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int B, int N,
+                                   const float *x, const uint8_t *depot_mask, float *emb,
+                                   void *workspace, void *stream) {
+  VRP_REQUIRE(w && x && emb && workspace, "encoder: NULL argument");
+  if (int r = encoder_check(w, B, N)) return r;
   VRP_REQUIRE(!depot_mask || w->depot_embed_weight, "encoder: depot mask without depot_embed");
   hipStream_t st = (hipStream_t)stream;
   const int R = B * N;
   EncWs ws = carve_encoder(workspace, B, N, w->hidden);
   float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;  // so that the last layer lands in emb
-  float *nxt = nullptr;
   hipLaunchKernelGGL(embed_kernel, dim3((R + 1) / 2), dim3(256), 0, st, x, depot_mask,
                      w->node_embed_weight, w->node_embed_bias, w->node_dim,
                      w->depot_embed_weight, w->depot_embed_bias, w->depot_dim, cur, R);
@@ -405,6 +504,33 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
                        ws.norm);
     VRP_CHECK_LAUNCH("bn_eval_norms");
   }
+  return encoder_layers(w, train, B, N, cur, emb, ws, st);
+}
+
+// vrp_rollout's entry: mask init + features + embedding + BN affines + accumulator reset in
+// one launch (rollout_setup_kernel), then the attention layers.
+int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const vrp_env *env,
+                                 float *emb, void *workspace, float *acc_loss, float *acc_logp,
+                                 int32_t *notdone, int nflags, hipStream_t st) {
+  const int B = env->B, N = env->N;
+  if (int r = encoder_check(w, B, N)) return r;
+  VRP_REQUIRE(env->kind == VRP_KIND_TSP || w->depot_embed_weight,
+              "encoder: VRP/IRP rollout needs depot_embed");
+  VRP_REQUIRE(nflags <= 256, "rollout: more than 255 steps");
+  EncWs ws = carve_encoder(workspace, B, N, w->hidden);
+  float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;
+  const int env_blocks = (B + 3) / 4;
+  hipLaunchKernelGGL(rollout_setup_kernel, dim3(env_blocks + 2 * w->num_layers), dim3(256), 0, st,
+                     *env, *w, train ? 0 : 1, cur, ws.norm, acc_loss, acc_logp, notdone, nflags,
+                     env_blocks);
+  VRP_CHECK_LAUNCH("rollout_setup");
+  return encoder_layers(w, train, B, N, cur, emb, ws, st);
+}
+
+static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N, float *cur,
+                          float *emb, const EncWs &ws, hipStream_t st) {
+  const int R = B * N;
+  float *nxt = nullptr;
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
     // out = bn1(x + MHA(x))
