@@ -102,7 +102,7 @@ def timed_rollouts(env, agent, greedy, steps, warmup, dist):
     return dt, res.T, float(-res.acc_loss.mean().item())
 
 
-def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0):
+def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_step=False):
     """Average duration of ONE decode_step launch, HIP events on the launch stream
     around every launch (the stream the library launches on is torch's current one)."""
     import ctypes as C
@@ -171,6 +171,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0):
     # for shorter kernels the C-loop figure (which still contains the ~1.5 us boundaries and
     # the three first-node launches of step 0) is the tighter upper bound.
     pair, loop = float(np.mean(durs)), float(np.mean(loops))
+    if per_step:  # tuning aid: mean duration of step t over the repetitions
+        return [round(float(np.mean(durs[t::T])) * 1e6, 2) for t in range(T)]
     avg = min(pair, loop)
     byts = algorithmic_bytes_per_step(B, N)
     achieved = byts / avg / 1e9

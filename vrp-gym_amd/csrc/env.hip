@@ -24,8 +24,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(vrp_env e, const int64_t 
   EnvStepOut o = env_step_wave(e, b, a, lane, e.mask + (size_t)parity_out * e.B * e.N);
   if (lane == 0) {
     reward[b] = -o.dist;  // tsp.py:98
-    if (!o.done && __hip_atomic_load(notdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-      __hip_atomic_store(notdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!o.done) *notdone = 1;  // same value from every writer (see flag_notdone, decoder.hip)
   }
 }
 
