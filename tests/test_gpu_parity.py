@@ -172,9 +172,11 @@ def test_encoder_against_reference(name, path):
 
 
 def test_encoder_large_against_oracle():
-    """B*N not a multiple of the 128-row GEMM tile, N > 64 attention path."""
+    """B*N not a multiple of the 128-row GEMM tile, N > 64 attention path, and every row
+    tiling of the fused eval-mode block kernel (16-row tiles x 2/3/4 up to 16384 rows, the
+    64-row tile above)."""
     from oracle import policy as opol
-    for kind, B, N in [(0, 37, 20), (2, 5, 100), (1, 300, 40)]:
+    for kind, B, N in [(0, 37, 20), (2, 5, 100), (1, 300, 40), (0, 350, 40), (1, 901, 20)]:
         agent = _agents()[kind](seed=69)
         sd, _ = opol.init_state_dicts(kind, 69)
         g = torch.Generator().manual_seed(B * N)

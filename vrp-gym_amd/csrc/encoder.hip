@@ -336,6 +336,169 @@ static int launch_encoder_block(const float *att, const float *x, const vrp_enco
   return 0;
 }
 
+// ---- the same fused block for SMALL row counts (R <= 16384) ------------------------------
+// There the 32-row tiling above leaves the chip unbalanced (R = 10240: 320 workgroups on 256
+// CUs, the doubly-loaded CUs set the duration).  This variant tiles rows in units of 16 on
+// v_mfma_f32_16x16x4_f32 so that the row count per workgroup (16 * RT16) can be chosen to
+// give every CU at most one workgroup.  Wave w owns output columns 32w..32w+31 (two 16-wide
+// column tiles) for all rows; the K = 128 inner dimension is split over the four 16-lane
+// groups (group q walks k = 32q + s), a fixed permutation applied to both operands.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void eb16_load_w(float (&w)[2][32], const float *w0, const float *w1) {
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    const float4 t0 = *reinterpret_cast<const float4 *>(w0 + s);
+    const float4 t1 = *reinterpret_cast<const float4 *>(w1 + s);
+    w[0][s] = t0.x; w[0][s + 1] = t0.y; w[0][s + 2] = t0.z; w[0][s + 3] = t0.w;
+    w[1][s] = t1.x; w[1][s + 1] = t1.y; w[1][s + 2] = t1.z; w[1][s + 3] = t1.w;
+  }
+}
+template <int RT16>
+__device__ __forceinline__ void eb16_mma(f32x4v (&acc)[RT16][2], const float *abuf,
+                                         const float (&w)[2][32], int lane) {
+  const int i16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    float4 a[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+      a[rt] = *reinterpret_cast<const float4 *>(abuf + (rt * 16 + i16) * EB_LD + 32 * q + s);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[ct][s], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[ct][s + 1], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[ct][s + 2], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[ct][s + 3], acc[rt][ct], 0, 0, 0);
+      }
+  }
+}
+
+template <int RT16>
+__global__ __launch_bounds__(256, 1) void encoder_block16_kernel(
+    const float *__restrict__ att, const float *__restrict__ x, const float *__restrict__ Wo,
+    const float *__restrict__ bo, const float *__restrict__ norm1, const float *__restrict__ W1,
+    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+    const float *__restrict__ norm2, float *__restrict__ y, int rows, int hidden) {
+  constexpr int RTW = 16 * RT16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;                 // att tile, then the hidden-layer slices
+  float *bufB = smem + RTW * EB_LD;   // x tile, then y1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * RTW;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int col[2] = {wave * 32 + i16, wave * 32 + 16 + i16};   // this lane's weight rows / D columns
+
+  float wa[2][32], wb[2][32];
+  eb16_load_w(wa, Wo + (size_t)col[0] * 128 + 32 * q, Wo + (size_t)col[1] * 128 + 32 * q);
+  for (int idx = tid; idx < RTW * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
+    if (row0 + r < rows) {
+      va = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+      vx = *reinterpret_cast<const float4 *>(x + (size_t)(row0 + r) * 128 + c4);
+    }
+    *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = va;
+    *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = vx;
+  }
+  __syncthreads();
+
+  f32x4v acc[RT16][2], gacc[RT16][2];
+#pragma unroll
+  for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[rt][ct][r] = 0.f; gacc[rt][ct][r] = 0.f; }
+
+  // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
+  eb16_load_w(wb, W1 + (size_t)col[0] * 128 + 32 * q, W1 + (size_t)col[1] * 128 + 32 * q);
+  eb16_mma<RT16>(acc, bufA, wa, lane);
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = col[ct];
+    const float bb = bo[c], mean = norm1[c], mult = norm1[128 + c], beta = norm1[256 + c];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *p = bufB + (rt * 16 + 4 * q + r) * EB_LD + c;   // D: row = 4*(lane>>4)+r, col = lane&15
+        *p = (acc[rt][ct][r] + bb + *p - mean) * mult + beta;  // x -> y1 in place
+      }
+  }
+  __syncthreads();
+
+  // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T --------------
+  const int nchunk = hidden / 128;
+  for (int ch = 0; ch < nchunk; ++ch) {
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][ct][r] = 0.f;
+    eb16_load_w(wa, W2 + (size_t)col[0] * hidden + ch * 128 + 32 * q,
+                W2 + (size_t)col[1] * hidden + ch * 128 + 32 * q);
+    eb16_mma<RT16>(acc, bufB, wb, lane);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const float bb = b1[ch * 128 + col[ct]];
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bufA[(rt * 16 + 4 * q + r) * EB_LD + col[ct]] = fmaxf(acc[rt][ct][r] + bb, 0.f);
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk)
+      eb16_load_w(wb, W1 + (size_t)((ch + 1) * 128 + col[0]) * 128 + 32 * q,
+                  W1 + (size_t)((ch + 1) * 128 + col[1]) * 128 + 32 * q);
+    eb16_mma<RT16>(gacc, bufA, wa, lane);
+    __syncthreads();
+  }
+
+  // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int c = col[ct];
+    const float bb = b2[c], mean = norm2[c], mult = norm2[128 + c], beta = norm2[256 + c];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        if (row0 + row < rows) {
+          const float v = gacc[rt][ct][r] + bb + bufB[row * EB_LD + c];
+          y[(size_t)(row0 + row) * 128 + c] = (v - mean) * mult + beta;
+        }
+      }
+  }
+}
+
+template <int RT16>
+static int launch_encoder_block16(const float *att, const float *x, const vrp_encoder_layer &L,
+                                  const float *norm1, const float *norm2, float *y, int rows,
+                                  int hidden, hipStream_t st) {
+  constexpr int RTW = 16 * RT16;
+  const size_t lds = (size_t)2 * RTW * EB_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block16_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_block16: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(encoder_block16_kernel<RT16>, dim3((rows + RTW - 1) / RTW), dim3(256), lds, st,
+                     att, x, L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
+                     L.ff2_weight, L.ff2_bias, norm2, y, rows, hidden);
+  VRP_CHECK_LAUNCH("encoder_block16");
+  return 0;
+}
+
 struct EncWs {
   float *h0, *h1, *qkv, *att, *ff, *norm;  // norm: (16,384) eval-mode BN affines
   double *stats;
@@ -545,11 +708,17 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       nxt = (cur == emb) ? ws.h0 : emb;
       const float *n1 = ws.norm + (2 * l) * 384, *n2 = ws.norm + (2 * l + 1) * 384;
       // row tile: enough workgroups to occupy all 256 CUs at every batch size
-      const int r = (R >= 64 * 1024)
-                        ? launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st)
-                        : (R >= 16 * 1024
-                               ? launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st)
-                               : launch_encoder_block<32>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st));
+      int r;
+      if (R >= 64 * 1024)
+        r = launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (R > 16 * 1024)
+        r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (R > 12 * 1024)   // small batches: at most one workgroup per CU (256 CUs)
+        r = launch_encoder_block16<4>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (R > 8 * 1024)
+        r = launch_encoder_block16<3>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else
+        r = launch_encoder_block16<2>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       if (r) return r;
       cur = nxt;
       continue;
