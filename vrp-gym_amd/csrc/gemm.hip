@@ -143,6 +143,64 @@ __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm
     }
 }
 
+// ---- small-M variant (M <= 1024, K = 128): the per-graph query projections of the decoder
+// (B rows: graph embedding, first chosen node).  A 64-row tiling would give 3 x 8 workgroups
+// at B = 512; this one tiles rows by 16 on v_mfma_f32_16x16x4_f32 (3 x 32 workgroups), keeps
+// the whole K in one shot (A tile in LDS, weight fragments straight from L2 to registers)
+// and has no K loop or barrier chain.  Wave w owns columns 32w..32w+31 of its 128-column
+// block; the 128-long inner dimension is split over the four 16-lane groups (group q walks
+// k = 32q + s), the same permutation on both operands.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+#define SG_LD 132
+
+__global__ __launch_bounds__(256) void gemm_nt_m16_k128_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int M) {
+  __shared__ __attribute__((aligned(16))) float As[16 * SG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 128 + wave * 32;
+  float w[2][32];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const float *wr = W + (size_t)(n0 + 16 * ct + i16) * ldw + 32 * q;
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(wr + s);
+      w[ct][s] = t.x; w[ct][s + 1] = t.y; w[ct][s + 2] = t.z; w[ct][s + 3] = t.w;
+    }
+  }
+  for (int idx = tid; idx < 16 * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m0 + r < M) v = *reinterpret_cast<const float4 *>(A + (size_t)(m0 + r) * lda + c4);
+    *reinterpret_cast<float4 *>(As + r * SG_LD + c4) = v;
+  }
+  __syncthreads();
+  f32x4m acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(As + i16 * SG_LD + 32 * q + s);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[ct][s], acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[ct][s + 1], acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[ct][s + 2], acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[ct][s + 3], acc[ct], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int n = n0 + 16 * ct + i16;  // D: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const float bb = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * q + r;
+      if (m < M) C[(size_t)m * ldc + n] = acc[ct][r] + bb;
+    }
+  }
+}
+
 // norm: optional BatchNorm affine (only for N == 128): [mean | mult | beta]
 int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, const float *bias,
                             const float *R, int ldr, const float *norm, const float *gate, float *C,
@@ -152,6 +210,12 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
               N, BN, K);
   VRP_REQUIRE((lda % 4) == 0 && (ldw % 4) == 0, "gemm: lda/ldw must be multiples of 4");
   VRP_REQUIRE(!norm || N == 128, "gemm: fused BatchNorm needs N == 128");
+  if (M <= 1024 && K == 128 && !R && !norm && !gate && !relu) {
+    hipLaunchKernelGGL(gemm_nt_m16_k128_kernel, dim3(N / BN, (M + 15) / 16), dim3(256), 0, stream,
+                       A, lda, W, ldw, bias, C, ldc, M);
+    VRP_CHECK_LAUNCH("gemm_nt_m16");
+    return 0;
+  }
   const long tiles128 = (long)(N / BN) * ((M + 127) / 128);
   static const char *force = getenv("VRP_GEMM_VARIANT");  // tuning aid: "64x32", "64x64", "128x32"
   if (force && force[0] == '6') {
