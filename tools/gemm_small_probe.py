@@ -1,0 +1,23 @@
+import os, sys
+sys.path[:0] = ["/root/repo/vrp-gym_amd", "/root/repo"]
+import torch
+import vrpgym_hip as hip
+lib = hip.lib()
+for M in (256, 512, 1024, 2048, 4096):
+    for N in (384, 1536):
+        K = 128
+        A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.1
+        b = torch.randn(N, device="cuda"); C = torch.empty(M, N, device="cuda")
+        st = hip.current_stream()
+        def run():
+            hip.check(lib.vrp_gemm_nt(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0,
+                                      C.data_ptr(), N, M, N, K, 0, hip.current_stream()))
+        for _ in range(3): run()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20): run()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        print(f"M={M} N={N}: {e0.elapsed_time(e1)*1e3/20:.1f} us")

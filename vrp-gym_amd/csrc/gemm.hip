@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm
     }
 }
 
-// ---- small-M variant (M <= 1024, K = 128): the per-graph query projections of the decoder
+// ---- small-problem variant (M*N <= 3M outputs, K = 128): the per-graph query projections of the decoder
 // (B rows: graph embedding, first chosen node).  A 64-row tiling would give 3 x 8 workgroups
 // at B = 512; this one tiles rows by 16 on v_mfma_f32_16x16x4_f32 (3 x 32 workgroups), keeps
 // the whole K in one shot (A tile in LDS, weight fragments straight from L2 to registers)
@@ -210,12 +210,6 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
               N, BN, K);
   VRP_REQUIRE((lda % 4) == 0 && (ldw % 4) == 0, "gemm: lda/ldw must be multiples of 4");
   VRP_REQUIRE(!norm || N == 128, "gemm: fused BatchNorm needs N == 128");
-  if (M <= 1024 && K == 128 && !R && !norm && !gate && !relu) {
-    hipLaunchKernelGGL(gemm_nt_m16_k128_kernel, dim3(N / BN, (M + 15) / 16), dim3(256), 0, stream,
-                       A, lda, W, ldw, bias, C, ldc, M);
-    VRP_CHECK_LAUNCH("gemm_nt_m16");
-    return 0;
-  }
   const long tiles128 = (long)(N / BN) * ((M + 127) / 128);
   static const char *force = getenv("VRP_GEMM_VARIANT");  // tuning aid: "64x32", "64x64", "128x32"
   if (force && force[0] == '6') {
@@ -234,6 +228,13 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, gate, C, ldc, M, N, K, relu);
+  } else if ((long)M * N <= (3L << 20) && K == 128 && !R && !norm && !gate && !relu) {
+    // measured (tools/gemm_small_probe.py): 5.7 vs 15.5 us at 512x384, 20 vs 21 at 2048x1536,
+    // 35 vs 28 at 4096x1536
+    hipLaunchKernelGGL(gemm_nt_m16_k128_kernel, dim3(N / BN, (M + 15) / 16), dim3(256), 0, stream,
+                       A, lda, W, ldw, bias, C, ldc, M);
+    VRP_CHECK_LAUNCH("gemm_nt_m16");
+    return 0;
   } else if (tiles128 >= 512) {
     // at least two workgroups per CU: 128x128x16 tiles, 32 KB of LDS
     // and 114 VGPRs -> 4 workgroups per CU overlap each other's barriers and load latency
