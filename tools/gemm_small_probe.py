@@ -3,8 +3,9 @@ sys.path[:0] = ["/root/repo/vrp-gym_amd", "/root/repo"]
 import torch
 import vrpgym_hip as hip
 lib = hip.lib()
-for M in (256, 512, 1024, 2048, 4096):
-    for N in (384, 1536):
+Ms = [int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (256, 512, 1024, 2048, 4096)
+for M in Ms:
+    for N in (128, 384, 512, 1536):
         K = 128
         A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.1
         b = torch.randn(N, device="cuda"); C = torch.empty(M, N, device="cuda")
@@ -20,4 +21,5 @@ for M in (256, 512, 1024, 2048, 4096):
         g.replay(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-        print(f"M={M} N={N}: {e0.elapsed_time(e1)*1e3/20:.1f} us")
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        print(f"M={M} N={N}: {us:.1f} us  {2*M*N*K/us/1e6:.1f} TFLOP/s")
