@@ -26,6 +26,9 @@
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *R, int ldr, float *C, int ldc, int M, int N, int K,
                        int relu, hipStream_t stream);
+int vrp_launch_gemm_gather_k128(const float *A, int lda, const int32_t *gidx, int gstride,
+                                const float *W, int ldw, float *C, int ldc, int M, int N,
+                                hipStream_t stream);
 
 // ------------------------------------------------------------------ derived weights
 struct Derived {
@@ -1177,10 +1180,15 @@ extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N,
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs ws = carve_decws(kind, workspace, B, N);
   const int P = proj_width(kind, N);
-  hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
-  VRP_CHECK_LAUNCH("gather_first");
-  if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
-                                 384, 128, 0, st)) return r;
+  // QF1 = e_first Wq_first^T: gather fused into the small-problem GEMM when the shape allows
+  const int gr = vrp_launch_gemm_gather_k128(emb, 128, ws.first, N, d.Wqf, 128, ws.QF1, 384, B, 384, st);
+  if (gr > 0) return gr;
+  if (gr < 0) {
+    hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
+    VRP_CHECK_LAUNCH("gather_first");
+    if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
+                                   384, 128, 0, st)) return r;
+  }
   return launch_pair_tables<1>(kind, B, N, P, ws.PROJ, ws.QG, d.qc0, d.wload, ws.QF1, ws.first, ws.SG,
                                ws.C0, ws.SLD, ws.SL, ws.row0, ws.curs, ws.RT, st);
 }

@@ -153,9 +153,12 @@ __global__ __launch_bounds__(256, (BK == 16 ? 4 : (BK == 64 ? 1 : 2))) void gemm
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 #define SG_LD 132
 
+// Optional row gather: with gidx, output row m reads A row m * gstride + gidx[m] (the
+// embedding of graph m's first chosen node, graph_decoder.py:111-113).
 __global__ __launch_bounds__(256) void gemm_nt_m16_k128_kernel(
     const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
-    const float *__restrict__ bias, float *__restrict__ C, int ldc, int M) {
+    const float *__restrict__ bias, float *__restrict__ C, int ldc, int M,
+    const int32_t *__restrict__ gidx, int gstride) {
   __shared__ __attribute__((aligned(16))) float As[16 * SG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, q = lane >> 4;
@@ -173,7 +176,10 @@ __global__ __launch_bounds__(256) void gemm_nt_m16_k128_kernel(
   for (int idx = tid; idx < 16 * 32; idx += 256) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (m0 + r < M) v = *reinterpret_cast<const float4 *>(A + (size_t)(m0 + r) * lda + c4);
+    if (m0 + r < M) {
+      const size_t src = gidx ? (size_t)(m0 + r) * gstride + gidx[m0 + r] : (size_t)(m0 + r);
+      v = *reinterpret_cast<const float4 *>(A + src * lda + c4);
+    }
     *reinterpret_cast<float4 *>(As + r * SG_LD + c4) = v;
   }
   __syncthreads();
@@ -232,7 +238,7 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
     // measured (tools/gemm_small_probe.py): 5.7 vs 15.5 us at 512x384, 20 vs 21 at 2048x1536,
     // 35 vs 28 at 4096x1536
     hipLaunchKernelGGL(gemm_nt_m16_k128_kernel, dim3(N / BN, (M + 15) / 16), dim3(256), 0, stream,
-                       A, lda, W, ldw, bias, C, ldc, M);
+                       A, lda, W, ldw, bias, C, ldc, M, nullptr, 0);
     VRP_CHECK_LAUNCH("gemm_nt_m16");
     return 0;
   } else if (tiles128 >= 512) {
@@ -255,6 +261,19 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
                          bias, R, ldr, norm, gate, C, ldc, M, N, K, relu);
   }
   VRP_CHECK_LAUNCH("gemm_nt");
+  return 0;
+}
+
+// C (M,N) = A[m*gstride + gidx[m]] W^T for small problems (K = 128); returns -1 when the
+// shape is outside the small-problem kernel's range (the caller then gathers and calls the
+// general GEMM).
+int vrp_launch_gemm_gather_k128(const float *A, int lda, const int32_t *gidx, int gstride,
+                                const float *W, int ldw, float *C, int ldc, int M, int N,
+                                hipStream_t stream) {
+  if ((long)M * N > (3L << 20) || N % BN != 0) return -1;
+  hipLaunchKernelGGL(gemm_nt_m16_k128_kernel, dim3(N / BN, (M + 15) / 16), dim3(256), 0, stream, A,
+                     lda, W, ldw, nullptr, C, ldc, M, gidx, gstride);
+  VRP_CHECK_LAUNCH("gemm_gather_m16");
   return 0;
 }
 
