@@ -74,13 +74,15 @@ extern "C" int64_t vrp_decoder_derived_bytes(void) {
 
 // C[i*scr + j*scc] = alpha * sum_k A[i*sar + k*sac] * Bm[k*sbr + j*sbc] + beta*C.
 // Tiny one-off weight folds only (<= 19 M MAC); one thread per output element.
-__global__ void mm_strided_kernel(float *C, int scr, int scc, const float *A, int sar, int sac,
-                                  const float *Bm, int sbr, int sbc, int M, int N, int K,
+__global__ void mm_strided_kernel(float *__restrict__ C, int scr, int scc,
+                                  const float *__restrict__ A, int sar, int sac,
+                                  const float *__restrict__ Bm, int sbr, int sbc, int M, int N, int K,
                                   float alpha, float beta) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * N) return;
   const int i = idx / N, j = idx - i * N;
   float acc = 0.f;
+#pragma unroll 16  // the loads of 16 k-steps in flight; the fmaf chain keeps the k order
   for (int k = 0; k < K; ++k)
     acc = fmaf(A[(size_t)i * sar + (size_t)k * sac], Bm[(size_t)k * sbr + (size_t)j * sbc], acc);
   float *c = C + (size_t)i * scr + (size_t)j * scc;
