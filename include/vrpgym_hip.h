@@ -130,7 +130,8 @@ typedef struct vrp_rollout_io {
 } vrp_rollout_io;
 
 /* D2  Per-episode constants of GraphDecoder.forward (agents/graph_decoder.py:75-83):
- * graph embedding, hoisted K projection and the per-node glimpse score tables. */
+ * graph embedding, hoisted K/V/_kp projections, the step-0 score row, the pointer-logit
+ * table and (IRP) the last-node score table. */
 int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
                         void *workspace, void *stream);
 
@@ -159,8 +160,10 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
 
 /* D2  GraphDecoder.forward's `first_` update (agents/graph_decoder.py:111-113) for
  * TSP/VRP: after step 0 the first chosen node is fixed; its part of the glimpse query is
- * folded once into the per-graph score row.  Appended to step 0 by vrp_decode_step
- * unless VRP_STEP_NO_FIRST_ROW is set.  No-op for IRP. */
+ * folded, together with the graph-embedding part, into the last-node score table that every
+ * later step reads one row of (the table is built here).  Appended to step 0 by
+ * vrp_decode_step unless VRP_STEP_NO_FIRST_ROW is set.  No-op for IRP, whose context has no
+ * first-node term (vrp_decode_prologue builds its table). */
 int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
                          void *workspace, void *stream);
 
