@@ -33,6 +33,8 @@ int vrp_launch_transpose(const float *src, int rows, int cols, int lds, float *d
 #define DB_E 128
 #define DB_C48 0.14433756729740643f   // 1/sqrt(48)   head dim of the 8-head glimpse
 #define DB_C128 0.08838834764831845f  // 1/sqrt(128)  graph_decoder.py:97
+#define DBL_LD 132  // LDS row stride of the (N x 128) _kp(emb) tile in the logit kernel
+#define DBK_LD 52   // LDS row stride of the (N x 48) K_h / V_h tiles in the backward kernel
 
 // ------------------------------------------------------------------ small helpers
 __global__ __launch_bounds__(128) void db_graph_mean_kernel(const float *__restrict__ emb, int N,
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(256) void db_attn_fwd_kernel(int B, int N, int T,
                                                           float *__restrict__ A,
                                                           float *__restrict__ O) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *K_s = smem;                 // [N][49]
-  float *V_s = K_s + N * 49;         // [N][48]
+  float *K_s = smem;                 // [N][52]: 16-byte aligned rows, conflict-free b128 reads
+  float *V_s = K_s + N * DBK_LD;     // [N][48]
   float *q_s = V_s + N * 48;         // [4][48]
   float *a_s = q_s + 4 * 48;         // [4][64*NPL]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void db_attn_fwd_kernel(int B, int N, int T,
   for (int idx = tid; idx < N * 48; idx += 256) {
     const int n = idx / 48, d = idx - n * 48;
     const size_t src = ((size_t)b * N + n) * VRP_D + h * VRP_HD + d;
-    K_s[n * 49 + d] = Kb[src];
+    K_s[n * DBK_LD + d] = Kb[src];
     V_s[n * 48 + d] = Vb[src];
   }
   __syncthreads();
@@ -123,7 +125,12 @@ __global__ __launch_bounds__(256) void db_attn_fwd_kernel(int B, int N, int T,
       if (n < N) {
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < 48; ++d) acc = fmaf(q_s[wave * 48 + d], K_s[n * 49 + d], acc);
+        for (int d = 0; d < 48; d += 4) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(q_s + wave * 48 + d);
+          const float4 k4 = *reinterpret_cast<const float4 *>(K_s + n * DBK_LD + d);
+          acc = fmaf(q4.x, k4.x, acc); acc = fmaf(q4.y, k4.y, acc);
+          acc = fmaf(q4.z, k4.z, acc); acc = fmaf(q4.w, k4.w, acc);
+        }
         s[i] = acc * DB_C48 + (float)masks[((size_t)(on ? t : 0) * B + mrow) * N + n];
       }
       mx = fmaxf(mx, s[i]);
@@ -167,19 +174,19 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
                                                           float *__restrict__ dK,
                                                           float *__restrict__ dV) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *K_s = smem;                  // [N][49]
-  float *V_s = K_s + N * 49;          // [N][49]
-  float *q_s = V_s + N * 49;          // [4][48]
-  float *do_s = q_s + 4 * 48;         // [4][48]
-  float *ds_s = do_s + 4 * 48;        // [4][64*NPL]
-  float *red_s = ds_s + 4 * 64 * NPL; // [N][49]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *K_s = smem;                  // [N][52]: rows 16-byte aligned, b128 reads conflict-free
+  float *V_s = K_s + N * DBK_LD;      // [N][52]
+  float *ds_s = V_s + N * DBK_LD;         // [4][64*NPL]  (each wave touches only its own row)
+  float *qd_s = ds_s + 4 * 64 * NPL;  // [4][96]      this step's q | dO rows, per wave
+  float *red_s = qd_s + 4 * 96;       // [N][49]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, h = blockIdx.y;
   for (int idx = tid; idx < N * 48; idx += 256) {
     const int n = idx / 48, d = idx - n * 48;
     const size_t src = ((size_t)b * N + n) * VRP_D + h * VRP_HD + d;
-    K_s[n * 49 + d] = Kb[src];
-    V_s[n * 49 + d] = Vb[src];
+    K_s[n * DBK_LD + d] = Kb[src];
+    V_s[n * DBK_LD + d] = Vb[src];
   }
   float dKa[NPL][48], dVa[NPL][48];
 #pragma unroll
@@ -187,26 +194,58 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
 #pragma unroll
     for (int d = 0; d < 48; ++d) { dKa[i][d] = 0.f; dVa[i][d] = 0.f; }
   __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += 4) {
-    const int t = t0 + wave;
-    const bool on = t < T;
-    const size_t r = (size_t)(on ? t : 0) * B + b;
-    if (lane < 48) {
-      q_s[wave * 48 + lane] = Q[r * VRP_D + h * VRP_HD + lane];
-      do_s[wave * 48 + lane] = on ? dO[r * VRP_D + h * VRP_HD + lane] : 0.f;
+  // Each wave walks its own steps (t = wave, wave+4, ...) without workgroup barriers: its
+  // query / output-gradient rows pass through a wave-private LDS slot (broadcast reads), and
+  // the rows and attention weights of the NEXT step are loaded while this one is computed --
+  // with two workgroups per CU the global-load latency of a step would otherwise be exposed.
+  float *dsw = ds_s + wave * 64 * NPL;
+  float *qw = qd_s + wave * 96, *dow = qw + 48;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  float qn = 0.f, don = 0.f, an[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) an[i] = 0.f;
+  auto prefetch = [&](int t) {
+    if (t < T) {
+      const size_t r = (size_t)t * B + b;
+      if (lane < 48) {
+        qn = Q[r * VRP_D + h * VRP_HD + lane];
+        don = dO[r * VRP_D + h * VRP_HD + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+        if (lane + 64 * i < N) an[i] = A[(r * 8 + h) * N + lane + 64 * i];
     }
-    __syncthreads();
-    float a[NPL], da[NPL], part = 0.f;
+  };
+  prefetch(wave);
+  for (int t = wave; t < T; t += 4) {
+    const size_t r = (size_t)t * B + b;
+    if (lane < 48) { qw[lane] = qn; dow[lane] = don; }
+    float a[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) a[i] = an[i];
+    wave_sync();
+    prefetch(t + 4);
+    float da[NPL], part = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       const int n = lane + 64 * i;
-      a[i] = 0.f; da[i] = 0.f;
-      if (n < N && on) {
-        a[i] = A[(r * 8 + h) * N + n];
+      da[i] = 0.f;
+      if (n < N) {
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < 48; ++d) acc = fmaf(do_s[wave * 48 + d], V_s[n * 49 + d], acc);
+        for (int d = 0; d < 48; d += 4) {
+          const float4 g4 = *reinterpret_cast<const float4 *>(dow + d);
+          const float4 v4 = *reinterpret_cast<const float4 *>(V_s + n * DBK_LD + d);
+          acc = fmaf(g4.x, v4.x, acc); acc = fmaf(g4.y, v4.y, acc);
+          acc = fmaf(g4.z, v4.z, acc); acc = fmaf(g4.w, v4.w, acc);
+        }
         da[i] = acc;
+      } else {
+        a[i] = 0.f;
       }
       part = fmaf(a[i], da[i], part);
     }
@@ -215,22 +254,27 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
     for (int i = 0; i < NPL; ++i) {
       const int n = lane + 64 * i;
       const float ds = a[i] * (da[i] - dot);
-      if (n < N) ds_s[wave * 64 * NPL + n] = ds;
+      if (n < N) dsw[n] = ds;
       const float dsc = ds * DB_C48;
 #pragma unroll
-      for (int d = 0; d < 48; ++d) {
-        dKa[i][d] = fmaf(dsc, q_s[wave * 48 + d], dKa[i][d]);
-        dVa[i][d] = fmaf(a[i], do_s[wave * 48 + d], dVa[i][d]);
+      for (int d = 0; d < 48; d += 4) {
+        const float4 q4 = *reinterpret_cast<const float4 *>(qw + d);
+        const float4 g4 = *reinterpret_cast<const float4 *>(dow + d);
+        dKa[i][d] = fmaf(dsc, q4.x, dKa[i][d]);         dVa[i][d] = fmaf(a[i], g4.x, dVa[i][d]);
+        dKa[i][d + 1] = fmaf(dsc, q4.y, dKa[i][d + 1]); dVa[i][d + 1] = fmaf(a[i], g4.y, dVa[i][d + 1]);
+        dKa[i][d + 2] = fmaf(dsc, q4.z, dKa[i][d + 2]); dVa[i][d + 2] = fmaf(a[i], g4.z, dVa[i][d + 2]);
+        dKa[i][d + 3] = fmaf(dsc, q4.w, dKa[i][d + 3]); dVa[i][d + 3] = fmaf(a[i], g4.w, dVa[i][d + 3]);
       }
     }
-    __syncthreads();
-    if (lane < 48 && on) {
+    wave_sync();
+    if (lane < 48) {
       float dq = 0.f;
-      for (int n = 0; n < N; ++n) dq = fmaf(ds_s[wave * 64 * NPL + n], K_s[n * 49 + lane], dq);
+      for (int n = 0; n < N; ++n) dq = fmaf(dsw[n], K_s[n * DBK_LD + lane], dq);
       dQ[r * VRP_D + h * VRP_HD + lane] = dq * DB_C48;
     }
-    __syncthreads();
+    wave_sync();
   }
+  __syncthreads();
   // ordered sum over the four waves: wave 0 + wave 1 + wave 2 + wave 3
   for (int pass = 0; pass < 2; ++pass) {
     float (&acc)[NPL][48] = pass == 0 ? dKa : dVa;
@@ -241,7 +285,7 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
           const int n = lane + 64 * i;
           if (n < N) {
 #pragma unroll
-            for (int d = 0; d < 48; ++d) red_s[n * 49 + d] = acc[i][d];
+            for (int d = 0; d < 48; ++d) red_s[n * DBK_LD + d] = acc[i][d];
           }
         }
       }
@@ -252,7 +296,7 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
           const int n = lane + 64 * i;
           if (n < N) {
 #pragma unroll
-            for (int d = 0; d < 48; ++d) acc[i][d] += red_s[n * 49 + d];
+            for (int d = 0; d < 48; ++d) acc[i][d] += red_s[n * DBK_LD + d];
           }
         }
       }
@@ -264,7 +308,7 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
         const int n = lane + 64 * i;
         if (n < N) {
 #pragma unroll
-          for (int d = 0; d < 48; ++d) red_s[n * 49 + d] = acc[i][d];
+          for (int d = 0; d < 48; ++d) red_s[n * DBK_LD + d] = acc[i][d];
         }
       }
     }
@@ -273,7 +317,7 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
       float *dst = pass == 0 ? dK : dV;
       for (int idx = tid; idx < N * 48; idx += 256) {
         const int n = idx / 48, d = idx - n * 48;
-        dst[((size_t)b * N + n) * VRP_D + h * VRP_HD + d] = red_s[n * 49 + d];
+        dst[((size_t)b * N + n) * VRP_D + h * VRP_HD + d] = red_s[n * DBK_LD + d];
       }
     }
     __syncthreads();
@@ -296,15 +340,15 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
                                                        float *__restrict__ dKP,
                                                        float *__restrict__ step_logp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *KP_s = smem;                  // [N][129]
-  float *q_s = KP_s + N * 129;         // [4][128]
+  float *KP_s = smem;                  // [N][132]
+  float *q_s = KP_s + N * DBL_LD;         // [4][128]
   float *dz_s = q_s + 4 * 128;         // [4][64*NPL]
-  float *red_s = dz_s + 4 * 64 * NPL;  // [N][129]
+  float *red_s = dz_s + 4 * 64 * NPL;  // [N][132]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   for (int idx = tid; idx < N * 128; idx += 256) {
     const int n = idx >> 7, k = idx & 127;
-    KP_s[n * 129 + k] = KP[((size_t)b * N + n) * DB_E + k];
+    KP_s[n * DBL_LD + k] = KP[((size_t)b * N + n) * DB_E + k];
   }
   float acc[NPL][128];
 #pragma unroll
@@ -328,8 +372,13 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
       u[i] = -INFINITY; th[i] = 0.f;
       if (n < N && !masks[r * N + n]) {
         float z = 0.f;
-#pragma unroll 16
-        for (int k = 0; k < 128; ++k) z = fmaf(q_s[wave * 128 + k], KP_s[n * 129 + k], z);
+#pragma unroll 8
+        for (int k = 0; k < 128; k += 4) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(q_s + wave * 128 + k);
+          const float4 p4 = *reinterpret_cast<const float4 *>(KP_s + n * DBL_LD + k);
+          z = fmaf(q4.x, p4.x, z); z = fmaf(q4.y, p4.y, z);
+          z = fmaf(q4.z, p4.z, z); z = fmaf(q4.w, p4.w, z);
+        }
         th[i] = tanhf(z * DB_C128);
         u[i] = 10.f * th[i];
       }
@@ -354,7 +403,13 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
       if (n == act) lp_part += u[i] - lse;
       if (n < N) dz_s[wave * 64 * NPL + n] = dz;
 #pragma unroll
-      for (int k = 0; k < 128; ++k) acc[i][k] = fmaf(dz, q_s[wave * 128 + k], acc[i][k]);
+      for (int k = 0; k < 128; k += 4) {
+        const float4 q4 = *reinterpret_cast<const float4 *>(q_s + wave * 128 + k);
+        acc[i][k] = fmaf(dz, q4.x, acc[i][k]);
+        acc[i][k + 1] = fmaf(dz, q4.y, acc[i][k + 1]);
+        acc[i][k + 2] = fmaf(dz, q4.z, acc[i][k + 2]);
+        acc[i][k + 3] = fmaf(dz, q4.w, acc[i][k + 3]);
+      }
     }
     const float lp = wave_sum(lp_part);
     if (step_logp && on && lane == 0) step_logp[r] = lp;
@@ -364,7 +419,7 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
       for (int j = 0; j < 2; ++j) {
         const int k = lane + 64 * j;
         float dq = 0.f;
-        for (int n = 0; n < N; ++n) dq = fmaf(dz_s[wave * 64 * NPL + n], KP_s[n * 129 + k], dq);
+        for (int n = 0; n < N; ++n) dq = fmaf(dz_s[wave * 64 * NPL + n], KP_s[n * DBL_LD + k], dq);
         dQ2[r * DB_E + k] = dq;
       }
     }
@@ -377,7 +432,7 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
         const int n = lane + 64 * i;
         if (n < N) {
 #pragma unroll
-          for (int k = 0; k < 128; ++k) red_s[n * 129 + k] = acc[i][k];
+          for (int k = 0; k < 128; ++k) red_s[n * DBL_LD + k] = acc[i][k];
         }
       }
     }
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
         const int n = lane + 64 * i;
         if (n < N) {
 #pragma unroll
-          for (int k = 0; k < 128; ++k) acc[i][k] += red_s[n * 129 + k];
+          for (int k = 0; k < 128; ++k) acc[i][k] += red_s[n * DBL_LD + k];
         }
       }
     }
@@ -400,14 +455,14 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
       const int n = lane + 64 * i;
       if (n < N) {
 #pragma unroll
-        for (int k = 0; k < 128; ++k) red_s[n * 129 + k] = acc[i][k];
+        for (int k = 0; k < 128; ++k) red_s[n * DBL_LD + k] = acc[i][k];
       }
     }
   }
   __syncthreads();
   for (int idx = tid; idx < N * 128; idx += 256) {
     const int n = idx >> 7, k = idx & 127;
-    dKP[((size_t)b * N + n) * DB_E + k] = red_s[n * 129 + k];
+    dKP[((size_t)b * N + n) * DB_E + k] = red_s[n * DBL_LD + k];
   }
 }
 
@@ -537,7 +592,7 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   if (int r = vrp_launch_gemm_nt(s.ctx, 384, w->q_proj_weight, 384, bias, nullptr, 0, s.Q, 384, R,
                                  384, 384, 0, st)) return r;
   {
-    const size_t lds = sizeof(float) * ((size_t)N * 49 + N * 48 + 4 * 48 + 4 * 64 * npl);
+    const size_t lds = sizeof(float) * ((size_t)N * DBK_LD + N * 48 + 4 * 48 + 4 * 64 * npl);
     if (npl == 1) {
       if (db_raise_lds(db_attn_fwd_kernel<1>, lds, "db_attn_fwd")) return 1;
       hipLaunchKernelGGL(db_attn_fwd_kernel<1>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
@@ -556,7 +611,7 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
 
   // ---- backward ------------------------------------------------------------------------
   {
-    const size_t lds = sizeof(float) * ((size_t)2 * N * 129 + 4 * 128 + 4 * 64 * npl);
+    const size_t lds = sizeof(float) * ((size_t)2 * N * DBL_LD + 4 * 128 + 4 * 64 * npl);
     if (npl == 1) {
       if (db_raise_lds(db_logit_kernel<1>, lds, "db_logit")) return 1;
       hipLaunchKernelGGL(db_logit_kernel<1>, dim3(B), dim3(256), lds, st, B, N, T, s.Q2, s.KPb,
@@ -582,7 +637,7 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   if (int r = vrp_launch_gemm_nt(s.dO2, 384, s.WT, 384, nullptr, nullptr, 0, s.dO, 384, R, 384, 384,
                                  0, st)) return r;
   {
-    const size_t lds = sizeof(float) * ((size_t)3 * N * 49 + 8 * 48 + 4 * 64 * npl);
+    const size_t lds = sizeof(float) * ((size_t)3 * N * DBK_LD + 4 * 64 * npl + 4 * 96);
     if (npl == 1) {
       if (db_raise_lds(db_attn_bwd_kernel<1>, lds, "db_attn_bwd")) return 1;
       hipLaunchKernelGGL(db_attn_bwd_kernel<1>, dim3(B, 8), dim3(256), lds, st, B, N, T, s.Q, s.Kb,
