@@ -312,6 +312,15 @@ extern "C" int vrp_bn_bwd(const float *dy, const float *z, const float *stats, c
 //   dV = P^T dO,  dP = dO V^T,  dS = P o (dP - rowsum(dP o P)),  dQ = dS K / 4,  dK = dS^T Q / 4
 // One wave per (graph, head).  Pass A (lane = query row i): row max, row sum, D_i and dQ_i.
 // Pass B (lane = key row j): dK_j, dV_j with P recomputed from the row statistics in LDS.
+// 16 consecutive floats from a 16-byte aligned LDS address as four 128-bit reads
+__device__ __forceinline__ void ld16(float (&v)[16], const float *p) {
+#pragma unroll
+  for (int d = 0; d < 16; d += 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p + d);
+    v[d] = t.x; v[d + 1] = t.y; v[d + 2] = t.z; v[d + 3] = t.w;
+  }
+}
+
 __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float *__restrict__ qkv,
                                                                     const float *__restrict__ dO,
                                                                     float *__restrict__ dqkv,
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
   // per wave: Q,K,V,dO (N x 16 each), row max / inverse sum / D (N each)
-  float *Qs = smem + (size_t)wave * N * 67;
+  float *Qs = smem + (size_t)wave * ((N * 67 + 3) & ~3);  // 16-byte aligned rows of 16 floats
   float *Ks = Qs + N * 16, *Vs = Ks + N * 16, *Gs = Vs + N * 16;
   float *mx = Gs + N * 16, *isum = mx + N, *Dv = isum + N;
   const float *base = qkv + (size_t)b * N * 384;
@@ -341,19 +350,24 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
   for (int i = lane; i < N; i += 64) {
     float q[16], g[16];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) { q[d] = Qs[i * 16 + d] * 0.25f; g[d] = Gs[i * 16 + d]; }
+    for (int d = 0; d < 16; ++d) { q[d] = Qs[i * 16 + d] * 0.25f; g[d] = Gs[i * 16 + d]; }  // own row
     float m = -INFINITY;
     for (int j = 0; j < N; ++j) {
+      float kk[16];
+      ld16(kk, Ks + j * 16);
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      for (int d = 0; d < 16; ++d) s = fmaf(q[d], kk[d], s);
       m = fmaxf(m, s);
     }
     float l = 0.f, Dacc = 0.f;
     for (int j = 0; j < N; ++j) {
+      float kk[16], vv[16];
+      ld16(kk, Ks + j * 16);
+      ld16(vv, Vs + j * 16);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], Ks[j * 16 + d], s); dp = fmaf(g[d], Vs[j * 16 + d], dp); }
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
       const float p = expf(s - m);
       l += p;
       Dacc = fmaf(p, dp, Dacc);
@@ -364,12 +378,15 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
 #pragma unroll
     for (int d = 0; d < 16; ++d) dq[d] = 0.f;
     for (int j = 0; j < N; ++j) {
+      float kk[16], vv[16];
+      ld16(kk, Ks + j * 16);
+      ld16(vv, Vs + j * 16);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], Ks[j * 16 + d], s); dp = fmaf(g[d], Vs[j * 16 + d], dp); }
+      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
       const float ds = expf(s - m) * inv * (dp - Di);
 #pragma unroll
-      for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds, Ks[j * 16 + d], dq[d]);
+      for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
     }
     mx[i] = m; isum[i] = inv; Dv[i] = Di;
     float *dst = dqkv + ((size_t)b * N + i) * 384 + h * 16;
@@ -385,15 +402,18 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
 #pragma unroll
     for (int d = 0; d < 16; ++d) { k[d] = Ks[j * 16 + d]; v[d] = Vs[j * 16 + d]; dk[d] = 0.f; dv[d] = 0.f; }
     for (int i = 0; i < N; ++i) {
+      float qq[16], gg[16];
+      ld16(qq, Qs + i * 16);
+      ld16(gg, Gs + i * 16);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(Qs[i * 16 + d] * 0.25f, k[d], s); dp = fmaf(Gs[i * 16 + d], v[d], dp); }
+      for (int d = 0; d < 16; ++d) { s = fmaf(qq[d] * 0.25f, k[d], s); dp = fmaf(gg[d], v[d], dp); }
       const float p = expf(s - mx[i]) * isum[i];
       const float ds = p * (dp - Dv[i]);
 #pragma unroll
       for (int d = 0; d < 16; ++d) {
-        dv[d] = fmaf(p, Gs[i * 16 + d], dv[d]);
-        dk[d] = fmaf(ds, Qs[i * 16 + d] * 0.25f, dk[d]);
+        dv[d] = fmaf(p, gg[d], dv[d]);
+        dk[d] = fmaf(ds, qq[d] * 0.25f, dk[d]);
       }
     }
     float *dst = dqkv + ((size_t)b * N + j) * 384 + h * 16;
@@ -407,7 +427,7 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
 
 int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
                              hipStream_t st) {
-  const size_t lds = (size_t)4 * N * 67 * sizeof(float);
+  const size_t lds = (size_t)4 * ((N * 67 + 3) & ~3) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_bwd_kernel),
