@@ -166,6 +166,36 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
         e1.record()
         torch.cuda.synchronize()
         loops.append(e0.elapsed_time(e1) * 1e-3 / T)
+    # third figure: step 0 in its own event pair, the first-node table build untimed, then ONE
+    # event pair around the launches t = 1..T-1 issued back to back (the host needs ~5 us per
+    # launch, so the queue stays ahead of any kernel longer than that): what remains between
+    # the events is kernel time plus the ~1 us kernel-to-kernel boundary, without the ~3 us
+    # that a record/launch/record triple adds to every launch of the first figure.
+    chains = []
+    for _ in range(reps if T > 1 else 0):
+        rewind(env)
+        cenv = env._cenv()
+        hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
+                                          dec_ws.data_ptr(), stream))
+        res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        step_flags = (0 if greedy else 1) | 8 | extra_flags
+        ev[0].record()
+        hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
+                                      res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), 0,
+                                      max_steps, step_flags, stream))
+        ev[1].record()
+        hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
+                                           dec_ws.data_ptr(), stream))
+        ev[2].record()
+        for t in range(1, T):
+            hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
+                                          res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
+                                          max_steps, step_flags, stream))
+        ev[3].record()
+        torch.cuda.synchronize()
+        chains.append((ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])) * 1e-3 / T)
     # The event-pair figure brackets exactly one decode_step launch each (agrees with the
     # rocprofv3 average when the kernel outlasts the host's ~13 us per Python-driven launch);
     # for shorter kernels the C-loop figure (which still contains the ~1.5 us boundaries and
@@ -173,7 +203,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
     pair, loop = float(np.mean(durs)), float(np.mean(loops))
     if per_step:  # tuning aid: mean duration of step t over the repetitions
         return [round(float(np.mean(durs[t::T])) * 1e6, 2) for t in range(T)]
-    avg = min(pair, loop)
+    chain = float(np.mean(chains)) if chains else pair
+    avg = min(pair, loop, chain)
     byts = algorithmic_bytes_per_step(B, N)
     achieved = byts / avg / 1e9
     return {"bound": "hbm", "kernel": "decode_step_rt_kernel", "workload": f"kind{kind}_N{N}_B{B}",
@@ -183,7 +214,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
             "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
             "launches_timed": len(durs),
             "event_pair_per_launch_us": round(pair * 1e6, 3),
-            "c_loop_per_launch_us": round(loop * 1e6, 3)}
+            "c_loop_per_launch_us": round(loop * 1e6, 3),
+            "chained_per_launch_us": round(chain * 1e6, 3)}
 
 
 def cpu_baseline(kind, N, B, greedy, budget_s=15.0):

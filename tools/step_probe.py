@@ -25,4 +25,4 @@ for shp in shapes:
                                                      extra_flags=extra, per_step=True)}))
         continue
     r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3, extra_flags=extra)
-    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "event_pair_per_launch_us", "c_loop_per_launch_us", "achieved", "frac")}))
+    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "event_pair_per_launch_us", "c_loop_per_launch_us", "chained_per_launch_us", "achieved", "frac")}))
