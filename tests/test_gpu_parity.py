@@ -193,26 +193,35 @@ def test_encoder_large_against_oracle():
 
 
 def test_gemm_mfma_against_torch():
-    """fp32 MFMA GEMM vs a plain torch fp32 reference (ragged M, bias, residual, relu)."""
+    """fp32 MFMA GEMM vs a plain torch fp32 reference: ragged M, bias, residual, relu, and
+    the small-problem kernel (<= 3M outputs, K = 128, no residual/relu: 16-row tiles)."""
     import vrpgym_hip as hip
     lib = hip.lib()
     g = torch.Generator().manual_seed(1)
-    for M, N, K, relu in [(1, 128, 128, 0), (200, 384, 128, 0), (777, 128, 512, 0),
-                          (1000, 512, 128, 1), (64, 1152, 128, 0)]:
+    for M, N, K, relu, res, bias in [(1, 128, 128, 0, 1, 1), (200, 384, 128, 0, 1, 1),
+                                     (777, 128, 512, 0, 1, 1), (1000, 512, 128, 1, 1, 1),
+                                     (64, 1152, 128, 0, 1, 1),
+                                     (1, 128, 128, 0, 0, 1), (17, 384, 128, 0, 0, 0),
+                                     (512, 384, 128, 0, 0, 1), (2047, 1536, 128, 0, 0, 1),
+                                     (8000, 384, 128, 0, 0, 1), (9000, 384, 128, 0, 0, 1)]:
         A = torch.randn(M, K, generator=g)
         W = torch.randn(N, K, generator=g) * 0.1
         b = torch.randn(N, generator=g)
         R = torch.randn(M, N, generator=g)
-        want = A.double() @ W.double().t() + b.double() + R.double()
+        want = A.double() @ W.double().t()
+        if bias:
+            want = want + b.double()
+        if res:
+            want = want + R.double()
         if relu:
             want = want.clamp_min(0)
         Ad, Wd, bd, Rd = A.cuda(), W.cuda(), b.cuda(), R.cuda()
         Cd = torch.zeros(M, N, device="cuda")
-        hip.check(lib.vrp_gemm_nt(Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(),
-                                  Rd.data_ptr(), N, Cd.data_ptr(), N, M, N, K, relu,
+        hip.check(lib.vrp_gemm_nt(Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr() if bias else None,
+                                  Rd.data_ptr() if res else None, N, Cd.data_ptr(), N, M, N, K, relu,
                                   hip.current_stream()))
         err = (Cd.cpu().double() - want).abs().max().item()
-        assert err < 5e-5 * max(1.0, want.abs().max().item()), (M, N, K, err)
+        assert err < 5e-5 * max(1.0, want.abs().max().item()), (M, N, K, res, err)
 
 
 # ------------------------------------------------------------------ D1-D6: decoder
