@@ -709,10 +709,13 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       const float *n1 = ws.norm + (2 * l) * 384, *n2 = ws.norm + (2 * l + 1) * 384;
       // row tile: enough workgroups to occupy all 256 CUs at every batch size
       int r;
-      if (R >= 64 * 1024)
-        r = launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
-      else if (R > 16 * 1024)
+      static const char *rtw_env = getenv("VRP_BLOCK_RTW");  // A/B aid: "64" or "128"
+      if (rtw_env && rtw_env[0] == '6')
         r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (rtw_env && rtw_env[0] == '1')
+        r = launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows (8.83 vs
+        r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);  // 8.95 ms per 8192x40 rollout)
       else if (R > 12 * 1024)   // small batches: at most one workgroup per CU (256 CUs)
         r = launch_encoder_block16<4>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 8 * 1024)
