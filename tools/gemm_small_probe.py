@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""fp32 GEMM timings at small/medium M with K = 128 (20 launches replayed from a hipGraph per
+shape).  usage: gemm_small_probe.py [M1,M2,...]; VRP_GEMM_VARIANT=64x32 forces the tiled kernel."""
 import os, sys
 sys.path[:0] = ["/root/repo/vrp-gym_amd", "/root/repo"]
 import torch
