@@ -329,7 +329,10 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
             ou = trace[t]["u"]
             fin = torch.isfinite(ou)
             assert torch.equal(fin, torch.isfinite(u)), t
-            assert (u[fin] - ou[fin]).abs().max().item() < 2e-5, (t, (u[fin] - ou[fin]).abs().max())
+            # logits live in [-10, 10]; train-mode BatchNorm (batch statistics of rounded
+            # activations) amplifies fp32 re-association noise: up to 7.4e-5 seen in a 480-case sweep (tools/parity_sweep.py), 2e-5 in eval mode
+            assert (u[fin] - ou[fin]).abs().max().item() < (1e-4 if train else 2e-5), \
+                (t, (u[fin] - ou[fin]).abs().max())
     return res, exempt
 
 
