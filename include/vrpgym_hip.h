@@ -199,6 +199,15 @@ int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
 int vrp_draw_instances_device(uint64_t seed, uint64_t episode, int first_graph, int B, int N,
                               double *pos, int32_t *depot, double *demand, void *stream);
 
+/* R3' RandomAgent.forward (agents/random_agent.py:15-41) on the device for throughput runs:
+ * max_steps x (uniform draw among the unmasked nodes from the Philox stream + env.step),
+ * acc_loss (B) fp32 = sum of -distance, notdone (max_steps+1) per-step flags as in
+ * vrp_rollout_io, actions (max_steps,B) or NULL.  Same distribution as the reference's
+ * RandomAgent, not its numpy stream. */
+int vrp_random_rollout(const vrp_env *env, uint64_t seed, uint64_t episode, int first_graph,
+                       int max_steps, float *acc_loss, int32_t *notdone, int64_t *actions,
+                       void *stream);
+
 /* ---- backward pass (K4): building blocks, each unit-tested against torch autograd ---- */
 /* C (N1,N2) (+)= X^T Y over R rows; deterministic split-K; slab_ws from *_workspace_bytes. */
 int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);

@@ -611,3 +611,42 @@ def test_device_instance_generator():
     assert torch.isfinite(loss).all() and (loss < 0).all()
     t = TSPEnv(20, 64, 1, 5, generator="device")
     assert torch.isfinite(agents.TSPAgent(seed=69).evaluate(t)).all()
+
+
+def test_device_random_agent():
+    """RandomAgent(on_device=True): Philox draws on the GPU -- valid tours, the reference's
+    cost level, deterministic in the seed."""
+    import ctypes as C
+    import agents
+    import vrpgym_hip as hip
+    from gym_vrp.envs import IRPEnv, TSPEnv, VRPEnv
+    B, N = 2048, 20
+    env = TSPEnv(N, B, 1, 7, generator="device")
+    cost = -agents.RandomAgent(seed=3, on_device=True)(env)
+    assert cost.shape == (B,) and torch.isfinite(cost).all()
+    # N-1 uniform-random edges in the unit square: E[d] = 0.5214 each
+    assert abs(cost.mean().item() - (N - 1) * 0.5214) < 0.15
+    assert env.step_count == N - 1
+    # same seed and instances -> same tours; explicit action trace is a permutation
+    env2 = TSPEnv(N, B, 1, 7, generator="device")
+    assert torch.equal(-agents.RandomAgent(seed=3, on_device=True)(env2), cost)
+    env3 = TSPEnv(N, B, 1, 7, generator="device")
+    lib = hip.lib()
+    acc = torch.empty(B, device="cuda")
+    nd = torch.empty(N, dtype=torch.int32, device="cuda")
+    acts = torch.full((N - 1, B), -1, dtype=torch.int64, device="cuda")
+    cenv = env3._cenv()
+    hip.check(lib.vrp_random_rollout(C.byref(cenv), 3, 0, 0, N - 1, acc.data_ptr(), nd.data_ptr(),
+                                     acts.data_ptr(), hip.current_stream()))
+    assert torch.equal(-acc, cost)
+    a = acts.t().cpu().numpy()                                    # (B, N-1)
+    dep = env3._depot.cpu().numpy()
+    for bi in range(0, B, 97):
+        assert sorted(a[bi].tolist()) == [n for n in range(N) if n != dep[bi]]
+    # each first move is uniform over the N-1 customers
+    first = np.bincount(a[:, 0], minlength=N)
+    assert first.max() < 1.6 * B / (N - 1)
+    for Env in (VRPEnv, IRPEnv):
+        e = Env(N, 256, 1, 11, generator="device")
+        c = -agents.RandomAgent(seed=5, on_device=True)(e)
+        assert torch.isfinite(c).all() and (c > 0).all() and N <= e.step_count <= 2 * (N - 1)

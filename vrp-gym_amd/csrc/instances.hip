@@ -155,3 +155,67 @@ extern "C" int vrp_draw_instances_device(uint64_t seed, uint64_t episode, int fi
   VRP_CHECK_LAUNCH("draw_instances");
   return 0;
 }
+
+// ------------------------------------------------------------------ device-side random policy
+// RandomAgent.forward (agents/random_agent.py:15-41) for throughput runs: per step and graph
+// one node drawn uniformly among the unmasked ones, env.step on it, fp32 reward accumulation.
+// The draw comes from the Philox stream (counter = graph, step, episode), NOT from the
+// reference's global numpy stream, so tours differ from the host RandomAgent's; the
+// distribution is the same.  One wave per graph, same env code as every other kernel.
+#include "env_device.h"
+
+__global__ __launch_bounds__(256) void random_step_kernel(vrp_env e, uint64_t seed,
+                                                          uint64_t episode, int first_graph, int t,
+                                                          float *__restrict__ acc_loss,
+                                                          int32_t *__restrict__ notdone,
+                                                          int64_t *__restrict__ actions) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= e.B) return;
+  if (t > 0 && notdone[t - 1] == 0) return;  // batch-wide done (tsp.py:95): exact no-op
+  const int N = e.N, par = t & 1;
+  const uint8_t *mask_in = e.mask + (size_t)par * e.B * N + (size_t)b * N;
+  const bool s0 = lane < N && mask_in[lane] == 0;
+  const bool s1 = lane + 64 < N && mask_in[lane + 64] == 0;
+  const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+  const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);  // >= 1: a feasible action always exists
+  uint32_t c[4] = {(uint32_t)(first_graph + b), (uint32_t)t, (uint32_t)episode,
+                   ((uint32_t)(episode >> 32) << 2) | 3u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  int k = (int)(u53(c[0], c[1]) * (double)cnt);
+  if (k >= cnt) k = cnt - 1;
+  unsigned long long bits = k < c0 ? m0 : m1;
+  int kk = k < c0 ? k : k - c0;
+  for (int i = 0; i < kk; ++i) bits &= bits - 1;
+  const int a = (k < c0 ? 0 : 64) + __ffsll((long long)bits) - 1;
+  EnvStepOut o = env_step_wave(e, b, a, lane, e.mask + (size_t)(par ^ 1) * e.B * N);
+  if (lane == 0) {
+    acc_loss[b] = (t == 0 ? 0.f : acc_loss[b]) + (float)(-o.dist);  // random_agent.py:39
+    if (!o.done) notdone[t] = 1;
+    if (actions) actions[(size_t)t * e.B + b] = a;
+  }
+}
+
+__global__ void random_init_kernel(int32_t *notdone, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) notdone[i] = 0;
+}
+
+extern "C" int vrp_random_rollout(const vrp_env *env, uint64_t seed, uint64_t episode,
+                                  int first_graph, int max_steps, float *acc_loss,
+                                  int32_t *notdone, int64_t *actions, void *stream) {
+  VRP_REQUIRE(env && acc_loss && notdone, "random_rollout: NULL argument");
+  VRP_REQUIRE(env->B > 0 && env->N >= 2 && env->N <= VRP_MAX_NODES && max_steps > 0,
+              "random_rollout: bad shape B=%d N=%d steps=%d", env->B, env->N, max_steps);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(random_init_kernel, dim3((max_steps + 256) / 256), dim3(256), 0, st, notdone,
+                     max_steps + 1);
+  VRP_CHECK_LAUNCH("random_init");
+  if (int r = vrp_env_mask(env, 0, stream)) return r;  // state = env.get_state()
+  for (int t = 0; t < max_steps; ++t) {
+    hipLaunchKernelGGL(random_step_kernel, dim3((env->B + 3) / 4), dim3(256), 0, st, *env, seed,
+                       episode, first_graph, t, acc_loss, notdone, actions);
+    VRP_CHECK_LAUNCH("random_step");
+  }
+  return 0;
+}

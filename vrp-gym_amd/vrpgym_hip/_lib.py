@@ -102,6 +102,7 @@ def _declare(lib):
                                     i32, i32, vp]),
         "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "vrp_draw_instances_device": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, vp, vp, vp, vp]),
+        "vrp_random_rollout": (i32, [P(Env), C.c_uint64, C.c_uint64, i32, i32, vp, vp, vp, vp]),
         "vrp_encoder_tape_bytes": (i64, [i32, i32, i32, i32]),
         "vrp_encoder_forward_tape": (i32, [P(EncoderWeights), i32, i32, vp, vp, vp, vp, i32, vp]),
         "vrp_encoder_backward_workspace_bytes": (i64, [i32, i32, i32]),
