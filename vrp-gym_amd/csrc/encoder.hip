@@ -110,6 +110,165 @@ __global__ __launch_bounds__(256) void encoder_attention_kernel(const float *__r
   }
 }
 
+// ---- small batches (B*N <= 16384, N <= 64): in_proj + attention of one graph in ONE launch ----
+// At ~10 k rows the QKV GEMM and the attention kernel are two launch-latency-bound launches
+// with an HBM round trip of the (R,384) projections between them.  Here one workgroup owns
+// one graph: the (N,128) input tile goes to LDS, the four waves project it onto the 384
+// in_proj columns in eight 48-column blocks on v_mfma_f32_16x16x4_f32 (A = input rows from
+// LDS, B = 48 weight rows straight from L2 into registers, K = 128 split over the four
+// 16-lane groups), the projections stay in LDS, and each wave then runs two heads of the
+// attention exactly like encoder_attention_kernel.  (At large B*N the weight re-read per
+// graph -- 196 KB -- would dominate; the GEMM path stays in charge there.)
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+#define QA_XLD 132
+#define QA_QLD 388
+
+template <int NTMAX>
+__global__ __launch_bounds__(256, 1) void encoder_qkv_attention_kernel(
+    const float *__restrict__ x, const float *__restrict__ Win, const float *__restrict__ bin,
+    float *__restrict__ att, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *X_s = smem;                          // [NTMAX*16][QA_XLD]
+  float *Q_s = smem + NTMAX * 16 * QA_XLD;    // [NTMAX*16][QA_QLD]  q | k | v of every node
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int NT = (N + 15) >> 4;
+  for (int idx = tid; idx < NT * 16 * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < N) v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + r) * VRP_EMB + c4);
+    *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = v;
+  }
+  __syncthreads();
+  // ---- in_proj: wave w owns column blocks w and w + 4 (48 columns each); the weight rows of
+  //      the second block are loaded while the first one is on the matrix cores ----------------
+  auto load_w = [&](float (&w)[3][32], int blk) {
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      const float *wr = Win + (size_t)(blk * 48 + ct * 16 + i16) * VRP_EMB + 32 * q;
+#pragma unroll
+      for (int s = 0; s < 32; s += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(wr + s);
+        w[ct][s] = t.x; w[ct][s + 1] = t.y; w[ct][s + 2] = t.z; w[ct][s + 3] = t.w;
+      }
+    }
+  };
+  auto project = [&](const float (&w)[3][32], int blk) {
+    f32x4q acc[NTMAX][3];
+#pragma unroll
+    for (int rt = 0; rt < NTMAX; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      float4 a[NTMAX];
+#pragma unroll
+      for (int rt = 0; rt < NTMAX; ++rt)
+        a[rt] = (rt < NT)
+                    ? *reinterpret_cast<const float4 *>(X_s + (rt * 16 + i16) * QA_XLD + 32 * q + s)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int rt = 0; rt < NTMAX; ++rt)
+        if (rt < NT) {
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) {
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[ct][s], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[ct][s + 1], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[ct][s + 2], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[ct][s + 3], acc[rt][ct], 0, 0, 0);
+          }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      const int col = blk * 48 + ct * 16 + i16;
+      const float bb = bin[col];
+#pragma unroll
+      for (int rt = 0; rt < NTMAX; ++rt)
+        if (rt < NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)  // D: row = 4*(lane>>4) + r, col = lane & 15
+            Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb;
+        }
+    }
+  };
+  float w0[3][32], w1[3][32];
+  load_w(w0, wave);       // (issued before the tile barrier would be even better; the tile
+  load_w(w1, wave + 4);   //  loads above are short)
+  project(w0, wave);
+  project(w1, wave + 4);
+  __syncthreads();
+  // ---- attention (graph_encoder.py:170-172,196): wave w runs heads 2w and 2w+1, lane = query;
+  //      for N <= 32 both heads at once, one per 32-lane half -------------------------------------
+  const int halves = (N <= 32) ? 1 : 2;
+  for (int hh = 0; hh < halves; ++hh) {
+    const int h = wave * 2 + ((N <= 32) ? (lane >> 5) : hh);
+    const int i = (N <= 32) ? (lane & 31) : lane;
+    if (i < N) {
+      float qv[16];
+#pragma unroll
+      for (int d = 0; d < 16; d += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(Q_s + i * QA_QLD + h * 16 + d);
+        qv[d] = t.x * 0.25f; qv[d + 1] = t.y * 0.25f; qv[d + 2] = t.z * 0.25f; qv[d + 3] = t.w * 0.25f;
+      }
+      float m = -INFINITY, l = 0.f, o[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) o[d] = 0.f;
+      for (int j = 0; j < N; ++j) {
+        float kk[16], vv[16];
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) {
+          const float4 tk = *reinterpret_cast<const float4 *>(Q_s + j * QA_QLD + 128 + h * 16 + d);
+          const float4 tv = *reinterpret_cast<const float4 *>(Q_s + j * QA_QLD + 256 + h * 16 + d);
+          kk[d] = tk.x; kk[d + 1] = tk.y; kk[d + 2] = tk.z; kk[d + 3] = tk.w;
+          vv[d] = tv.x; vv[d + 1] = tv.y; vv[d + 2] = tv.z; vv[d + 3] = tv.w;
+        }
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) sc = fmaf(qv[d], kk[d], sc);
+        if (sc > m) {
+          const float corr = expf(m - sc);
+          l *= corr;
+#pragma unroll
+          for (int d = 0; d < 16; ++d) o[d] *= corr;
+          m = sc;
+        }
+        const float pw = expf(sc - m);
+        l += pw;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] = fmaf(pw, vv[d], o[d]);
+      }
+      const float inv = 1.f / l;
+      float *dst = att + ((size_t)b * N + i) * VRP_EMB + h * 16;
+#pragma unroll
+      for (int d = 0; d < 16; d += 4)
+        *reinterpret_cast<float4 *>(dst + d) =
+            make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+  }
+}
+
+template <int NTMAX>
+static int launch_qkv_attention(const float *x, const float *Win, const float *bin, float *att,
+                                int B, int N, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)NTMAX * 16 * (QA_XLD + QA_QLD);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_qkv_attention_kernel<NTMAX>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("qkv_attention: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(encoder_qkv_attention_kernel<NTMAX>, dim3(B), dim3(256), lds, st, x, Win, bin,
+                     att, N);
+  VRP_CHECK_LAUNCH("encoder_qkv_attention");
+  return 0;
+}
+
 // ---- BatchNorm1d(128) over the flattened (B*N,128) view (graph_encoder.py:141-154) ---
 // stats: fp64 column sums of x and x^2 (two 128-vectors), zeroed by the caller.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, int rows,
@@ -697,11 +856,21 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
     // out = bn1(x + MHA(x))
-    if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
-                                   ws.qkv, 384, R, 384, 128, 0, st)) return r;
-    const size_t lds = (size_t)4 * N * 32 * sizeof(float);
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
-    VRP_CHECK_LAUNCH("encoder_attention");
+    static const char *qa_off = getenv("VRP_UNFUSED_QKV");  // A/B aid
+    if (N <= 64 && R <= 16 * 1024 && !qa_off) {
+      // small batches: in_proj + attention of a graph in one launch
+      int r;
+      if (N <= 32) r = launch_qkv_attention<2>(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st);
+      else if (N <= 48) r = launch_qkv_attention<3>(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st);
+      else r = launch_qkv_attention<4>(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st);
+      if (r) return r;
+    } else {
+      if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
+                                     ws.qkv, 384, R, 384, 128, 0, st)) return r;
+      const size_t lds = (size_t)4 * N * 32 * sizeof(float);
+      hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
+      VRP_CHECK_LAUNCH("encoder_attention");
+    }
     static const char *unfused = getenv("VRP_ENCODER_UNFUSED");  // A/B aid
     if (!train && !unfused) {
       // eval: out-proj + BN1 + FF + BN2 in one kernel, activations stay in LDS
