@@ -123,25 +123,13 @@ typedef float f32x4q __attribute__((ext_vector_type(4)));
 #define QA_XLD 132
 #define QA_QLD 388
 
+// in_proj of one graph: X_s (NT*16 x 128, LDS) -> Q_s (q | k | v, LDS)
 template <int NTMAX>
-__global__ __launch_bounds__(256, 1) void encoder_qkv_attention_kernel(
-    const float *__restrict__ x, const float *__restrict__ Win, const float *__restrict__ bin,
-    float *__restrict__ att, int N) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *X_s = smem;                          // [NTMAX*16][QA_XLD]
-  float *Q_s = smem + NTMAX * 16 * QA_XLD;    // [NTMAX*16][QA_QLD]  q | k | v of every node
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
+__device__ __forceinline__ void qa_stage_project(const float *X_s, float *Q_s,
+                                                 const float *__restrict__ Win,
+                                                 const float *__restrict__ bin, int NT, int lane,
+                                                 int wave) {
   const int i16 = lane & 15, q = lane >> 4;
-  const int NT = (N + 15) >> 4;
-  for (int idx = tid; idx < NT * 16 * 32; idx += 256) {
-    const int r = idx >> 5, c4 = (idx & 31) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < N) v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + r) * VRP_EMB + c4);
-    *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = v;
-  }
-  __syncthreads();
   // ---- in_proj: wave w owns column blocks w and w + 4 (48 columns each); the weight rows of
   //      the second block are loaded while the first one is on the matrix cores ----------------
   auto load_w = [&](float (&w)[3][32], int blk) {
@@ -199,7 +187,11 @@ __global__ __launch_bounds__(256, 1) void encoder_qkv_attention_kernel(
   load_w(w1, wave + 4);   //  loads above are short)
   project(w0, wave);
   project(w1, wave + 4);
-  __syncthreads();
+}
+
+// attention of one graph from Q_s; row i of the result goes to out + i*out_ld (global or LDS)
+__device__ __forceinline__ void qa_stage_attention(const float *Q_s, int N, float *out, int out_ld,
+                                                   int lane, int wave) {
   // ---- attention (graph_encoder.py:170-172,196): wave w runs heads 2w and 2w+1, lane = query;
   //      for N <= 32 both heads at once, one per 32-lane half -------------------------------------
   const int halves = (N <= 32) ? 1 : 2;
@@ -241,13 +233,36 @@ __global__ __launch_bounds__(256, 1) void encoder_qkv_attention_kernel(
         for (int d = 0; d < 16; ++d) o[d] = fmaf(pw, vv[d], o[d]);
       }
       const float inv = 1.f / l;
-      float *dst = att + ((size_t)b * N + i) * VRP_EMB + h * 16;
+      float *dst = out + (size_t)i * out_ld + h * 16;
 #pragma unroll
       for (int d = 0; d < 16; d += 4)
         *reinterpret_cast<float4 *>(dst + d) =
             make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
     }
   }
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(256, 1) void encoder_qkv_attention_kernel(
+    const float *__restrict__ x, const float *__restrict__ Win, const float *__restrict__ bin,
+    float *__restrict__ att, int N) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *X_s = smem;                          // [NTMAX*16][QA_XLD]
+  float *Q_s = smem + NTMAX * 16 * QA_XLD;    // [NTMAX*16][QA_QLD]  q | k | v of every node
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  const int NT = (N + 15) >> 4;
+  for (int idx = tid; idx < NT * 16 * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < N) v = *reinterpret_cast<const float4 *>(x + ((size_t)b * N + r) * VRP_EMB + c4);
+    *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = v;
+  }
+  __syncthreads();
+  qa_stage_project<NTMAX>(X_s, Q_s, Win, bin, NT, lane, wave);
+  __syncthreads();
+  qa_stage_attention(Q_s, N, att + (size_t)b * N * VRP_EMB, VRP_EMB, lane, wave);
 }
 
 template <int NTMAX>
@@ -535,35 +550,18 @@ __device__ __forceinline__ void eb16_mma(f32x4v (&acc)[RT16][2], const float *ab
   }
 }
 
+// The stages of the fused block on a tile already in LDS: bufA = attention output (later the
+// hidden-layer slices), bufB = layer input (y1 in place); wa holds the Wo fragment.  Rows
+// [0, valid_rows) of the result go to y_tile (global, row stride 128).
 template <int RT16>
-__global__ __launch_bounds__(256, 1) void encoder_block16_kernel(
-    const float *__restrict__ att, const float *__restrict__ x, const float *__restrict__ Wo,
-    const float *__restrict__ bo, const float *__restrict__ norm1, const float *__restrict__ W1,
-    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
-    const float *__restrict__ norm2, float *__restrict__ y, int rows, int hidden) {
-  constexpr int RTW = 16 * RT16;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *bufA = smem;                 // att tile, then the hidden-layer slices
-  float *bufB = smem + RTW * EB_LD;   // x tile, then y1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * RTW;
+__device__ __forceinline__ void eb16_block_stages(
+    float *bufA, float *bufB, float (&wa)[2][32], const float *__restrict__ bo,
+    const float *__restrict__ norm1, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ norm2,
+    float *__restrict__ y_tile, int valid_rows, int hidden, int lane, int wave) {
   const int i16 = lane & 15, q = lane >> 4;
-  const int col[2] = {wave * 32 + i16, wave * 32 + 16 + i16};   // this lane's weight rows / D columns
-
-  float wa[2][32], wb[2][32];
-  eb16_load_w(wa, Wo + (size_t)col[0] * 128 + 32 * q, Wo + (size_t)col[1] * 128 + 32 * q);
-  for (int idx = tid; idx < RTW * 32; idx += 256) {
-    const int r = idx >> 5, c4 = (idx & 31) * 4;
-    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
-    if (row0 + r < rows) {
-      va = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
-      vx = *reinterpret_cast<const float4 *>(x + (size_t)(row0 + r) * 128 + c4);
-    }
-    *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = va;
-    *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = vx;
-  }
-  __syncthreads();
-
+  const int col[2] = {wave * 32 + i16, wave * 32 + 16 + i16};
+  float wb[2][32];
   f32x4v acc[RT16][2], gacc[RT16][2];
 #pragma unroll
   for (int rt = 0; rt < RT16; ++rt)
@@ -628,12 +626,44 @@ __global__ __launch_bounds__(256, 1) void encoder_block16_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rt * 16 + 4 * q + r;
-        if (row0 + row < rows) {
+        if (row < valid_rows) {
           const float v = gacc[rt][ct][r] + bb + bufB[row * EB_LD + c];
-          y[(size_t)(row0 + row) * 128 + c] = (v - mean) * mult + beta;
+          y_tile[(size_t)row * 128 + c] = (v - mean) * mult + beta;
         }
       }
   }
+}
+
+template <int RT16>
+__global__ __launch_bounds__(256, 1) void encoder_block16_kernel(
+    const float *__restrict__ att, const float *__restrict__ x, const float *__restrict__ Wo,
+    const float *__restrict__ bo, const float *__restrict__ norm1, const float *__restrict__ W1,
+    const float *__restrict__ b1, const float *__restrict__ W2, const float *__restrict__ b2,
+    const float *__restrict__ norm2, float *__restrict__ y, int rows, int hidden) {
+  constexpr int RTW = 16 * RT16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufA = smem;                 // att tile, then the hidden-layer slices
+  float *bufB = smem + RTW * EB_LD;   // x tile, then y1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * RTW;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int col[2] = {wave * 32 + i16, wave * 32 + 16 + i16};   // this lane's weight rows / D columns
+
+  float wa[2][32];
+  eb16_load_w(wa, Wo + (size_t)col[0] * 128 + 32 * q, Wo + (size_t)col[1] * 128 + 32 * q);
+  for (int idx = tid; idx < RTW * 32; idx += 256) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
+    if (row0 + r < rows) {
+      va = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+      vx = *reinterpret_cast<const float4 *>(x + (size_t)(row0 + r) * 128 + c4);
+    }
+    *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = va;
+    *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = vx;
+  }
+  __syncthreads();
+  eb16_block_stages<RT16>(bufA, bufB, wa, bo, norm1, W1, b1, W2, b2, norm2,
+                          y + (size_t)row0 * 128, rows - row0, hidden, lane, wave);
 }
 
 template <int RT16>
