@@ -69,11 +69,7 @@ def make(kind, N, B, seed, device):
 
 def rewind(env):
     """Start-of-episode state on the SAME resident instances (device memsets only)."""
-    env._visited.zero_()
-    env._cur.copy_(env._depot)
-    env._load.fill_(1.0)
-    env._parity = 0
-    env._mask_fresh = False
+    env._reset_state()
     env._step_count = 0
     env._last_rollout = None
 

@@ -47,6 +47,11 @@ typedef struct vrp_env {
   double *load;          /* (B)    IRPEnv.load (fp64), unused otherwise            */
 } vrp_env;
 
+/* E1  The state part of TSPEnv.reset / generate_graphs (tsp.py:150-160,172-174; irp.py:47,184)
+ * for instances already in place: visited := 0, mask buffers := 0, current_location :=
+ * depots, load := 1 (when env->load is set). */
+int vrp_env_reset(const vrp_env *env, void *stream);
+
 /* E7/E8  TSPEnv.generate_mask tsp.py:131-148 / vrp.py:13-37 / irp.py:126-155.
  * Applies the depot fix-ups to `visited` in place and writes mask buffer `parity`. */
 int vrp_env_mask(const vrp_env *env, int parity, void *stream);

@@ -39,6 +39,22 @@ __global__ __launch_bounds__(256) void env_features_kernel(vrp_env e, float *x, 
   is_depot[i] = (n == e.depot[b]) ? 1 : 0;
 }
 
+// Start-of-episode state in one launch: visited := 0, both mask buffers := 0,
+// current_location := depots, load := 1 (tsp.py:150-160,172-174, irp.py:47,184).
+__global__ __launch_bounds__(256) void env_reset_kernel(vrp_env e) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = e.B * e.N;
+  if (i < total) {
+    e.visited[i] = 0;
+    e.mask[i] = 0;
+    e.mask[(size_t)total + i] = 0;
+  }
+  if (i < e.B) {
+    e.cur[i] = e.depot[i];
+    if (e.load) e.load[i] = 1.0;
+  }
+}
+
 static int check_env(const vrp_env *env) {
   VRP_REQUIRE(env != nullptr, "env is NULL");
   VRP_REQUIRE(env->kind >= 0 && env->kind <= 2, "env.kind %d out of range", env->kind);
@@ -76,5 +92,14 @@ extern "C" int vrp_env_features(const vrp_env *env, float *x, uint8_t *is_depot,
   hipLaunchKernelGGL(env_features_kernel, dim3((total + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, *env, x, is_depot);
   VRP_CHECK_LAUNCH("env_features");
+  return 0;
+}
+
+extern "C" int vrp_env_reset(const vrp_env *env, void *stream) {
+  if (int r = check_env(env)) return r;
+  const int total = env->B * env->N;
+  hipLaunchKernelGGL(env_reset_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     *env);
+  VRP_CHECK_LAUNCH("env_reset");
   return 0;
 }

@@ -123,10 +123,12 @@ class TSPEnv(GymEnv):
                                       _arrays=(pos[s], depots[s], demands[s]))
             self._depots_host = self.sampler.get_depots()
             self._upload_instances()
-        self._visited.zero_()
-        self._mask.zero_()
-        self._cur.copy_(self._depot)
-        self._load.fill_(1.0)
+        self._reset_state()
+
+    def _reset_state(self):
+        """Start-of-episode state on the instances in place (one launch)."""
+        from vrpgym_hip import check
+        check(self._lib.vrp_env_reset(self._cenv(), self._stream()))
         self._parity = 0
         self._mask_fresh = False
 

@@ -84,6 +84,7 @@ def _declare(lib):
     i32, i64, vp = C.c_int, C.c_int64, C.c_void_p
     P = C.POINTER
     sig = {
+        "vrp_env_reset": (i32, [P(Env), vp]),
         "vrp_env_mask": (i32, [P(Env), i32, vp]),
         "vrp_env_step": (i32, [P(Env), vp, i32, vp, vp, vp]),
         "vrp_env_features": (i32, [P(Env), vp, vp, vp]),
