@@ -251,16 +251,20 @@ def test_decoder_teacher_forced(name, path):
 # ------------------------------------------------------------------ R1: rollouts
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
                      ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
-                     throughput_kernel=False):
-    """HIP rollout vs oracle (and vs reference outputs when given)."""
+                     throughput_kernel=False, agent=None):
+    """HIP rollout vs oracle (and vs reference outputs when given).  `agent`: use this
+    (e.g. trained) agent's weights on both sides instead of the seed's initial ones."""
     from oracle import envs as oenv
     from oracle import policy as opol
     from agents import runtime
-    agent = _agents()[kind](seed=agent_seed)
+    if agent is None:
+        agent = _agents()[kind](seed=agent_seed)
+        sd, _ = opol.init_state_dicts(kind, agent_seed)
+    else:
+        sd = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
     model = agent.model
     model.train(train)
     env = _envs()[kind](N, B, 1, env_seed)
-    sd, _ = opol.init_state_dicts(kind, agent_seed)
     oe = oenv.OracleEnv(kind, N, B, 1, env_seed)
     trace = []
     torch.manual_seed(torch_seed)
@@ -650,3 +654,21 @@ def test_device_random_agent():
         e = Env(N, 256, 1, 11, generator="device")
         c = -agents.RandomAgent(seed=5, on_device=True)(e)
         assert torch.isfinite(c).all() and (c > 0).all() and N <= e.step_count <= 2 * (N - 1)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_rollout_parity_with_trained_weights(kind, tmp_path):
+    """After some REINFORCE epochs the weights (and the BatchNorm running statistics) have
+    left their initial values and the glimpse scores are larger: the HIP rollout still
+    matches the oracle run on the SAME trained state dict, greedy and sampled."""
+    import logging
+    logging.disable(logging.CRITICAL)
+    agent = _agents()[kind](seed=69, csv_path=str(tmp_path / "log.csv"))
+    env = _envs()[kind](20, 128, 1, 69)
+    agent.train(env, epochs=40, check_point_dir=str(tmp_path) + "/")
+    logging.disable(logging.NOTSET)
+    moved = (agent.model.decoder._kp.weight - _agents()[kind](seed=69).model.decoder._kp.weight)
+    assert moved.abs().max().item() > 1e-4
+    for greedy in (True, False):
+        _compare_rollout(kind, 64, 20, greedy, 321, 69, 17, agent=agent)
+    _compare_rollout(kind, 33, 40, True, 322, 69, 18, agent=agent, throughput_kernel=True)
