@@ -4,21 +4,39 @@
 Metric (BASELINE.json): env-steps/sec in node-steps (batch x nodes x steps / s) on
 TSP-20, batch 512 per GPU, greedy rollout of the untrained seed-69 attention agent
 (configs[1]).  One bench "step" = one complete rollout of one batch: encoder + T
-fused decode/env steps, instances already resident in HBM.  Weak scaling: every
-rank runs its own 512-graph batch; the value is the whole-job aggregate.
+fused decode/env steps, instances already resident in HBM.  Weak scaling: rank r owns
+rows [512 r, 512 (r+1)) of ONE seed-ordered instance stream of 512 x N graphs
+(`Env(shard=(rank, world))`); the value is the whole-job aggregate.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 launches the N ranks itself (a `python -m torch.distributed.run`
+child process, started before this process touches the GPU) unless it already runs under
+torchrun (RANK/WORLD_SIZE set).  Workloads:
+
+    tsp20_b512         BASELINE configs[1], greedy rollout (default: the metric's config)
+    tsp40_b8192        north-star shape, greedy rollout
+    vrp40_b2048        greedy rollout
+    vrp100_b2048       configs[4] per-GPU shard, sampling rollout
+    vrp40_b2048_train  configs[2]: REINFORCE epochs (2 sampled rollouts, HIP backward, Adam,
+                       2 greedy rollouts + paired t-test), step = one epoch
+    irp40_b1024_train  configs[3] per-GPU shard: the same with the RCCL all-reduce of the
+                       flat gradient; its time is reported separately
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline            decode_step kernel of the benched workload vs HBM peak
-  roofline_north_star the same kernel at 8192 x 40 (the north-star target shape), TSP;
-                      roofline_north_star_vrp: VRP at the same shape
+  roofline            the decode_step kernel of the benched workload vs the HBM peak, plus
+                      the loop-level (prologue + table builds + steps) and whole-rollout
+                      fractions on the same algorithmic bytes
+  roofline_north_star the same at 8192 x 40 TSP (the north-star target shape);
+  roofline_north_star_vrp / roofline_cfg5: VRP 8192 x 40 greedy, VRP 2048 x 100 sampling
+  other_configs       short runs of the training / sampling configs (ms per step)
   cpu_baseline        the CPU oracle (oracle/, a port of the reference) on this host
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,28 +45,58 @@ for p in (os.path.join(ROOT, "vrp-gym_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import logging  # noqa: E402
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+logging.getLogger().setLevel(logging.WARNING)  # the agents log every epoch at INFO
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.3 TB/s achievable
 
 WORKLOADS = {
-    # name: (kind, nodes, batch per GPU, greedy)
-    "tsp20_b512": (0, 20, 512, True),       # BASELINE configs[1] (the metric's config)
-    "tsp40_b8192": (0, 40, 8192, True),     # north-star shape
-    "vrp40_b2048": (1, 40, 2048, True),
-    "vrp100_b2048": (1, 100, 2048, False),  # configs[4] per-GPU shard, sampling
+    # name: (kind, nodes, batch per GPU, mode)
+    "tsp20_b512": (0, 20, 512, "greedy"),       # BASELINE configs[1] (the metric's config)
+    "tsp40_b8192": (0, 40, 8192, "greedy"),     # north-star shape
+    "vrp40_b2048": (1, 40, 2048, "greedy"),
+    "vrp100_b2048": (1, 100, 2048, "sample"),   # configs[4] per-GPU shard
+    "vrp40_b2048_train": (1, 40, 2048, "train"),  # configs[2]
+    "irp40_b1024_train": (2, 40, 1024, "train"),  # configs[3] per-GPU shard
 }
+KIND_NAMES = "TSP VRP IRP".split()
 
 
+# ---------------------------------------------------------------------- multi-rank launch
+def spawn_ranks(a, argv):
+    """--gpus N outside torchrun: start the N ranks as a CHILD process group and relay its
+    exit code.  Nothing in this process has initialised the GPU (device_count() does not)."""
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if ndev < a.gpus and env.get("VRPGYM_BENCH_ONE_GPU") != "1":
+        sys.exit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible "
+                 "(VRPGYM_BENCH_ONE_GPU=1 maps every rank to cuda:0 over gloo: a test aid, "
+                 "flagged in the JSON line)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+# ---------------------------------------------------------------------- helpers
 def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            return json.load(fh)["workloads"][workload]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                return json.load(fh)["workloads"][workload]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
 def algorithmic_bytes_per_step(B, N):
@@ -56,51 +104,103 @@ def algorithmic_bytes_per_step(B, N):
     return B * (523 * N + 72)
 
 
-def make(kind, N, B, seed, device):
+def make(kind, N, B, seed, device, shard=None, generator="numpy"):
     import agents
     from gym_vrp.envs import IRPEnv, TSPEnv, VRPEnv
+    logging.getLogger().setLevel(logging.WARNING)  # the agents' module sets INFO on import
     Env = (TSPEnv, VRPEnv, IRPEnv)[kind]
     Agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
-    env = Env(num_nodes=N, batch_size=B, num_draw=1, seed=seed, device=device)
-    agent = Agent(seed=69)
+    gb = B * (shard[1] if shard else 1)
+    env = Env(num_nodes=N, batch_size=gb, num_draw=1, seed=seed, device=device, shard=shard,
+              generator=generator)
+    agent = Agent(seed=69, csv_path=os.devnull)
     agent.model.eval()
     return env, agent
 
 
 def rewind(env):
-    """Start-of-episode state on the SAME resident instances (device memsets only)."""
+    """Start-of-episode state on the SAME resident instances (one device launch)."""
     env._reset_state()
     env._step_count = 0
     env._last_rollout = None
 
 
-def timed_rollouts(env, agent, greedy, steps, warmup, dist):
+def sync_barrier(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def timed_rollouts(env, agent, greedy, steps, warmup, dist, reset=None):
+    """K rollouts between barrier + synchronize brackets.  reset=None: instances stay
+    resident (the headline); "env": env.reset() (new instances) before every rollout."""
     from agents import runtime
+
+    def one():
+        if reset == "env":
+            env.reset(return_state=False)
+        else:
+            rewind(env)
+        return runtime.rollout(agent.model, env, greedy)
+
     res = None
     with torch.no_grad():
-        for _ in range(warmup):
-            rewind(env)
-            res = runtime.rollout(agent.model, env, greedy)
-        T = res.T if res is not None else None
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        for _ in range(max(warmup, 1)):
+            res = one()
+        sync_barrier(dist)
         t0 = time.perf_counter()
         for _ in range(steps):
-            rewind(env)
-            res = runtime.rollout(agent.model, env, greedy)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            res = one()
+        sync_barrier(dist)
         dt = time.perf_counter() - t0
     return dt, res.T, float(-res.acc_loss.mean().item())
 
 
+def timed_training(env, agent, steps, warmup, dist):
+    """K training epochs (TSPAgent.train_epoch: graph_tsp_agent.py:174-189 of the reference)
+    between the same brackets.  Returns (seconds, env steps taken by all rollouts of the
+    timed epochs on this rank, mean sampled cost of the last epoch, all-reduce ms/epoch)."""
+    from agents import distributed, runtime
+    from scipy import stats  # noqa: F401  (first import outside the timed region)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):  # "replacing baceline" must not hit the JSON
+        for _ in range(max(warmup, 1)):
+            agent.train_epoch(env, 1)
+        sync_barrier(dist)
+        runtime.ROLLOUT_LOG = log = []
+        distributed.ALLREDUCE_EVENTS = evs = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, cost, _ = agent.train_epoch(env, 1)
+        sync_barrier(dist)
+        dt = time.perf_counter() - t0
+    runtime.ROLLOUT_LOG = distributed.ALLREDUCE_EVENTS = None
+    sum_T = sum(r.T for r in log)  # env steps per graph over every rollout of the timed epochs
+    ar_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)
+    return dt, sum_T, len(log) // max(steps, 1), float(-cost.item()), ar_ms
+
+
+def _event():
+    return torch.cuda.Event(enable_timing=True)
+
+
 def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_step=False):
-    """Average duration of ONE decode_step launch, HIP events on the launch stream
-    around every launch (the stream the library launches on is torch's current one)."""
+    """Timing of the decode+env step on the library's launch stream (torch's current one),
+    HIP events only:
+
+    avg_launch_us     the step kernel itself: the launches the product's own C loop issues
+                      (vrp_rollout_steps_range), step 0 in one event pair and steps 1..T-1
+                      back to back in another, the once-per-episode table build between
+                      them untimed; = kernel time + the ~1 us kernel-to-kernel boundary.
+                      This is the figure `achieved`/`frac` use; rocprofv3's average duration
+                      of the same kernel (profiles/) must agree with it.
+    loop_us_per_step  (prologue + step loop incl. the first-node table build and the no-op
+                      launches after `done`) / T, one event pair: what a step costs the
+                      decode loop once the work hoisted out of it is charged to it.
+    rollout_us        the whole vrp_rollout (encoder + prologue + loop), one event pair.
+    event_pair_per_launch_us  an event pair around EVERY launch, driven from Python (adds
+                      ~2.5 us of record/launch/record per launch; kept as a cross-check)."""
     import ctypes as C
     import vrpgym_hip as hip
     from agents import runtime
@@ -113,7 +213,7 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
     max_steps = res.max_steps
     ew, dw = runtime.encoder_struct(model.encoder), runtime.decoder_struct(model.decoder)
     derived = runtime.decoder_derived(model.decoder, kind)
-    dec_ws = runtime._buf("dec", device, 0)
+    enc_ws, dec_ws = runtime.workspaces(model, env)
     io = hip.RolloutIO()
     io.acc_loss, io.acc_logp = res.acc_loss.data_ptr(), res.acc_logp.data_ptr()
     io.notdone = res.notdone.data_ptr()
@@ -122,96 +222,102 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
         noise = torch.empty((max_steps, B, N), device=device).exponential_(1)
         io.noise = noise.data_ptr()
     stream = hip.current_stream(device)
-    durs = []
-    for _ in range(reps):
+    sflags = (0 if greedy else 1) | extra_flags
+    args = (kind, derived.data_ptr(), C.byref(dw))
+    tail = (res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io))
+
+    def start_episode():
         rewind(env)
         cenv = env._cenv()
         hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
         hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
-                                          dec_ws.data_ptr(), stream))  # resets the score rows
+                                          dec_ws.data_ptr(), stream))
         res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(T)]
+        return cenv
+
+    pairs = []
+    for _ in range(reps):
+        cenv = start_episode()
+        evs = [(_event(), _event()) for _ in range(T)]
         for t in range(T):
             evs[t][0].record()
-            hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
-                                          res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
-                                          max_steps, (0 if greedy else 1) | 8 | extra_flags, stream))
+            hip.check(lib.vrp_decode_step(*args, C.byref(cenv), *tail, t, max_steps,
+                                          sflags | 8, stream))
             evs[t][1].record()
             if t == 0:  # the once-per-episode first-node fold: other kernels, outside the pair
                 hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N,
                                                    res.emb.data_ptr(), dec_ws.data_ptr(), stream))
         torch.cuda.synchronize()
-        durs += [a.elapsed_time(b) * 1e-3 for a, b in evs]
-    # primary figure: the library's own step loop (vrp_rollout_steps: T launches issued
-    # from C, no Python between them) bracketed by ONE HIP event pair on the launch stream.
-    # Per-launch event pairs driven from Python leave the GPU idle between launches and
-    # over-state very short kernels; both are reported.
+        pairs += [a.elapsed_time(b) * 1e-3 for a, b in evs]
+    if per_step:  # tuning aid: mean duration of step t over the repetitions
+        return [round(float(np.mean(pairs[t::T])) * 1e6, 2) for t in range(T)]
+
+    kern = []
+    for _ in range(reps):
+        cenv = start_episode()
+        ev = [_event() for _ in range(4)]
+        ev[0].record()
+        hip.check(lib.vrp_rollout_steps_range(*args, C.byref(cenv), *tail, 0, 1, max_steps,
+                                              sflags | 8, stream))
+        ev[1].record()
+        hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
+                                           dec_ws.data_ptr(), stream))
+        ev[2].record()
+        hip.check(lib.vrp_rollout_steps_range(*args, C.byref(cenv), *tail, 1, T, max_steps,
+                                              sflags | 8, stream))
+        ev[3].record()
+        torch.cuda.synchronize()
+        kern.append((ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])) * 1e-3 / T)
+
     loops = []
     for _ in range(reps):
         rewind(env)
         cenv = env._cenv()
         hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
+        e0, e1 = _event(), _event()
+        e0.record()
         hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
                                           dec_ws.data_ptr(), stream))
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        hip.check(lib.vrp_rollout_steps(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
-                                        res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io),
-                                        T, (0 if greedy else 1) | extra_flags, stream))
+        hip.check(lib.vrp_rollout_steps(*args, C.byref(cenv), *tail, max_steps, sflags, stream))
         e1.record()
         torch.cuda.synchronize()
-        loops.append(e0.elapsed_time(e1) * 1e-3 / T)
-    # third figure: step 0 in its own event pair, the first-node table build untimed, then ONE
-    # event pair around the launches t = 1..T-1 issued back to back (the host needs ~5 us per
-    # launch, so the queue stays ahead of any kernel longer than that): what remains between
-    # the events is kernel time plus the ~1 us kernel-to-kernel boundary, without the ~3 us
-    # that a record/launch/record triple adds to every launch of the first figure.
-    chains = []
-    for _ in range(reps if T > 1 else 0):
+        loops.append(e0.elapsed_time(e1) * 1e-3)
+
+    rolls = []
+    for _ in range(reps):
         rewind(env)
         cenv = env._cenv()
-        hip.check(lib.vrp_env_mask(C.byref(cenv), 0, stream))
-        hip.check(lib.vrp_decode_prologue(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
-                                          dec_ws.data_ptr(), stream))
-        res.acc_loss.zero_(); res.acc_logp.zero_(); res.notdone.zero_()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        step_flags = (0 if greedy else 1) | 8 | extra_flags
-        ev[0].record()
-        hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
-                                      res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), 0,
-                                      max_steps, step_flags, stream))
-        ev[1].record()
-        hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
-                                           dec_ws.data_ptr(), stream))
-        ev[2].record()
-        for t in range(1, T):
-            hip.check(lib.vrp_decode_step(kind, derived.data_ptr(), C.byref(dw), C.byref(cenv),
-                                          res.emb.data_ptr(), dec_ws.data_ptr(), C.byref(io), t,
-                                          max_steps, step_flags, stream))
-        ev[3].record()
+        e0, e1 = _event(), _event()
+        e0.record()
+        hip.check(lib.vrp_rollout(kind, C.byref(ew), C.byref(dw), derived.data_ptr(),
+                                  C.byref(cenv), 0, sflags, res.emb.data_ptr(), enc_ws.data_ptr(),
+                                  dec_ws.data_ptr(), C.byref(io), max_steps, stream))
+        e1.record()
         torch.cuda.synchronize()
-        chains.append((ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])) * 1e-3 / T)
-    # The event-pair figure brackets exactly one decode_step launch each (agrees with the
-    # rocprofv3 average when the kernel outlasts the host's ~13 us per Python-driven launch);
-    # for shorter kernels the C-loop figure (which still contains the ~1.5 us boundaries and
-    # the three first-node launches of step 0) is the tighter upper bound.
-    pair, loop = float(np.mean(durs)), float(np.mean(loops))
-    if per_step:  # tuning aid: mean duration of step t over the repetitions
-        return [round(float(np.mean(durs[t::T])) * 1e6, 2) for t in range(T)]
-    chain = float(np.mean(chains)) if chains else pair
-    avg = min(pair, loop, chain)
+        rolls.append(e0.elapsed_time(e1) * 1e-3)
+
+    avg, pair = float(np.mean(kern)), float(np.mean(pairs))
+    loop, roll = float(np.mean(loops)), float(np.mean(rolls))
     byts = algorithmic_bytes_per_step(B, N)
     achieved = byts / avg / 1e9
-    return {"bound": "hbm", "kernel": "decode_step_rt_kernel", "workload": f"kind{kind}_N{N}_B{B}",
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic(f"kind{kind}_N{N}_B{B}"),
-            "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
-            "launches_timed": len(durs),
-            "event_pair_per_launch_us": round(pair * 1e6, 3),
-            "c_loop_per_launch_us": round(loop * 1e6, 3),
-            "chained_per_launch_us": round(chain * 1e6, 3)}
+    wl = f"kind{kind}_N{N}_B{B}"
+    traffic = pmc_traffic(wl)
+    name = lib.vrp_step_kernel_name(kind, B, N, sflags)
+    out = {"bound": "hbm", "kernel": name.decode() if name else "?", "workload": wl,
+           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "algorithmic_bytes_per_launch": byts, "avg_launch_us": round(avg * 1e6, 3),
+           "timer": "HIP events around the C loop's launches (vrp_rollout_steps_range)",
+           "launches_timed": reps * T, "steps_per_episode": T,
+           "event_pair_per_launch_us": round(pair * 1e6, 3),
+           "loop_us_per_step": round(loop / T * 1e6, 3),
+           "loop_frac": round(byts * T / loop / 1e9 / HBM_PEAK_GBS, 4),
+           "loop_us": round(loop * 1e6, 1),
+           "rollout_us": round(roll * 1e6, 1),
+           "rollout_frac": round(byts * T / roll / 1e9 / HBM_PEAK_GBS, 4)}
+    if traffic:
+        out["frac_on_measured_traffic"] = round(traffic / avg / 1e9 / HBM_PEAK_GBS, 4)
+    return out
 
 
 def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
@@ -237,6 +343,53 @@ def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
                       f"(oracle/: numpy env + torch-CPU fp32 policy)"}
 
 
+def run_workload(name, steps, warmup, device, dist, rank, world):
+    """One workload on this rank -> dict of whole-job figures (rank-reduced)."""
+    kind, N, B, mode = WORKLOADS[name]
+    shard = (rank, world) if world > 1 else None
+    train = mode == "train"
+    env, agent = make(kind, N, B, 69, device, shard=shard,
+                      generator="device" if train else "numpy")
+    extra = {}
+    if train:
+        from agents import distributed
+        distributed.broadcast_model(agent.model)
+        distributed.broadcast_model(agent.target_model)
+        dt, sum_T, rollouts, cost, ar_ms = timed_training(env, agent, steps, warmup, dist)
+        graph_steps = sum_T * B
+        node_steps = graph_steps * N
+        T = round(sum_T / max(steps * rollouts, 1), 2)
+        extra = {"rollouts_per_step": rollouts, "allreduce_ms_per_step": round(ar_ms, 4),
+                 "grad_bucket_bytes": 4 * sum(p.numel() for p in agent.model.parameters()
+                                              if p.grad is not None)}
+    else:
+        dt, T, cost = timed_rollouts(env, agent, mode == "greedy", steps, warmup, dist)
+        graph_steps = steps * B * T
+        node_steps = graph_steps * N
+    red = torch.tensor([dt, cost, float(node_steps), float(graph_steps)], device=device,
+                       dtype=torch.float64)
+    tmax = red[:1].clone()
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+    tmax = float(tmax.item())
+    out = {"name": name, "kind": kind, "N": N, "B": B, "mode": mode, "T": T,
+           "seconds": tmax, "ms_per_step": round(tmax / steps * 1e3, 4),
+           "node_steps_per_s": round(float(red[2].item()) / tmax, 1),
+           "graph_steps_per_s": round(float(red[3].item()) / tmax, 1),
+           "mean_tour_cost": round(float(red[1].item()) / world, 6)}
+    out.update(extra)
+    return out, env, agent
+
+
+def describe(kind, N, B, mode, T, world):
+    what = {"greedy": "attention agent greedy rollout", "sample": "attention agent sampling rollout",
+            "train": "REINFORCE training epoch (2 sampled rollouts, HIP backward, gradient "
+                     "all-reduce, Adam, 2 greedy rollouts + paired t-test)"}[mode]
+    return (f"{KIND_NAMES[kind]}Env num_nodes={N} batch_size={B} per GPU, {what} "
+            f"(encoder + {T} fused decode/env steps per rollout), untrained seed-69 weights")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,14 +398,19 @@ def main():
     ap.add_argument("--workload", default="tsp20_b512", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short runs of the other BASELINE configs")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(a, sys.argv[1:])  # does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {a.gpus}"
+    assert world == a.gpus, f"WORLD_SIZE={world} but --gpus {a.gpus}"
     # test aid (one-GPU boxes): VRPGYM_BENCH_ONE_GPU=1 maps every rank to cuda:0 and the
-    # rendezvous/timing collectives run over gloo; the driver's real runs never set it
+    # collectives run over gloo; the driver's real runs never set it
     one_gpu = os.environ.get("VRPGYM_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
@@ -267,40 +425,73 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
-    kind, N, B, greedy = WORKLOADS[a.workload]
-    env, agent = make(kind, N, B, 69 + rank, device)  # each rank its own instance stream
-    dt, T, cost = timed_rollouts(env, agent, greedy, a.steps, a.warmup, dist)
-    tmax = torch.tensor([dt], device=device)
-    costs = torch.tensor([cost], device=device)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(costs, op=dist.ReduceOp.SUM)
-    tmax, cost = float(tmax.item()), float(costs.item()) / world
-    node_steps = world * a.steps * B * N * T
+    kind, N, B, mode = WORKLOADS[a.workload]
+    r, env, agent = run_workload(a.workload, a.steps, a.warmup, device, dist, rank, world)
+    T = r["T"]
     out = {
-        "metric": "env-steps/sec (batch x nodes), greedy attention rollout",
-        "value": round(node_steps / tmax, 1), "unit": "node-steps/s",
+        "metric": "env-steps/sec (batch x nodes), " + ("REINFORCE training" if mode == "train"
+                                                       else f"{mode} attention rollout"),
+        "value": r["node_steps_per_s"], "unit": "node-steps/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(tmax / a.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{'TSP VRP IRP'.split()[kind]}Env num_nodes={N} "
-                               f"batch_size={B} per GPU, attention agent "
-                               f"{'greedy' if greedy else 'sampling'} rollout "
-                               f"(encoder + {T} fused decode/env steps), untrained seed-69 weights",
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" + (" (instances drawn on the device, Philox stream, reference "
+                               "distributions)" if mode == "train" else
+                               " (reference-exact numpy-stream instances, resident in HBM)"),
+        "config": {"workload": describe(kind, N, B, mode, T, world),
                    "name": a.workload, "global_batch": B * world, "num_nodes": N,
-                   "steps_per_rollout": T, "parallelism": f"dp{world} (independent shards, no "
-                   "collective on the rollout path)"},
-        "graph_steps_per_s": round(world * a.steps * B * T / tmax, 1),
-        "mean_tour_cost": round(cost, 6),
+                   "steps_per_rollout": T,
+                   "parallelism": f"dp{world} (rank r = rows [r*{B},(r+1)*{B}) of one "
+                                  f"seed-ordered stream; " +
+                                  ("one RCCL all-reduce of the flat gradient per epoch)"
+                                   if mode == "train" else "no collective on the rollout path)")},
+        "graph_steps_per_s": r["graph_steps_per_s"],
+        "mean_tour_cost": r["mean_tour_cost"],
     }
-    if rank == 0:
-        out["roofline"] = step_kernel_roofline(kind, N, B, greedy, device)
+    if one_gpu and world > 1:
+        out["one_gpu_test_mode"] = True  # all ranks share cuda:0: not a scaling measurement
+    if mode == "train":
+        out["training"] = {k: r[k] for k in ("rollouts_per_step", "allreduce_ms_per_step",
+                                             "grad_bucket_bytes")}
+
+    # ---- short runs of the other BASELINE configs (bounded; failures are reported, not fatal)
+    if not a.no_extras and a.workload == "tsp20_b512":
+        extras = {}
+        todo = [("irp40_b1024_train", 3, 1)] if world > 1 else \
+               [("vrp40_b2048_train", 3, 1), ("irp40_b1024_train", 3, 1), ("vrp100_b2048", 3, 1)]
+        for name, k, w in todo:
+            try:
+                e, _, _ = run_workload(name, k, w, device, dist, rank, world)
+                extras[name] = {kk: e[kk] for kk in e if kk not in ("name", "kind", "seconds")}
+            except Exception as exc:  # pragma: no cover
+                extras[name] = {"error": repr(exc)[:300]}
+        out["other_configs"] = extras
+
+    if rank == 0 and mode != "train":
+        out["roofline"] = step_kernel_roofline(kind, N, B, mode == "greedy", device)
         if not a.no_north_star and world == 1 and a.workload != "tsp40_b8192":
             out["roofline_north_star"] = step_kernel_roofline(0, 40, 8192, True, device)
             out["roofline_north_star_vrp"] = step_kernel_roofline(1, 40, 8192, True, device)
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, N, B, greedy)
+            if a.workload != "vrp100_b2048":
+                out["roofline_cfg5"] = step_kernel_roofline(1, 100, 2048, False, device, reps=2)
+    if rank == 0 and world == 1 and mode != "train":
+        # the same rollouts with env.reset() (new instances: host numpy stream + upload, or
+        # the device generator) inside the timed region
+        dt, T2, _ = timed_rollouts(env, agent, mode == "greedy", max(a.steps // 2, 1), 1, None,
+                                   reset="env")
+        out["incl_env_reset"] = {"generator": "numpy (host MT19937 replay + upload)",
+                                 "ms_per_step": round(dt / max(a.steps // 2, 1) * 1e3, 4),
+                                 "value": round(max(a.steps // 2, 1) * B * N * T2 / dt, 1)}
+        env_d, _ = make(kind, N, B, 69, device, generator="device")
+        dt, T2, _ = timed_rollouts(env_d, agent, mode == "greedy", a.steps, 1, None, reset="env")
+        out["incl_env_reset_device_generator"] = {
+            "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "value": round(a.steps * B * N * T2 / dt, 1)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kind, N, B, mode != "sample")
+        if mode != "train":
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -163,6 +163,10 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     const vrp_rollout_io *io, int t, int max_steps, int flags,
                     void *stream);
 
+/* Name of the kernel vrp_decode_step launches for this shape and these flags (what a
+ * rocprofv3 kernel trace will show). */
+const char *vrp_step_kernel_name(int kind, int B, int N, int flags);
+
 /* D2  GraphDecoder.forward's `first_` update (agents/graph_decoder.py:111-113) for
  * TSP/VRP: after step 0 the first chosen node is fixed; its part of the glimpse query is
  * folded, together with the graph-embedding part, into the last-node score table that every
@@ -187,6 +191,14 @@ int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weigh
 int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,
                       const vrp_env *env, const float *emb, void *dec_workspace,
                       const vrp_rollout_io *io, int max_steps, int flags, void *stream);
+
+/* Steps t_begin..t_end-1 of that loop, issued back to back from C (the loop vrp_rollout and
+ * vrp_rollout_steps run; exported so a benchmark can bracket exactly these launches with
+ * one event pair).  Accumulators are NOT reset.  flags as for vrp_decode_step. */
+int vrp_rollout_steps_range(int kind, const void *derived, const vrp_decoder_weights *dw,
+                            const vrp_env *env, const float *emb, void *dec_workspace,
+                            const vrp_rollout_io *io, int t_begin, int t_end, int max_steps,
+                            int flags, void *stream);
 
 /* E1  Host-side instance sampler, bit-exact with numpy's legacy global stream
  * (VRPGraph.__init__ gym_vrp/graph/vrp_graph.py:28-43 called B times,

@@ -1,0 +1,89 @@
+"""bench.py's multi-rank path: `--gpus N` spawns its own ranks; the sharded training workload
+runs end to end (Env(shard=...), broadcast_model, gradient all-reduce, gather_costs for the
+paired t-test, average_buffers).  On a one-GPU box the ranks share cuda:0 and the
+collectives run over gloo (VRPGYM_BENCH_ONE_GPU=1, flagged in the JSON line)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    return p
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """--gpus N never silently benchmarks fewer ranks (round-1 verdict)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
+    env.pop("VRPGYM_BENCH_ONE_GPU", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2" in p.stderr and "{" not in p.stdout
+
+
+@pytest.mark.gpu
+def test_bench_spawns_two_ranks_rollout():
+    p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                "--no-north-star", "--no-extras"], {"VRPGYM_BENCH_ONE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["one_gpu_test_mode"] is True
+    assert out["config"]["global_batch"] == 1024 and out["config"]["steps_per_rollout"] == 19
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    # rank 0 + rank 1 are the two halves of ONE seed-69 stream of 1024 graphs: their mean cost
+    # is the mean cost of the unsharded 1024-graph batch only if the shards are disjoint rows
+    # of that stream (scrambled masks differ per shard, so compare loosely)
+    assert 6.0 < out["mean_tour_cost"] < 7.6
+
+
+@pytest.mark.gpu
+def test_bench_sharded_training_two_ranks():
+    """configs[3]'s per-GPU shard with the all-reduce, t-test gather and buffer averaging."""
+    p = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                "--workload", "irp40_b1024_train"], {"VRPGYM_BENCH_ONE_GPU": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048
+    tr = out["training"]
+    assert tr["rollouts_per_step"] == 4          # 2 sampled + 2 greedy (baseline update)
+    assert tr["grad_bucket_bytes"] == 4 * (1154944 - 128)   # IRP: _first_node has no gradient
+    assert tr["allreduce_ms_per_step"] > 0
+    assert out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_line_has_contract_keys():
+    p = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-north-star"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+              "loop_us_per_step", "loop_frac", "rollout_frac", "kernel"):
+        assert k in r, k
+    assert r["kernel"].startswith("decode_step_rt_kernel<1, 1>")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["loop_frac"] <= r["frac"] + 1e-6 and r["rollout_frac"] <= r["loop_frac"] + 1e-6
+    for name in ("vrp40_b2048_train", "irp40_b1024_train", "vrp100_b2048"):
+        assert "error" not in out["other_configs"][name], out["other_configs"][name]
+        assert out["other_configs"][name]["ms_per_step"] > 0

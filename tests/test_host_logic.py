@@ -111,7 +111,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert lib.vrp_abi_version() == 2
+    assert lib.vrp_abi_version() == 3
     assert lib.vrp_decoder_derived_bytes() > 0
     assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
     assert lib.vrp_decoder_workspace_bytes(0, 512, 20) > 2 * 512 * 20 * 8 * 20 * 4
@@ -174,7 +174,13 @@ if rank == 1:
     with torch.no_grad():
         for p in a.model.parameters():
             p.add_(1.0)
+ver = [p._version for p in a.model.decoder.parameters()]
 D.broadcast_model(a.model)
+# the broadcast must be visible to the version-keyed cache of the folded decoder matrices
+assert all(p._version > v for p, v in zip(a.model.decoder.parameters(), ver))
+m = D.global_means(torch.tensor(float(rank)), torch.tensor(2.0 * rank + 1.0))
+assert m == (0.5, 2.0), m
+assert D.rank() == rank and D.world_size() == 2
 bn = a.model.encoder.attention_layers[0].bn1.norm
 bn.running_mean.fill_(float(rank))
 bn.num_batches_tracked.fill_(3 + rank)

@@ -19,10 +19,11 @@ dev = torch.device("cuda", 0)
 for shp in shapes:
     kind, N, B = shp[:3]
     extra = 16 if len(shp) > 3 and shp[3] else 0   # 4th field 1 = VRP_STEP_THROUGHPUT_KERNEL
+    greedy = not (len(shp) > 4 and shp[4])         # 5th field 1 = sampling
     if os.environ.get("STEP_PROBE_PER_STEP"):
         print(json.dumps({"workload": f"kind{kind}_N{N}_B{B}", "per_step_us":
-                          bench.step_kernel_roofline(kind, N, B, True, dev, reps=3,
+                          bench.step_kernel_roofline(kind, N, B, greedy, dev, reps=3,
                                                      extra_flags=extra, per_step=True)}))
         continue
-    r = bench.step_kernel_roofline(kind, N, B, True, dev, reps=3, extra_flags=extra)
-    print(json.dumps({k: r[k] for k in ("workload", "avg_launch_us", "event_pair_per_launch_us", "c_loop_per_launch_us", "chained_per_launch_us", "achieved", "frac")}))
+    r = bench.step_kernel_roofline(kind, N, B, greedy, dev, reps=3, extra_flags=extra)
+    print(json.dumps({k: r[k] for k in ("workload", "kernel", "avg_launch_us", "event_pair_per_launch_us", "loop_us_per_step", "loop_us", "rollout_us", "achieved", "frac", "loop_frac", "rollout_frac")}))

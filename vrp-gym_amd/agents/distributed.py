@@ -10,6 +10,30 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def rank():
+    return dist.get_rank() if is_distributed() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+# bench.py sets this to a list to collect (start, end) device events around every gradient
+# all-reduce (the only collective on the training path); None = no timing
+ALLREDUCE_EVENTS = None
+
+
+def global_means(*scalars):
+    """Host floats of per-shard 0-d tensors averaged over ranks (equal shard sizes, so the
+    mean of local means is the global mean): what rank 0 logs (graph_tsp_agent.py:191-206)."""
+    t = torch.stack([torch.as_tensor(s, dtype=torch.float32).detach().reshape(())
+                     .to(scalars[0].device) for s in scalars])
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t / dist.get_world_size()
+    return tuple(t.tolist())
+
+
 def grad_parameters(model):
     """Parameters that take part in the bucket.  Parameters that never receive a
     gradient (decoder._context_proj for TSP/VRP, decoder._first_node for IRP) have
@@ -37,7 +61,14 @@ def allreduce_gradients(model):
     if not params:
         return
     flat = flatten_grads(params)
+    ev = None
+    if ALLREDUCE_EVENTS is not None and flat.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if ev is not None:
+        ev[1].record()
+        ALLREDUCE_EVENTS.append(ev)
     flat.div_(dist.get_world_size())
     unflatten_grads(flat, params)
 
@@ -57,11 +88,19 @@ def gather_costs(cur, base):
 
 
 def broadcast_model(model, src=0):
-    """Replica consistency at start / after load_state_dict (params + BN buffers)."""
+    """Replica consistency at start / after load_state_dict (params + BN buffers).  The
+    in-place write bumps every parameter's version counter, and the folded decoder matrices
+    derived from the old values are dropped explicitly as well."""
     if not is_distributed():
         return
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src)
+    from . import runtime
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            buf = t.detach().clone()
+            dist.broadcast(buf, src=src)
+            t.copy_(buf)
+    for m in model.modules():
+        runtime.invalidate(m)
 
 
 def average_buffers(model):

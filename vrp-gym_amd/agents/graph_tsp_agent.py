@@ -88,27 +88,39 @@ class TSPAgent:
     # ------------------------------------------------------------------ training
     def train(self, env, epochs: int = 100, eval_epochs: int = 1,
               check_point_dir: str = "./check_points/"):
-        """REINFORCE with a rollout baseline (graph_tsp_agent.py:150-208)."""
+        """REINFORCE with a rollout baseline (graph_tsp_agent.py:150-208).  Data parallel:
+        every rank trains on its shard; the CSV, the log lines and the checkpoints are
+        written by rank 0 only, with means taken over the whole (global) batch."""
+        from . import distributed
+        root = distributed.rank() == 0
         logging.info("Start Training")
-        with open(self.csv_path, "w+", newline="") as fh:
-            csv.writer(fh).writerow(["Epoch", "Loss", "Cost", "Advantage", "Time"])
+        if root:
+            with open(self.csv_path, "w+", newline="") as fh:
+                csv.writer(fh).writerow(["Epoch", "Loss", "Cost", "Advantage", "Time"])
         t0 = time.time()
         for e in range(epochs):
-            self.model.train()
-            loss_m, loss_b, log_prob = self.step(env, (False, True))
-            advantage = (loss_m - loss_b) * -1
-            loss = (advantage * log_prob).mean()
-            self.opt.zero_grad()
-            loss.backward()
-            self.reduce_gradients()
-            self.opt.step()
-            self.baseline_update(env, eval_epochs)
-            logging.info(f"Epoch {e} finished - Loss: {loss}, Advantage: {advantage.mean()} "
-                         f"Dist: {loss_m.mean()}")
-            with open(self.csv_path, "a", newline="") as fh:
-                csv.writer(fh).writerow([e, loss.item(), loss_m.mean().item(),
-                                         advantage.mean().item(), time.time() - t0])
+            loss, cost, adv = distributed.global_means(*self.train_epoch(env, eval_epochs))
+            if root:
+                logging.info(f"Epoch {e} finished - Loss: {loss}, Advantage: {adv} Dist: {cost}")
+                with open(self.csv_path, "a", newline="") as fh:
+                    csv.writer(fh).writerow([e, loss, cost, adv, time.time() - t0])
             self.save_model(episode=e, check_point_dir=check_point_dir)
+
+    def train_epoch(self, env, eval_epochs: int = 1):
+        """One iteration of the reference's training loop (graph_tsp_agent.py:174-189):
+        sampled model + baseline rollouts, REINFORCE loss, backward (HIP), gradient
+        all-reduce, Adam, baseline t-test.  Returns this shard's (loss, mean cost, mean
+        advantage) as 0-d device tensors (no host sync)."""
+        self.model.train()
+        loss_m, loss_b, log_prob = self.step(env, (False, True))
+        advantage = (loss_m - loss_b) * -1
+        loss = (advantage * log_prob).mean()
+        self.opt.zero_grad()
+        loss.backward()
+        self.reduce_gradients()
+        self.opt.step()
+        self.baseline_update(env, eval_epochs)
+        return loss.detach(), loss_m.mean(), advantage.mean()
 
     def reduce_gradients(self):
         """Data parallel: one flat RCCL all-reduce of the gradient."""

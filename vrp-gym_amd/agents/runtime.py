@@ -16,7 +16,8 @@ EMB, HEADS = 128, 8
 
 _struct_cache = weakref.WeakKeyDictionary()  # module -> (struct, keepalive tensors)
 _derived_cache = weakref.WeakKeyDictionary()  # decoder -> (version key, device buffer)
-_buffers = {}         # (tag, device) -> scratch tensor
+_scratch = weakref.WeakKeyDictionary()  # owner (model / module) -> {tag: scratch tensor}
+ROLLOUT_LOG = None    # bench.py: a list collecting every RolloutResult (step accounting)
 
 
 def check_supported_dims(emb_dim, num_heads, hidden_dim, decoder=False):
@@ -45,13 +46,38 @@ def _require_cuda(module):
     return dev
 
 
-def _buf(tag, device, nbytes):
+def _buf(owner, tag, device, nbytes):
+    """Scratch owned by `owner` (a model, or an (env, model) pair through env._ws): nothing
+    is shared between models, so two agents may run on two streams at the same time."""
+    bufs = owner if isinstance(owner, dict) else _scratch.setdefault(owner, {})
     key = (tag, str(device))
-    t = _buffers.get(key)
+    t = bufs.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _buffers[key] = t
+        bufs[key] = t
     return t
+
+
+def workspaces(model, env):
+    """(encoder scratch, decoder per-episode workspace) private to this (model, env) pair:
+    the decoder workspace holds the episode's tables, so the model and the baseline model
+    (or two envs of one model) must not share it when they run on different streams.  The
+    env owns the tensors (they die with it); the model is referenced weakly."""
+    lib = hip.lib()
+    dev = _dev(model)
+    ew = encoder_struct(model.encoder)
+    B, N = env.batch_size, env.num_nodes
+    per_env = env.__dict__.setdefault("_ws", {})
+    key = id(model)
+    slot = per_env.get(key)
+    if slot is None or slot[0]() is not model:
+        if len(per_env) > 8:  # ids of dead models
+            for k in [k for k, v in per_env.items() if v[0]() is None]:
+                del per_env[k]
+        slot = per_env[key] = (weakref.ref(model), {})
+    enc = _buf(slot[1], "enc", dev, lib.vrp_encoder_workspace_bytes(B, N, ew.hidden))
+    dec = _buf(slot[1], "dec", dev, lib.vrp_decoder_workspace_bytes(env.KIND, B, N))
+    return enc, dec
 
 
 # ------------------------------------------------------------------ weight structs
@@ -160,7 +186,7 @@ def encoder_forward(enc, x, depot_mask, train):
     if depot_mask is not None:
         dm = depot_mask.detach().to(device=dev).to(torch.uint8).contiguous()
     emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
-    ws = _buf("enc", dev, lib.vrp_encoder_workspace_bytes(B, N, w.hidden))
+    ws = _buf(enc, "enc", dev, lib.vrp_encoder_workspace_bytes(B, N, w.hidden))
     hip.check(lib.vrp_encoder_forward(C.byref(w), int(bool(train)), B, N, x3.data_ptr(),
                                       hip.ptr(dm), emb.data_ptr(), ws.data_ptr(),
                                       hip.current_stream(dev)))
@@ -390,8 +416,7 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     max_steps = max_steps_for(kind, N)
     stream = hip.current_stream(dev)
 
-    enc_ws = _buf("enc", dev, lib.vrp_encoder_workspace_bytes(B, N, ew.hidden))
-    dec_ws = _buf("dec", dev, lib.vrp_decoder_workspace_bytes(kind, B, N))
+    enc_ws, dec_ws = workspaces(model, env)
     emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
     acc_loss = torch.empty((B,), dtype=torch.float32, device=dev)
     acc_logp = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -479,6 +504,8 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
         torch.set_rng_state(gen_state)
         host_noise(T, B, N)
     env._last_rollout = res  # env.step_count adds its T lazily
+    if ROLLOUT_LOG is not None:
+        ROLLOUT_LOG.append(res)
     return res
 
 
@@ -567,7 +594,7 @@ def decoder_backward(dec, kind, emb, actions, masks, loads, d_logp, T, want_logp
         setattr(g, name, hip.ptr(t))
     d_emb = torch.empty((B, N, EMB), dtype=torch.float32, device=dev)
     step_logp = torch.empty((T, B), dtype=torch.float32, device=dev) if want_logp else None
-    ws = _buf("dec_bwd", dev, lib.vrp_decoder_backward_workspace_bytes(kind, B, N, T))
+    ws = _buf(dec, "dec_bwd", dev, lib.vrp_decoder_backward_workspace_bytes(kind, B, N, T))
     assert actions.dtype == torch.int64 and masks.dtype == torch.uint8
     assert actions.is_contiguous() and masks.is_contiguous() and emb.is_contiguous()
     d_logp = d_logp.to(torch.float32).contiguous()

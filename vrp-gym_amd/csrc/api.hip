@@ -12,7 +12,7 @@ void vrp_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *vrp_last_error(void) { return g_err; }
-extern "C" int vrp_abi_version(void) { return 2; }
+extern "C" int vrp_abi_version(void) { return 3; }
 
 // Episode accumulators := 0.  A kernel rather than hipMemsetAsync: memset nodes inside a
 // captured hipGraph were observed to race with the kernels that follow them (ROCm 7.0
@@ -24,14 +24,25 @@ __global__ void rollout_init_kernel(float *acc_loss, float *acc_logp, int32_t *n
   if (i < nflags) notdone[i] = 0;
 }
 
-static int rollout_step_loop(int kind, const void *derived, const vrp_decoder_weights *dw,
-                             const vrp_env *env, const float *emb, void *dec_workspace,
-                             const vrp_rollout_io *io, int max_steps, int flags, void *stream) {
-  for (int t = 0; t < max_steps; ++t)
+extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
+                                       const vrp_decoder_weights *dw, const vrp_env *env,
+                                       const float *emb, void *dec_workspace,
+                                       const vrp_rollout_io *io, int t_begin, int t_end,
+                                       int max_steps, int flags, void *stream) {
+  VRP_REQUIRE(0 <= t_begin && t_begin <= t_end && t_end <= max_steps,
+              "rollout_steps_range: [%d,%d) outside [0,%d]", t_begin, t_end, max_steps);
+  for (int t = t_begin; t < t_end; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,
                                 flags, stream))
       return r;
   return 0;
+}
+
+static int rollout_step_loop(int kind, const void *derived, const vrp_decoder_weights *dw,
+                             const vrp_env *env, const float *emb, void *dec_workspace,
+                             const vrp_rollout_io *io, int max_steps, int flags, void *stream) {
+  return vrp_rollout_steps_range(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
+                                 max_steps, flags, stream);
 }
 
 extern "C" int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,

@@ -1195,6 +1195,18 @@ extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N,
                                ws.C0, ws.SLD, ws.SL, ws.row0, ws.curs, ws.RT, st);
 }
 
+// name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
+extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
+  (void)kind;
+  if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
+    const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
+    if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
+    return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";
+  }
+  return N <= 24 ? "decode_step_kernel<24>" : N <= 40 ? "decode_step_kernel<40>"
+       : N <= 64 ? "decode_step_kernel<64>" : "decode_step_kernel<104>";
+}
+
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
   const int B = p.B, N = p.N;
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {

@@ -265,7 +265,7 @@ class TSPEnv(GymEnv):
                 new.__dict__[k] = v.clone()
             elif k in ("_lib", "_torch", "vid", "_last_rollout"):
                 new.__dict__[k] = v
-            elif k in ("_twin_env", "_graph_sightings"):
+            elif k in ("_twin_env", "_graph_sightings", "_ws"):
                 continue
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -283,7 +283,7 @@ class TSPEnv(GymEnv):
             return tw
         t = self._torch
         for k, v in self.__dict__.items():
-            if k in ("_twin_env", "_graph_sightings"):
+            if k in ("_twin_env", "_graph_sightings", "_ws"):
                 continue
             if isinstance(v, t.Tensor):
                 tw.__dict__[k].copy_(v)

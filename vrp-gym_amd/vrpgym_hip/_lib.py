@@ -101,6 +101,8 @@ def _declare(lib):
                               vp, vp, vp, P(RolloutIO), i32, vp]),
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                     i32, i32, vp]),
+        "vrp_rollout_steps_range": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp,
+                                          P(RolloutIO), i32, i32, i32, i32, vp]),
         "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
         "vrp_draw_instances_device": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, vp, vp, vp, vp]),
         "vrp_random_rollout": (i32, [P(Env), C.c_uint64, C.c_uint64, i32, i32, vp, vp, vp, vp]),
@@ -121,6 +123,7 @@ def _declare(lib):
         "vrp_attention_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
         "vrp_gemm_nt_gated": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+        "vrp_step_kernel_name": (C.c_char_p, [i32, i32, i32, i32]),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
     }
