@@ -268,3 +268,44 @@ def test_backward_full_size_properties():
     for x, y, z in zip(ga, gb, gs):
         scale = max(1.0, z.abs().max().item())
         assert (x + y - z).abs().max().item() < 2e-4 * scale
+
+
+@pytest.mark.parametrize("kind,B,N", [(0, 512, 20), (2, 1024, 40)])
+def test_training_step_is_bitwise_reproducible(kind, B, N):
+    """Two identical training steps (train-mode rollout with batch-statistics BatchNorm, HIP
+    backward) give torch.equal embeddings, tapes, BN running statistics and gradients: the
+    batch statistics are a fixed-order two-stage reduction, not float atomics.  (2, 1024, 40)
+    is BASELINE config 4's per-GPU shard."""
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import IRPEnv, TSPEnv, VRPEnv
+    Env = (TSPEnv, VRPEnv, IRPEnv)[kind]
+    Agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
+
+    def one():
+        agent = Agent(seed=69)
+        model = agent.model
+        model.train()
+        env = Env(N, B, 1, 69)
+        noise = torch.empty((runtime.max_steps_for(kind, N), B, N),
+                            generator=torch.Generator().manual_seed(5)).exponential_(1)
+        res = runtime.rollout(model, env, greedy=False, train=True, record=True, noise=noise)
+        logp = runtime.attach_grad(model, env, res)
+        wgt = torch.linspace(-1.0, 1.0, B, device=logp.device)
+        model.zero_grad()
+        (wgt * logp).mean().backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        bufs = {n: b.clone() for n, b in model.named_buffers()}
+        return res, grads, bufs
+
+    r1, g1, b1 = one()
+    r2, g2, b2 = one()
+    assert r1.T == r2.T
+    assert torch.equal(r1.emb, r2.emb) and torch.equal(r1.tape, r2.tape)
+    assert torch.equal(r1.acc_logp, r2.acc_logp) and torch.equal(r1.acc_loss, r2.acc_loss)
+    assert torch.equal(r1.actions, r2.actions)
+    assert g1.keys() == g2.keys() and len(g1) > 30
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
+    for n in b1:
+        assert torch.equal(b1[n], b2[n]), n

@@ -178,3 +178,57 @@ def test_reference_env_kats():
     e2.current_location = np.array([[0]])
     _, r, _, _ = e2.step(np.array([[1]]))
     assert r[0] == -5
+
+
+@pytest.mark.parametrize("name,z", _load("trainstep_*.npz"))
+def test_training_step(name, z):
+    """One REINFORCE step of the reference (agent.step(env, (False, True)) + backward,
+    graph_tsp_agent.py:174-186, 227-255) through the oracle with torch autograd: sampled
+    actions from the same CPU stream, loss, T and per-parameter gradient norms as the
+    reference produced them.  The *_B64_N20 files are SURVEY.md 8a row A1's pins (loss
+    22.715494 / -34.453243 / 7.296117, T 19 / 35 / 30, grad-norm 54.92951 / 134.16078 /
+    72.18533)."""
+    kind, B, N = int(z["kind"]), int(z["B"]), int(z["N"])
+    env_first = int(z["env_first"]) if "env_first" in z.files else 0
+    if env_first:
+        env = oenv.OracleEnv(kind, N, B, 1, 69)
+        sd, tsd = opol.init_state_dicts(kind, 69)
+    else:
+        sd, tsd = opol.init_state_dicts(kind, 69)
+        env = oenv.OracleEnv(kind, N, B, 1, 69)
+    if int(z["torch_seed"]) >= 0:
+        torch.manual_seed(int(z["torch_seed"]))
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    env.reset()                                        # graph_tsp_agent.py:246
+    env_b = deepcopy(env)
+    noise = lambda t, u: torch.empty(u.shape).exponential_(1)   # Categorical.sample's draw
+    loss_m, logp, T = opol.rollout(sd, env, False, train=True, noise_fn=noise)
+    with torch.no_grad():                              # QUIRK :253: baseline sampled too
+        loss_b, _, _ = opol.rollout(tsd, env_b, False, train=False, noise_fn=noise)
+    assert T == int(z["T"])
+    assert np.max(np.abs(loss_m.detach().numpy() - z["loss_m"])) < 1e-5
+    assert np.max(np.abs(loss_b.numpy() - z["loss_b"])) < 1e-5
+    assert np.max(np.abs(logp.detach().numpy() - z["logp"])) < 5e-5
+    loss = (((loss_m - loss_b) * -1).detach() * logp).mean()
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    got = {k: (v.grad.norm().item() if v.grad is not None else -1.0) for k, v in sd.items()
+           if v.is_floating_point() and "running" not in k}
+    for k, want in zip(z["grad_keys"], z["grad_norms"]):
+        g = got[str(k)]
+        if want < 0:
+            assert g < 0, f"{k} must not receive a gradient"
+        else:
+            # (biases feeding a train-mode BatchNorm have an exactly-zero gradient: both
+            # sides hold rounding noise there, hence the floor tied to the total norm)
+            assert abs(g - want) <= 2e-3 * want + 2e-6 * float(z["grad_total"]), \
+                (str(k), g, float(want))
+    tot = np.sqrt(sum(v * v for v in got.values() if v >= 0))
+    assert abs(tot - float(z["grad_total"])) < 1e-3 * float(z["grad_total"])
+    if name.endswith("_B64_N20"):
+        pins = {0: (22.715494, 19, 54.92951), 1: (-34.453243, 35, 134.16078),
+                2: (7.296117, 30, 72.18533)}[kind]
+        assert abs(loss.item() - pins[0]) < 2e-4 * abs(pins[0]) and T == pins[1]
+        assert abs(tot - pins[2]) < 1e-3 * pins[2]

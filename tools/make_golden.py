@@ -345,28 +345,40 @@ def gen_kats():
 
 # ---------------------------------------------------------------- (vii) training step
 def gen_train_step():
+    """(B, N, torch seed) = (16, 8, 31) small cases, and SURVEY.md 8a row A1's pins: N=20,
+    B=64, env/agent seed 69, the torch stream left where the agent constructor put it."""
     print("[training step]")
-    for kind in (0, 1, 2):
-        B, N = 16, 8
-        ag = REF_AGENT[kind](seed=69)
-        env = REF_ENV[kind](N, B, 1, 69)
-        ag.model.train()
-        torch.manual_seed(31)
-        loss_m, loss_b, logp = ag.step(env, (False, True))
-        adv = (loss_m - loss_b) * -1
-        loss = (adv * logp).mean()
-        ag.opt.zero_grad()
-        loss.backward()
-        gn = {k: (p.grad.norm().item() if p.grad is not None else -1.0)
-              for k, p in ag.model.named_parameters()}
-        ag.opt.step()
-        post = sd_hash(ag.model.state_dict())
-        tot = math_sqrt(sum(v * v for v in gn.values() if v >= 0))
-        print(f"   kind={kind}: loss={loss.item():.6f} gradnorm={tot:.5f}")
-        save(f"trainstep_k{kind}", kind=kind, B=B, N=N, torch_seed=31, loss=loss.item(),
-             loss_m=loss_m.detach().numpy(), loss_b=loss_b.numpy(),
-             logp=logp.detach().numpy(), grad_keys=np.array(list(gn.keys())),
-             grad_norms=np.array(list(gn.values())), grad_total=tot, post_adam_sha=post)
+    for B, N, tseed, tag in ((16, 8, 31, ""), (64, 20, None, "_B64_N20")):
+        for kind in (0, 1, 2):
+            if tseed is None:   # the pins: env first, then the agent (whose constructor
+                env = REF_ENV[kind](N, B, 1, 69)   # reseeds numpy: step()'s reset() then
+                ag = REF_AGENT[kind](seed=69)      # draws from a fresh seed-69 stream)
+            else:
+                ag = REF_AGENT[kind](seed=69)
+                env = REF_ENV[kind](N, B, 1, 69)
+            ag.model.train()
+            if tseed is not None:
+                torch.manual_seed(tseed)
+            loss_m, loss_b, logp = ag.step(env, (False, True))
+            T = int(env.step_count)
+            adv = (loss_m - loss_b) * -1
+            loss = (adv * logp).mean()
+            ag.opt.zero_grad()
+            loss.backward()
+            gn = {k: (p.grad.norm().item() if p.grad is not None else -1.0)
+                  for k, p in ag.model.named_parameters()}
+            nbt = int(ag.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked)
+            ag.opt.step()
+            post = sd_hash(ag.model.state_dict())
+            tot = math_sqrt(sum(v * v for v in gn.values() if v >= 0))
+            print(f"   kind={kind} B={B} N={N}: loss={loss.item():.6f} T={T} gradnorm={tot:.5f} "
+                  f"num_batches_tracked={nbt}")
+            save(f"trainstep_k{kind}{tag}", kind=kind, B=B, N=N,
+                 torch_seed=-1 if tseed is None else tseed, env_first=int(tseed is None),
+                 loss=loss.item(), T=T,
+                 loss_m=loss_m.detach().numpy(), loss_b=loss_b.numpy(),
+                 logp=logp.detach().numpy(), grad_keys=np.array(list(gn.keys())),
+                 grad_norms=np.array(list(gn.values())), grad_total=tot, post_adam_sha=post)
 
 
 def math_sqrt(x):

@@ -50,10 +50,18 @@ class TSPModel(nn.Module):
         if env.KIND not in self.ENV_KINDS:
             raise TypeError(f"{type(self).__name__} cannot drive a {type(env).__name__}")
         grad = self.training and torch.is_grad_enabled() and not rollout
+        # somebody watches the tour (reproduction.py:37-47: enable_video_capturing, then
+        # agent.evaluate; or sampler.graphs materialised for render()): the reference records
+        # the edge and captures a frame inside every env.step (tsp.py:88-93).  The fused
+        # rollout keeps the chosen nodes and replays that bookkeeping on the host afterwards.
+        watched = env.video_save_path is not None or env.sampler._graphs is not None
+        start = env.current_location if watched else None
         res = runtime.rollout(self, env, greedy=bool(rollout), train=self.training,
-                              noise_mode=self.sampling_noise, record=grad)
+                              noise_mode=self.sampling_noise, record=grad, trace=watched)
         self.last_rollout = res
         self.decoder.reset()
+        if watched:
+            env.replay_tour(start, res.actions[: res.T].cpu().numpy())
         logp = res.acc_logp
         if grad:
             logp = runtime.attach_grad(self, env, res)
@@ -121,6 +129,15 @@ class TSPAgent:
         self.opt.step()
         self.baseline_update(env, eval_epochs)
         return loss.detach(), loss_m.mean(), advantage.mean()
+
+    def sync_weights(self):
+        """Call after writing parameters through `.data` (or any other route that bypasses
+        autograd's version counters): drops the folded decoder matrices derived from the old
+        values.  Optimizer steps, load_state_dict, `.to()` and in-place ops on the parameters
+        themselves are noticed automatically."""
+        for model in (self.model, self.target_model):
+            for m in model.modules():
+                runtime.invalidate(m)
 
     def reduce_gradients(self):
         """Data parallel: one flat RCCL all-reduce of the gradient."""

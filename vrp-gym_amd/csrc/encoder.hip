@@ -285,9 +285,12 @@ static int launch_qkv_attention(const float *x, const float *Win, const float *b
 }
 
 // ---- BatchNorm1d(128) over the flattened (B*N,128) view (graph_encoder.py:141-154) ---
-// stats: fp64 column sums of x and x^2 (two 128-vectors), zeroed by the caller.
+// Batch statistics in two fixed-order stages (no atomics: bitwise reproducible): block k
+// writes the fp64 column sums of x and x^2 over its rows (rows k, k+G, k+2G, ... in that
+// order) to partial[k][256]; bn_stats_reduce_kernel adds the partials in block order.
+#define BN_MAX_BLOCKS 512
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__ x, int rows,
-                                                       double *__restrict__ stats) {
+                                                       double *__restrict__ partial) {
   __shared__ double sh[2][256];
   const int c = threadIdx.x & 127, par = threadIdx.x >> 7;
   double s = 0.0, ss = 0.0;
@@ -300,9 +303,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
   sh[1][threadIdx.x] = ss;
   __syncthreads();
   if (par == 0) {
-    atomicAdd(&stats[c], sh[0][c] + sh[0][c + 128]);
-    atomicAdd(&stats[128 + c], sh[1][c] + sh[1][c + 128]);
+    partial[(size_t)blockIdx.x * 256 + c] = sh[0][c] + sh[0][c + 128];
+    partial[(size_t)blockIdx.x * 256 + 128 + c] = sh[1][c] + sh[1][c + 128];
   }
+}
+// stats[j] = sum_k partial[k][j], k ascending; four independent chains per thread keep the
+// loads in flight, combined in a fixed order
+__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double *__restrict__ partial,
+                                                              int blocks,
+                                                              double *__restrict__ stats) {
+  const int j = threadIdx.x;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int k = 0;
+  for (; k + 3 < blocks; k += 4) {
+    a0 += partial[(size_t)(k + 0) * 256 + j];
+    a1 += partial[(size_t)(k + 1) * 256 + j];
+    a2 += partial[(size_t)(k + 2) * 256 + j];
+    a3 += partial[(size_t)(k + 3) * 256 + j];
+  }
+  for (; k < blocks; ++k) a0 += partial[(size_t)k * 256 + j];
+  stats[j] = (a0 + a1) + (a2 + a3);
+}
+
+// sums: [256 final | BN_MAX_BLOCKS x 256 partials] doubles
+static size_t bn_sums_bytes() { return vrp_align_up((size_t)(1 + BN_MAX_BLOCKS) * 256 * 8); }
+static int launch_bn_stats(const float *x, int rows, double *sums, hipStream_t st) {
+  int blocks = (rows + 31) / 32;
+  if (blocks > BN_MAX_BLOCKS) blocks = BN_MAX_BLOCKS;
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, sums + 256);
+  VRP_CHECK_LAUNCH("bn_stats");
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(1), dim3(256), 0, st, sums + 256, blocks, sums);
+  VRP_CHECK_LAUNCH("bn_stats_reduce");
+  return 0;
 }
 
 // Eval mode: BatchNorm is a per-channel affine known before the layer runs; all 2L
@@ -712,21 +744,12 @@ extern "C" int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden) {
   // + feature scratch used by vrp_rollout: x (R,3) fp32 and is_depot (R) u8
   return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
                    vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(16 * 384 * 4) +
-                   vrp_align_up(256 * 8) + vrp_align_up(R * 12) + vrp_align_up(R));
+                   bn_sums_bytes() + vrp_align_up(R * 12) + vrp_align_up(R));
 }
-
-__global__ void bn_zero_stats_kernel(double *stats) { stats[threadIdx.x] = 0.0; }
 
 static int batchnorm_train(float *x, int rows, const float *w, const float *b, float *rm,
                            float *rv, int64_t *nbt, const EncWs &ws, hipStream_t st) {
-  hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, ws.stats);
-  VRP_CHECK_LAUNCH("bn_zero_stats");
-  // every block ends with 256 same-address fp64 atomics (~11 ns each, serialised per
-  // address): keep the block count low enough that they stay below the streaming time
-  int blocks = (rows + 31) / 32;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, ws.stats);
-  VRP_CHECK_LAUNCH("bn_stats");
+  if (int r = launch_bn_stats(x, rows, ws.stats, st)) return r;
   const size_t n4 = (size_t)rows * 32;
   hipLaunchKernelGGL(bn_train_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                      x, n4, ws.stats, rows, w, b, rm, rv, nbt);
@@ -1007,7 +1030,7 @@ static size_t layer_tape_floats(size_t R, int hidden) {
 
 extern "C" int64_t vrp_encoder_tape_bytes(int B, int N, int hidden, int num_layers) {
   const size_t R = (size_t)B * N;
-  return (int64_t)(num_layers * vrp_align_up(layer_tape_floats(R, hidden) * 4) + vrp_align_up(256 * 8));
+  return (int64_t)(num_layers * vrp_align_up(layer_tape_floats(R, hidden) * 4) + bn_sums_bytes());
 }
 
 static EncTape carve_tape(void *tape, int B, int N, int hidden, int num_layers) {
@@ -1036,14 +1059,7 @@ static EncTape carve_tape(void *tape, int B, int N, int hidden, int num_layers) 
 static int bn_train_taped(const float *z, float *y, int rows, const float *w, const float *b,
                           float *stats, float *rm, float *rv, int64_t *nbt, int update,
                           double *sums, hipStream_t st) {
-  hipLaunchKernelGGL(bn_zero_stats_kernel, dim3(1), dim3(256), 0, st, sums);
-  VRP_CHECK_LAUNCH("bn_zero_stats");
-  // every block ends with 256 same-address fp64 atomics (~11 ns each, serialised per
-  // address): keep the block count low enough that they stay below the streaming time
-  int blocks = (rows + 31) / 32;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, z, rows, sums);
-  VRP_CHECK_LAUNCH("bn_stats");
+  if (int r = launch_bn_stats(z, rows, sums, st)) return r;
   const size_t n4 = (size_t)rows * 32;
   hipLaunchKernelGGL(bn_train_apply_oop_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
                      z, y, n4, sums, rows, w, b, stats, rm, rv, nbt, update);

@@ -192,10 +192,18 @@ class TSPEnv(GymEnv):
         if isinstance(actions, t.Tensor):
             self._actions.copy_(actions.reshape(-1))
         else:
-            self._actions.copy_(t.from_numpy(np.ascontiguousarray(
-                np.asarray(actions).reshape(-1).astype(np.int64))))
+            # numpy indexing semantics of `self.visited[..., actions]` (tsp.py:86): negative
+            # indices wrap, anything outside [-N, N) raises IndexError
+            a = np.asarray(actions).reshape(-1).astype(np.int64)
+            if a.size and (a.min() < -self.num_nodes or a.max() >= self.num_nodes):
+                raise IndexError(f"index {int(a.max() if a.max() >= self.num_nodes else a.min())}"
+                                 f" is out of bounds for axis 1 with size {self.num_nodes}")
+            a = np.where(a < 0, a + self.num_nodes, a)
+            actions = a.reshape(-1, 1)
+            self._actions.copy_(t.from_numpy(np.ascontiguousarray(a)))
         if self.sampler._graphs is not None:  # rendering flags only (vrp_network.py:143-152)
-            edges = np.hstack([self.current_location, np.asarray(actions).reshape(-1, 1)])
+            host = actions.cpu().numpy() if isinstance(actions, t.Tensor) else np.asarray(actions)
+            edges = np.hstack([self.current_location, host.reshape(-1, 1)])
             self.sampler.visit_edges(edges.astype(int))
         self._notdone.zero_()
         e = self._cenv()
@@ -208,6 +216,19 @@ class TSPEnv(GymEnv):
             self.vid.capture_frame()
         done = int(self._notdone.item()) == 0
         return self.get_state(), self._reward.cpu().numpy(), done, None
+
+    def replay_tour(self, start, actions):
+        """Host-side part of T env.steps that ran fused on the device: the rendering flags of
+        the traversed edges (vrp_network.py:143-152 via tsp.py:88-89) and one video frame per
+        step (tsp.py:92-93).  start (B,1) = current_location before the first step, actions
+        (T,B) the chosen nodes."""
+        cur = np.asarray(start).reshape(-1, 1)
+        for a in np.asarray(actions):
+            nxt = a.reshape(-1, 1)
+            self.sampler.visit_edges(np.hstack([cur, nxt]).astype(int))
+            if self.video_save_path is not None:
+                self.vid.capture_frame()
+            cur = nxt
 
     def is_done(self):
         """tsp.py:103-104."""
