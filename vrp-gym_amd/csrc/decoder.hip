@@ -9,11 +9,13 @@
 //     q_h.K_{h,n}/sqrt(48) splits into per-episode tables
 //        SG[b][h][n]        graph-embedding + bias part
 //        C0[b][h][n]        step-0 placeholders _first_node/_last_node;  row0 = SG + C0
-//        SL[b][m][h][n]     "last node = m" part PLUS everything constant after step 0
-//                           (SG, and for TSP/VRP the "first node" part, known after step 0)
+//        SL[b][m][h][n]     "last node = m" part
+//        base[b][h][n]      everything constant after step 0: SG, and for TSP/VRP the "first
+//                           node" part (known after step 0)
 //        SLD[b][h][n]       load coefficient           (IRP)
-//     built once per episode (vrp_decode_prologue / vrp_decode_first_row); a step reads ONE
-//     table row: row0 at t = 0, SL[b][last] afterwards.
+//     built once per episode (decoder_prologue.hip: vrp_decode_prologue /
+//     vrp_decode_first_row); a step reads row0 at t = 0, SL[b][last] + base[b] afterwards
+//     (pre-added into `curs` by the previous launch in the latency mode).
 //   * sum_n a_n (Wv e_n + bv) = Wv (sum_n a_n e_n) + bv, and _kp/_att_output/out_proj
 //     fold into one 128x384 matrix M, so a step reads only the RAW (N,128)
 //     embedding tile, once, and keeps it in registers for both the glimpse
@@ -22,96 +24,74 @@
 //     head h of graph b reads mask row (8b+h) mod B (graph_decoder.py:93-94).
 #include <stdlib.h>
 #include "env_device.h"
-
-int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
-                       const float *R, int ldr, float *C, int ldc, int M, int N, int K,
-                       int relu, hipStream_t stream);
-int vrp_launch_gemm_gather_k128(const float *A, int lda, const int32_t *gidx, int gstride,
-                                const float *W, int ldw, float *C, int ldc, int M, int N,
-                                hipStream_t stream);
+#include "decoder_ws.h"
 
 // ------------------------------------------------------------------ derived weights
-struct Derived {
-  float *Wproj;  // (1536,128) = [Wq_last | Wk | M^T | Wv]
-  float *bproj;  // (1536)       0 | bk | 0 | bv
-  float *Wqf;    // (384,128)  first-node block of the query projection (TSP/VRP)
-  float *Wqg;    // (384,128)  graph-embedding block of the query projection
-  float *bq;     // (384)
-  float *qc0;    // (384)      query contribution of the step-0 placeholders
-  float *wload;  // (384)      query coefficient of the vehicle load (IRP)
-  float *WvT;    // (128,384)  v_proj_weight transposed
-  float *bv;     // (384)
-  float *MT;     // (384,128)  transpose of M = Wkp^T Watt Wo / sqrt(128)
-  float *mb;     // (128)      Wkp^T Watt bo / sqrt(128)
-  float *tmpA;   // (128,384)  Watt Wo
-  float *tmpv;   // (128)      Watt bo
+extern "C" int64_t vrp_decoder_derived_bytes(void) { return (int64_t)sizeof(float) * derived_floats(); }
+
+// All folds are small strided matrix products (<= 19 M MAC each) and copies.  They run as
+// TWO launches (the second consumes products of the first): a launch executes a table of
+// tasks, one thread per output element,
+//   C[i*scr + j*scc] = alpha * sum_k A[i*sar + k*sac] * Bm[k*sbr + j*sbc] + (add ? add[i*adr + j*adc] : 0)
+// (K = 0: a strided copy, or a zero fill when add is NULL).  The fmaf chain keeps the k order.
+struct FoldTask {
+  float *C;
+  const float *A, *Bm, *add;
+  int scr, scc, sar, sac, sbr, sbc, adr, adc;
+  int M, N, K, first_block;
+  float alpha;
+};
+#define FOLD_MAX_TASKS 28
+struct FoldTable {
+  FoldTask t[FOLD_MAX_TASKS];
+  int n, blocks;
 };
 
-static Derived carve_derived(void *base) {
-  float *p = (float *)base;
-  Derived d;
-  d.Wproj = p; p += 1536 * 128;
-  d.bproj = p; p += 1536;
-  d.Wqf = p;   p += 384 * 128;
-  d.Wqg = p;   p += 384 * 128;
-  d.bq = p;    p += 384;
-  d.qc0 = p;   p += 384;
-  d.wload = p; p += 384;
-  d.WvT = p;   p += 128 * 384;
-  d.bv = p;    p += 384;
-  d.MT = p;    p += 384 * 128;
-  d.mb = p;    p += 128;
-  d.tmpA = p;  p += 128 * 384;
-  d.tmpv = p;  p += 128;
-  return d;
-}
-
-extern "C" int64_t vrp_decoder_derived_bytes(void) {
-  return (int64_t)sizeof(float) *
-         (1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
-          128 * 384 + 128);
-}
-
-// C[i*scr + j*scc] = alpha * sum_k A[i*sar + k*sac] * Bm[k*sbr + j*sbc] + beta*C.
-// Tiny one-off weight folds only (<= 19 M MAC); one thread per output element.
-__global__ void mm_strided_kernel(float *__restrict__ C, int scr, int scc,
-                                  const float *__restrict__ A, int sar, int sac,
-                                  const float *__restrict__ Bm, int sbr, int sbc, int M, int N, int K,
-                                  float alpha, float beta) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * N) return;
-  const int i = idx / N, j = idx - i * N;
+__global__ __launch_bounds__(256) void fold_tasks_kernel(FoldTable tab) {
+  int ti = 0;
+#pragma unroll 1
+  for (int i = 1; i < tab.n; ++i)
+    if ((int)blockIdx.x >= tab.t[i].first_block) ti = i;
+  const FoldTask &k = tab.t[ti];
+  const int idx = (blockIdx.x - k.first_block) * 256 + threadIdx.x;
+  if (idx >= k.M * k.N) return;
+  const int i = idx / k.N, j = idx - i * k.N;
   float acc = 0.f;
-#pragma unroll 16  // the loads of 16 k-steps in flight; the fmaf chain keeps the k order
-  for (int k = 0; k < K; ++k)
-    acc = fmaf(A[(size_t)i * sar + (size_t)k * sac], Bm[(size_t)k * sbr + (size_t)j * sbc], acc);
-  float *c = C + (size_t)i * scr + (size_t)j * scc;
-  *c = alpha * acc + (beta != 0.f ? beta * *c : 0.f);
+#pragma unroll 16  // the loads of 16 k-steps in flight
+  for (int kk = 0; kk < k.K; ++kk)
+    acc = fmaf(k.A[(size_t)i * k.sar + (size_t)kk * k.sac],
+               k.Bm[(size_t)kk * k.sbr + (size_t)j * k.sbc], acc);
+  float v = k.alpha * acc;
+  if (k.add) v += k.add[(size_t)i * k.adr + (size_t)j * k.adc];
+  k.C[(size_t)i * k.scr + (size_t)j * k.scc] = v;
 }
 
-// dst[r*sdr + c*sdc] = src ? src[r*ssr + c*ssc] : 0
-__global__ void copy2d_kernel(float *dst, int sdr, int sdc, const float *src, int ssr, int ssc,
-                              int rows, int cols) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * cols) return;
-  const int r = idx / cols, c = idx - r * cols;
-  dst[(size_t)r * sdr + (size_t)c * sdc] = src ? src[(size_t)r * ssr + (size_t)c * ssc] : 0.f;
-}
-
-static int mm(hipStream_t st, float *C, int scr, int scc, const float *A, int sar, int sac,
-              const float *Bm, int sbr, int sbc, int M, int N, int K, float alpha, float beta) {
-  hipLaunchKernelGGL(mm_strided_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, C, scr, scc,
-                     A, sar, sac, Bm, sbr, sbc, M, N, K, alpha, beta);
-  VRP_CHECK_LAUNCH("mm_strided");
-  return 0;
-}
-static int cp(hipStream_t st, float *dst, int sdr, int sdc, const float *src, int ssr, int ssc,
-              int rows, int cols) {
-  hipLaunchKernelGGL(copy2d_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, st, dst, sdr,
-                     sdc, src, ssr, ssc, rows, cols);
-  VRP_CHECK_LAUNCH("copy2d");
-  return 0;
-}
+struct FoldBuilder {
+  FoldTable tab;
+  FoldBuilder() { tab.n = 0; tab.blocks = 0; }
+  // C = alpha * A Bm (+ add)
+  void mm(float *C, int scr, int scc, const float *A, int sar, int sac, const float *Bm, int sbr,
+          int sbc, int M, int N, int K, float alpha, const float *add = nullptr, int adr = 0,
+          int adc = 0) {
+    if (tab.n >= FOLD_MAX_TASKS) { ++tab.n; return; }  // reported by launch()
+    FoldTask &k = tab.t[tab.n++];
+    k.C = C; k.A = A; k.Bm = Bm; k.add = add;
+    k.scr = scr; k.scc = scc; k.sar = sar; k.sac = sac; k.sbr = sbr; k.sbc = sbc;
+    k.adr = adr; k.adc = adc; k.M = M; k.N = N; k.K = K; k.alpha = alpha;
+    k.first_block = tab.blocks;
+    tab.blocks += (M * N + 255) / 256;
+  }
+  // dst[r*sdr + c*sdc] = src ? src[r*ssr + c*ssc] : 0
+  void cp(float *dst, int sdr, int sdc, const float *src, int ssr, int ssc, int rows, int cols) {
+    mm(dst, sdr, sdc, nullptr, 0, 0, nullptr, 0, 0, rows, cols, 0, 0.f, src, ssr, ssc);
+  }
+  int launch(hipStream_t st) {
+    if (tab.n > FOLD_MAX_TASKS) { vrp_set_error("decoder_prepare: task table overflow"); return 2; }
+    hipLaunchKernelGGL(fold_tasks_kernel, dim3(tab.blocks), dim3(256), 0, st, tab);
+    VRP_CHECK_LAUNCH("fold_tasks");
+    return 0;
+  }
+};
 
 extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
                                    void *stream) {
@@ -121,300 +101,56 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(derived);
   const float *Wq = w->q_proj_weight, *bias = w->in_proj_bias;
-  int r = 0;
+  const float s = 0.08838834764831845f;   // 1/sqrt(128)   graph_decoder.py:97
+  const float c48 = 0.14433756729740643f; // 1/sqrt(48)    head dim of the glimpse attention
+  FoldBuilder a, b;
+  // ---- launch 1: everything that reads the raw parameters only ---------------------------
   if (kind != VRP_KIND_IRP) {
     // ctx = [graph_emb | first_ | last_]   graph_decoder.py:88
-    r |= cp(st, d.Wqf, 128, 1, Wq + 128, 384, 1, 384, 128);
-    r |= cp(st, d.Wproj, 128, 1, Wq + 256, 384, 1, 384, 128);
-    r |= cp(st, d.Wqg, 128, 1, Wq, 384, 1, 384, 128);
+    a.cp(d.Wqf, 128, 1, Wq + 128, 384, 1, 384, 128);
+    a.cp(d.Wproj, 128, 1, Wq + 256, 384, 1, 384, 128);
+    a.cp(d.Wqg, 128, 1, Wq, 384, 1, 384, 128);
     // qc0 = Wq_first * _first_node + Wq_last * _last_node   graph_decoder.py:79-81
-    r |= mm(st, d.qc0, 1, 0, Wq + 128, 384, 1, w->first_node, 1, 0, 384, 1, 128, 1.f, 0.f);
-    r |= mm(st, d.qc0, 1, 0, Wq + 256, 384, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 1.f);
-    r |= cp(st, d.wload, 0, 1, nullptr, 0, 0, 1, 384);
+    a.mm(d.qc0, 1, 0, Wq + 128, 384, 1, w->first_node, 1, 0, 384, 1, 128, 1.f);
+    b.mm(d.qc0, 1, 0, Wq + 256, 384, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, d.qc0, 1, 0);
+    a.cp(d.wload, 0, 1, nullptr, 0, 0, 1, 384);
+    // first-node query folded through the keys:
+    //   AfT[h*128+k][i] = sum_d Wk[48h+d][k] Wq_first[48h+d][i] / sqrt(48)
+    // (the bias part (Wq_first e_first) . bk is constant over the nodes of a head's score row:
+    // softmax-invariant, dropped)
+    for (int h = 0; h < 8; ++h)
+      a.mm(d.AfT + (size_t)h * 128 * 128, 128, 1, w->k_proj_weight + (size_t)h * 48 * 128, 1, 128,
+           Wq + (size_t)h * 48 * 384 + 128, 384, 1, 128, 128, 48, c48);
   } else {
     // ctx = _context_proj([graph_emb | last_ | load])   graph_decoder.py:90-91
     const float *Wc = w->context_proj_weight;  // (384,257)
-    r |= cp(st, d.Wqf, 0, 1, nullptr, 0, 0, 1, 384 * 128);
-    r |= mm(st, d.Wqg, 128, 1, Wq, 384, 1, Wc, 257, 1, 384, 128, 384, 1.f, 0.f);
-    r |= mm(st, d.Wproj, 128, 1, Wq, 384, 1, Wc + 128, 257, 1, 384, 128, 384, 1.f, 0.f);
-    r |= mm(st, d.wload, 1, 0, Wq, 384, 1, Wc + 256, 257, 0, 384, 1, 384, 1.f, 0.f);
-    r |= mm(st, d.qc0, 1, 0, d.Wproj, 128, 1, w->last_node, 1, 0, 384, 1, 128, 1.f, 0.f);
+    a.cp(d.Wqf, 0, 1, nullptr, 0, 0, 1, 384 * 128);
+    a.mm(d.Wqg, 128, 1, Wq, 384, 1, Wc, 257, 1, 384, 128, 384, 1.f);
+    a.mm(d.Wproj, 128, 1, Wq, 384, 1, Wc + 128, 257, 1, 384, 128, 384, 1.f);
+    a.mm(d.wload, 1, 0, Wq, 384, 1, Wc + 256, 257, 0, 384, 1, 384, 1.f);
+    b.mm(d.qc0, 1, 0, d.Wproj, 128, 1, w->last_node, 1, 0, 384, 1, 128, 1.f);
+    a.cp(d.AfT, 0, 1, nullptr, 0, 0, 1, 1024 * 128);
   }
-  r |= cp(st, d.Wproj + 384 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
-  r |= cp(st, d.bproj, 0, 1, nullptr, 0, 0, 1, 384);
-  r |= cp(st, d.bproj + 384, 0, 1, bias + 384, 0, 1, 1, 384);
-  r |= cp(st, d.bq, 0, 1, bias, 0, 1, 1, 384);
-  r |= cp(st, d.bv, 0, 1, bias + 768, 0, 1, 1, 384);
-  r |= cp(st, d.WvT, 1, 384, w->v_proj_weight, 128, 1, 384, 128);  // WvT[k][j] = Wv[j][k]
-  const float s = 0.08838834764831845f;  // 1/sqrt(128)   graph_decoder.py:97
-  // tmpA = Watt (128,384) * Wo (384,384);  M = s * Wkp^T tmpA;  MT[j][i] = M[i][j]
-  r |= mm(st, d.tmpA, 384, 1, w->att_output_weight, 384, 1, w->out_proj_weight, 384, 1, 128, 384,
-          384, 1.f, 0.f);
-  r |= mm(st, d.MT, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s, 0.f);
-  // tmpv = Watt * bo;  mb = s * Wkp^T tmpv
-  r |= mm(st, d.tmpv, 1, 0, w->att_output_weight, 384, 1, w->out_proj_bias, 1, 0, 128, 1, 384, 1.f,
-          0.f);
-  r |= mm(st, d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s, 0.f);
-  // per-node KM[m] = M^T e_m and VV[n] = Wv e_n + bv for the pointer-logit table
-  r |= cp(st, d.Wproj + (size_t)768 * 128, 128, 1, d.MT, 128, 1, 384, 128);
-  r |= cp(st, d.Wproj + (size_t)1152 * 128, 128, 1, w->v_proj_weight, 128, 1, 384, 128);
-  r |= cp(st, d.bproj + 768, 0, 1, nullptr, 0, 0, 1, 384);
-  r |= cp(st, d.bproj + 1152, 0, 1, bias + 768, 0, 1, 1, 384);
-  return r ? 1 : 0;
-}
-
-// ------------------------------------------------------------------ per-episode workspace
-struct DecWs {
-  float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
-  float *QG;     // (B,384)     Wq_g g + bq
-  float *PROJ;   // (B*N,P)     [QF | QL | KK] rows
-  float *SG, *C0, *SLD, *row0, *curs;  // (B,8,N) each; curs = next step's row (latency mode)
-  float *SL;                     // (B,N,8,N)  complete score row of every later step
-  float *Efirst, *QF1;           // (B,128) (B,384): first chosen node and its query part
-  float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:] (N <= 64)
-  float *cvec;                   // (B,N)                e_m . mb
-  int32_t *last, *first;         // (B)
-};
-
-#define VRP_RT_MAX_N 128  // above this the tile kernel (one raw-tile read per step) is used
-static bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
-static int proj_width(int kind, int N) {
-  (void)kind;
-  return 768 + (use_rtable(N) ? 768 : 0);  // [QL | KK] (+ [KM | VV])
-}
-static size_t rtable_floats(int B, int N) {
-  return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
-}
-
-static DecWs carve_decws(int kind, void *ws, int B, int N) {
-  char *p = (char *)ws;
-  DecWs w;
-  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
-  w.g = (float *)p;     p += vrp_align_up((size_t)B * 128 * 4);
-  w.QG = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
-  w.PROJ = (float *)p;  p += vrp_align_up(R * proj_width(kind, N) * 4);
-  w.SG = (float *)p;    p += vrp_align_up(hn);
-  w.C0 = (float *)p;    p += vrp_align_up(hn);
-  w.SLD = (float *)p;   p += vrp_align_up(hn);
-  w.row0 = (float *)p;  p += vrp_align_up(hn);
-  w.curs = (float *)p;  p += vrp_align_up(hn);
-  w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
-  w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
-  w.SL = (float *)p;    p += vrp_align_up(tb);
-  w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
-  w.cvec = (float *)p;  p += vrp_align_up(R * 4);
-  w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
-  w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
-  return w;
-}
-
-extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
-  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
-  return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
-                   vrp_align_up(R * proj_width(kind, N) * 4) + 5 * vrp_align_up(hn) +
-                   vrp_align_up(tb) + vrp_align_up((size_t)B * 128 * 4) +
-                   vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(rtable_floats(B, N) * 4) +
-                   vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
-}
-
-// graph embedding = mean over nodes (sum, then divide; graph_decoder.py:75-77) and
-// cvec[b][m] = e_m . mb in one launch: one workgroup per graph, threads 0..127 own an
-// embedding column of the mean, each wave owns every fourth node row of cvec.
-__global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__restrict__ emb,
-                                                              const float *__restrict__ mb, int N,
-                                                              float *__restrict__ g,
-                                                              float *__restrict__ cvec) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float *eb = emb + (size_t)b * N * VRP_EMB;
-  if (tid < VRP_EMB) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += eb[(size_t)n * VRP_EMB + tid];
-    g[(size_t)b * VRP_EMB + tid] = s / (float)N;
-  }
-  const float2 m = reinterpret_cast<const float2 *>(mb)[lane];
-  for (int n = wave; n < N; n += 4) {
-    const float2 e = reinterpret_cast<const float2 *>(eb + (size_t)n * VRP_EMB)[lane];
-    const float s = wave_sum(fmaf(e.x, m.x, e.y * m.y));
-    if (lane == 0) cvec[(size_t)b * N + n] = s;
-  }
-}
-
-// ------------------------------------------------------------------ tables on the matrix cores
-// All per-episode tables are per-(graph, head) products of two (N x 48) row blocks of PROJ:
-//   SL = QL KK^T / sqrt(48),  RT = KM VV^T,
-//   [SG; C0; SLD] = [QG; qc0; wload] KK^T / sqrt(48)        (three extra query rows)
-// One wave per (graph, head) runs them as 16x16 tiles of v_mfma_f32_16x16x4_f32 (exact
-// fp32).  The 48-long inner dimension is split over the four 16-lane groups: group q
-// holds k in [12q, 12q+12) of its row (three float4 loads), MFMA step s consumes element
-// s of every group -- a fixed permutation of k applied to both operands.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NTMAX>
-__device__ __forceinline__ void load_rows12(float (&dst)[12], const float *row_ptr, bool on) {
-  if (on) {
-#pragma unroll
-    for (int d = 0; d < 12; d += 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(row_ptr + d);
-      dst[d] = t.x; dst[d + 1] = t.y; dst[d + 2] = t.z; dst[d + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int d = 0; d < 12; ++d) dst[d] = 0.f;
-  }
-}
-
-// PHASE 0 (prologue): score rows SG / C0 / SLD, the step-0 row `row0` = SG + C0, the
-//   pointer-logit table RT and -- IRP only, whose context has no first-node term -- the
-//   last-node table with the constant row folded in: SL[m] = QL_m KK^T/sqrt(48) + SG.
-// PHASE 1 (TSP/VRP, right after step 0, when first_ is known, graph_decoder.py:111-113):
-//   base1 = SG + (Wq_first e_first).KK/sqrt(48), and SL[m] = QL_m KK^T/sqrt(48) + base1.
-// Either way a later step's complete glimpse score row is the single table row SL[b][last].
-template <int NTMAX, int PHASE>  // 16-column tiles per row: ceil(N/16) <= NTMAX
-__global__ __launch_bounds__(256) void pair_tables_kernel(
-    int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
-    const float *__restrict__ qc0, const float *__restrict__ wload, const float *__restrict__ QF1,
-    const int32_t *__restrict__ first, float *__restrict__ SG, float *__restrict__ C0,
-    float *__restrict__ SLD, float *__restrict__ SL, float *__restrict__ row0,
-    float *__restrict__ curs, float *__restrict__ RT) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x;
-  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
-  const int i16 = lane & 15, q = lane >> 4;
-  const int NT = (N + 15) >> 4;
-  const int qloff = 0, kkoff = 384, kmoff = 768, vvoff = 1152;
-  const int hq = h * VRP_HD + 12 * q;
-  const float c = 0.14433756729740643f;  // 1/sqrt(48)
-  const float *rows = PROJ + (size_t)b * N * P;
-  const size_t hn = ((size_t)b * 8 + h) * N;
-
-  float bf[NTMAX][12];
-  auto load_b = [&](int off) {
-#pragma unroll
-    for (int nt = 0; nt < NTMAX; ++nt) {
-      const int n = nt * 16 + i16;
-      load_rows12<NTMAX>(bf[nt], rows + (size_t)(n < N ? n : 0) * P + off + hq, nt < NT && n < N);
-    }
-  };
-  // one 16-row tile of A against every column tile; store(row, column tile, column, value)
-  auto tile_rows = [&](const float (&af)[12], auto &&store) {
-#pragma unroll
-    for (int nt = 0; nt < NTMAX; ++nt) {
-      if (nt < NT) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s_ = 0; s_ < 12; ++s_)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], bf[nt][s_], acc, 0, 0, 0);
-        const int n = nt * 16 + i16;  // D: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-        for (int r = 0; r < 4; ++r) store(q * 4 + r, nt, n, acc[r]);
-      }
-    }
-  };
-
-  // ---- glimpse score tables: B operand = projected keys -----------------------------
-  load_b(kkoff);
-  float base[NTMAX];  // constant part of every later score row, column nt*16 + i16
-#pragma unroll
-  for (int nt = 0; nt < NTMAX; ++nt) base[nt] = 0.f;
-  {
-    float af[12];
-    if (PHASE == 0) {
-      // three extra query rows: 0 = graph embedding + bq, 1 = step-0 placeholders, 2 = load
-      const float *src = (i16 == 0) ? QG + (size_t)b * VRP_D : (i16 == 1 ? qc0 : wload);
-      load_rows12<NTMAX>(af, src + hq, i16 < 3);
-    } else {
-      load_rows12<NTMAX>(af, QF1 + (size_t)b * VRP_D + hq, i16 == 0);  // row 0 = first-node query
-    }
-    float keep[NTMAX];  // row 0 of the tile lives in lanes q == 0, reg 0
-    tile_rows(af, [&](int r, int nt, int n, float v) {
-      v *= c;
-      if (r == 0) keep[nt] = v;
-      if (PHASE == 0 && n < N) {
-        if (r == 0) SG[hn + n] = v;
-        if (r == 1) { C0[hn + n] = v; row0[hn + n] = keep[nt] + v; }  // step-0 score row
-        if (r == 2) SLD[hn + n] = v;
-      }
-    });
-#pragma unroll
-    for (int nt = 0; nt < NTMAX; ++nt) {
-      if (nt < NT) {
-        float v = keep[nt];  // meaningful in lanes q == 0 only
-        if (PHASE == 1) {
-          const int n = nt * 16 + i16;
-          v += (n < N) ? SG[hn + n] : 0.f;
-        }
-        base[nt] = __shfl(v, i16, 64);  // lane i16 (q == 0) holds column i16 of this tile
-      }
-    }
-  }
-  if (PHASE == 1 || kind == VRP_KIND_IRP) {
-    // PHASE 1 also hands step 1 its row (last = first) for the latency-mode step kernel
-    const int fb = (PHASE == 1) ? first[b] : -1;
-    for (int mt = 0; mt < NT; ++mt) {
-      const int m = mt * 16 + i16;
-      const float *rp = rows + (size_t)(m < N ? m : 0) * P;
-      float af[12];
-      load_rows12<NTMAX>(af, rp + qloff + hq, m < N);
-      tile_rows(af, [&](int r, int nt, int n, float v) {
-        const int mm = mt * 16 + r;
-        if (mm < N && n < N) {
-          const float val = fmaf(v, c, base[nt]);
-          SL[(((size_t)b * N + mm) * 8 + h) * N + n] = val;
-          if (mm == fb) curs[hn + n] = val;
-        }
-      });
-    }
-  }
-  if (PHASE == 1) return;
-  // ---- pointer-logit table: B operand = projected values ------------------------------
-  load_b(vvoff);
-  for (int mt = 0; mt < NT; ++mt) {
-    const int m = mt * 16 + i16;
-    float af[12];
-    load_rows12<NTMAX>(af, rows + (size_t)(m < N ? m : 0) * P + kmoff + hq, m < N);
-    tile_rows(af, [&](int r, int nt, int n, float v) {
-      const int mm = mt * 16 + r;
-      if (mm < N && n < N) RT[(((size_t)b * N + mm) * 8 + h) * N + n] = v;
-    });
-  }
-}
-
-template <int PHASE>
-static int launch_pair_tables(int kind, int B, int N, int P, const float *PROJ, const float *QG,
-                              const float *qc0, const float *wload, const float *QF1,
-                              const int32_t *first, float *SG, float *C0, float *SLD, float *SL,
-                              float *row0, float *curs, float *RT, hipStream_t st) {
-  if (N <= 32)
-    hipLaunchKernelGGL((pair_tables_kernel<2, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
-  else if (N <= 64)
-    hipLaunchKernelGGL((pair_tables_kernel<4, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
-  else
-    hipLaunchKernelGGL((pair_tables_kernel<8, PHASE>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ,
-                       QG, qc0, wload, QF1, first, SG, C0, SLD, SL, row0, curs, RT);
-  VRP_CHECK_LAUNCH("pair_tables");
-  return 0;
-}
-
-extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
-                                   void *workspace, void *stream) {
-  VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
-  VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "decode_prologue: bad shape B=%d N=%d", B, N);
-  hipStream_t st = (hipStream_t)stream;
-  Derived d = carve_derived(const_cast<void *>(derived));
-  DecWs w = carve_decws(kind, workspace, B, N);
-  const int P = proj_width(kind, N);
-  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec);
-  VRP_CHECK_LAUNCH("graph_mean_cvec");
-  if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
-                                 st)) return r;
-  if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, w.PROJ, P, B * N, P,
-                                 128, 0, st)) return r;
-  VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
-  if (int r = launch_pair_tables<0>(kind, B, N, P, w.PROJ, w.QG, d.qc0, d.wload, nullptr, nullptr,
-                                    w.SG, w.C0, w.SLD, w.SL, w.row0, w.curs, w.RT, st)) return r;
-  return 0;
+  a.cp(d.Wproj + 384 * 128, 128, 1, w->k_proj_weight, 128, 1, 384, 128);
+  a.cp(d.Wproj + (size_t)1152 * 128, 128, 1, w->v_proj_weight, 128, 1, 384, 128);
+  // bproj = 0 | bk | 0 | bv;  bq;  bv
+  a.cp(d.bproj, 0, 1, nullptr, 0, 0, 1, 384);
+  a.cp(d.bproj + 384, 0, 1, bias + 384, 0, 1, 1, 384);
+  a.cp(d.bproj + 768, 0, 1, nullptr, 0, 0, 1, 384);
+  a.cp(d.bproj + 1152, 0, 1, bias + 768, 0, 1, 1, 384);
+  a.cp(d.bq, 0, 1, bias, 0, 1, 1, 384);
+  a.cp(d.bv, 0, 1, bias + 768, 0, 1, 1, 384);
+  a.cp(d.WvT, 1, 384, w->v_proj_weight, 128, 1, 384, 128);  // WvT[k][j] = Wv[j][k]
+  // tmpA = Watt (128,384) * Wo (384,384);  tmpv = Watt * bo
+  a.mm(d.tmpA, 384, 1, w->att_output_weight, 384, 1, w->out_proj_weight, 384, 1, 128, 384, 384, 1.f);
+  a.mm(d.tmpv, 1, 0, w->att_output_weight, 384, 1, w->out_proj_bias, 1, 0, 128, 1, 384, 1.f);
+  // ---- launch 2: M = s * Wkp^T tmpA (stored transposed, twice: MT and the KM block of
+  // Wproj);  mb = s * Wkp^T tmpv
+  b.mm(d.MT, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
+  b.mm(d.Wproj + (size_t)768 * 128, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
+  b.mm(d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s);
+  if (int r = a.launch(st)) return r;
+  return b.launch(st);
 }
 
 // Batch-wide "somebody is not done" flag.  Only zero / non-zero matters, the readers are
@@ -425,23 +161,11 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
 // first to skip the store +2..4 us (a round trip at the very end of every wave).
 __device__ __forceinline__ void flag_notdone(int32_t *flag) { *flag = 1; }
 
-// After the first step of a TSP/VRP episode first_ := embedding of the first chosen node
-// (graph_decoder.py:111-113) and stays fixed: its query part is folded ONCE into the
-// last-node table (pair_tables_kernel PHASE 1) instead of keeping an (N,8,N) table for every
-// possible first node.  Three launches after step 0: gather e_first,
-// QF1 = e_first Wq_first^T (MFMA GEMM), the table build.
-__global__ __launch_bounds__(128) void gather_first_kernel(const float *__restrict__ emb,
-                                                           const int32_t *__restrict__ first,
-                                                           int N, float *__restrict__ out) {
-  const int b = blockIdx.x, c = threadIdx.x;
-  out[(size_t)b * VRP_EMB + c] = emb[((size_t)b * N + first[b]) * VRP_EMB + c];
-}
-
 // ------------------------------------------------------------------ the step kernel
 struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only;
   const float *emb;
-  const float *row0, *SLD, *SL;
+  const float *row0, *SLD, *SL, *base;
   float *curs;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
@@ -492,6 +216,7 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
     const float *srow = (p.t == 0) ? p.row0 + (size_t)b * 8 * N
                                    : p.SL + ((size_t)b * N + last) * 8 * N;
     const float *sldp = p.SLD + (size_t)b * 8 * N;
+    const float *basep = p.base ? p.base + (size_t)b * 8 * N : nullptr;
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       const uint8_t *mrow = mask_in + (size_t)((b * 8 + h) % B) * N;  // QUIRK D3
@@ -503,6 +228,7 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
         s[i] = -INFINITY;
         if (n < N) {
           float v = srow[h * N + n];
+          if (p.t > 0 && basep) v += basep[h * N + n];
           if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sldp[h * N + n], v);
           s[i] = v + (float)mrow[n];
         }
@@ -809,7 +535,10 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   // (one dependent load: last[b] was written by the previous launch)
   // WPG == 1 is the latency mode of small batches: there the previous launch already copied
   // its table row into `curs`, so no launch starts with a pointer chase.
+  // (N > 80 only: the constant part lives in a second row, base[b]; the latency mode gets
+  // the sum pre-added)
   const float *srow = p.row0 + row;
+  const bool add_base = p.base && WPG != 1 && p.t > 0;
   if (p.t > 0) {
     if (WPG == 1) {
       srow = p.curs + row;
@@ -819,7 +548,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     }
   }
   int own_mask[NPL];
-  float sc[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
+  float sc[NPL][8], bs[NPL][8], sld[NPL][8], cv[NPL], q_noise[NPL];
   int msk[NPL][8];
   double2 xy[NPL];
   int vis[NPL];
@@ -830,6 +559,9 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       sc[i][h] = srow[h * N + ln[i]];
+      // (added at the softmax, not here: an add at this point would wait for this load and,
+      // vmcnt being in order, for every load issued before it)
+      bs[i][h] = add_base ? p.base[row + h * N + ln[i]] : 0.f;
       sld[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
       msk[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
     }
@@ -906,7 +638,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        float v = sc[i][h];
+        float v = sc[i][h] + bs[i][h];
         if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sld[i][h], v);
         v = inN[i] ? v + (float)msk[i][h] : -INFINITY;
         s[i][h] = v;
@@ -1037,7 +769,8 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
-      for (int h = 0; h < 8; ++h) sl[i][h] = arow[h * N + ln[i]];
+      for (int h = 0; h < 8; ++h)
+        sl[i][h] = arow[h * N + ln[i]] + (p.base ? p.base[row + h * N + ln[i]] : 0.f);
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
@@ -1155,12 +888,13 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   VRP_REQUIRE(use_rtable(N) || N <= 104, "decode_step: tile kernel supports N <= 104");
   VRP_REQUIRE(!(flags & VRP_STEP_TILE_KERNEL) || N <= 104, "decode_step: tile kernel supports N <= 104");
   Derived d = carve_derived(const_cast<void *>(derived));
-  DecWs ws = carve_decws(kind, workspace, B, N);
+  DecWs ws = carve_decws(workspace, B, N);
   StepParams p;
   p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps; p.sample = sample;
   p.decode_only = decode_only;
   p.emb = emb;
   p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
+  p.base = (kind == VRP_KIND_IRP) ? nullptr : ws.base;  // IRP: the constant row is inside SL
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
   p.RT = ws.RT; p.cvec = ws.cvec;
@@ -1171,28 +905,6 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   if (t == 0 && kind != VRP_KIND_IRP && !(flags & VRP_STEP_NO_FIRST_ROW))
     return vrp_decode_first_row(kind, derived, B, N, emb, workspace, stream);
   return 0;
-}
-
-// first_ is known after step 0: build the last-node table with its query part folded in
-extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
-                                    void *workspace, void *stream) {
-  VRP_REQUIRE(derived && emb && workspace, "decode_first_row: NULL argument");
-  if (kind == VRP_KIND_IRP) return 0;  // no first-node term: the prologue built the table
-  hipStream_t st = (hipStream_t)stream;
-  Derived d = carve_derived(const_cast<void *>(derived));
-  DecWs ws = carve_decws(kind, workspace, B, N);
-  const int P = proj_width(kind, N);
-  // QF1 = e_first Wq_first^T: gather fused into the small-problem GEMM when the shape allows
-  const int gr = vrp_launch_gemm_gather_k128(emb, 128, ws.first, N, d.Wqf, 128, ws.QF1, 384, B, 384, st);
-  if (gr > 0) return gr;
-  if (gr < 0) {
-    hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
-    VRP_CHECK_LAUNCH("gather_first");
-    if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.Wqf, 128, nullptr, nullptr, 0, ws.QF1, 384, B,
-                                   384, 128, 0, st)) return r;
-  }
-  return launch_pair_tables<1>(kind, B, N, P, ws.PROJ, ws.QG, d.qc0, d.wload, ws.QF1, ws.first, ws.SG,
-                               ws.C0, ws.SLD, ws.SL, ws.row0, ws.curs, ws.RT, st);
 }
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)

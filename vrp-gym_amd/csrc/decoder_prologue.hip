@@ -1,0 +1,636 @@
+// Per-episode constants of the decoder (D2/D3 hoisting): everything in
+// GraphDecoder.forward (agents/graph_decoder.py:75-98) that does not depend on the step.
+//
+//   SL[b][m][h][n]  = (Wq_last e_m)_h . (Wk e_n + bk)_h / sqrt(48)    last-node part of the score
+//   RT[b][m][h][n]  = (M^T e_m)_h . (Wv e_n + bv)_h                   pointer-logit table
+//   SG, C0, SLD     = [Wq_g g + bq ; qc0 ; wload]_h . (Wk e_n + bk)_h / sqrt(48)
+//   row0 = SG + C0 (the step-0 score row);  base = SG (IRP) or, after step 0 (TSP/VRP,
+//   first_ known: graph_decoder.py:111-113), SG + (Wq_first e_first)_h . (Wk e_n)_h / sqrt(48)
+//
+// N <= 80: ONE kernel projects the embedding rows AND builds the tables: the projected rows
+// ([QL | KK | KM | VV], 1536 floats per node: 2 GB at 8192 x 40) never exist in memory.
+// N > 80: projection GEMM into PROJ, then pair_tables_kernel.
+#include "decoder_ws.h"
+
+// graph embedding = mean over nodes (sum, then divide; graph_decoder.py:75-77) and
+// cvec[b][m] = e_m . mb in one launch: one workgroup per graph, threads 0..127 own an
+// embedding column of the mean, each wave owns every fourth node row of cvec.
+__global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__restrict__ emb,
+                                                              const float *__restrict__ mb, int N,
+                                                              float *__restrict__ g,
+                                                              float *__restrict__ cvec) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *eb = emb + (size_t)b * N * VRP_EMB;
+  if (tid < VRP_EMB) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += eb[(size_t)n * VRP_EMB + tid];
+    g[(size_t)b * VRP_EMB + tid] = s / (float)N;
+  }
+  const float2 m = reinterpret_cast<const float2 *>(mb)[lane];
+  for (int n = wave; n < N; n += 4) {
+    const float2 e = reinterpret_cast<const float2 *>(eb + (size_t)n * VRP_EMB)[lane];
+    const float s = wave_sum(fmaf(e.x, m.x, e.y * m.y));
+    if (lane == 0) cvec[(size_t)b * N + n] = s;
+  }
+}
+
+// ------------------------------------------------------------------ fused projection + tables
+// Work unit = (pack of G consecutive graphs, head h).  A pack's G*N <= 80 embedding rows are
+// RT <= 5 tiles of 16 rows of the flat (B*N,128) matrix (N = 20: four graphs in five tiles
+// instead of eight; N = 40: two graphs in five instead of six).  One WAVE owns a unit from
+// the embedding rows to the finished tables -- no workgroup barrier after the weights are
+// staged:
+//   stage 1  P_X^T (48 x 16RT) = W_{X,h} (48 x 128) E^T for X in {QL, KK, KM, VV}:
+//            v_mfma_f32_16x16x4_f32 with the head's weight slices in LDS (A operand, one
+//            ds_read_b128 per 4 k-steps, reused by all node tiles) and the embedding rows in
+//            registers (B operand, lane = node: 32 contiguous floats of its row).  The
+//            result sits transposed in the accumulators: lane (node j, group q) holds
+//            projection columns 16c + 4q + reg of node j --
+//   stage 2  -- which IS the operand layout of the next product: SL tile = QL KK^T and RT
+//            tile = KM VV^T run as 12 MFMAs per 16 x 16 tile straight from those registers
+//            (k = projection column; both operands use the same column -> (group, step)
+//            map), then go to memory.
+// Two halves -- (QL, KK) -> score tables, (KM, VV) -> logit table -- keep at most 2 x 3 x RT
+// accumulator tiles live.  The next pack's embedding rows are requested before the last
+// stage 2 starts.
+// MODE 0 (IRP): everything in the prologue; the constant score row SG is folded into SL.
+// MODE 1 (TSP/VRP prologue): KK, KM, VV -> SG / C0 / row0 / SLD and RT; the projected keys
+//        (accumulator registers as they stand, 1 KB per store) are kept for MODE 2.
+// MODE 2 (TSP/VRP after step 0, first_ known: graph_decoder.py:111-113): QL + the stored keys
+//        -> base = SG + (Wq_first e_first) . K / sqrt(48), SL = QL K^T / sqrt(48) + base: a
+//        later step reads ONE score row, SL[b][last]; the row of the first node also goes to
+//        `curs` for step 1 of the latency-mode step kernel.
+// The 128-long inner dimension of stage 1 is split over the four 16-lane groups as
+// k = koff(q) + s, koff = {0, 64, 32, 96}: with LDS rows of 132 floats the two lane groups
+// that one ds_read_b128 pass serves together (q = 0 with 1, 2 with 3) are 64 floats apart,
+// which makes the 16-byte reads conflict-free.
+#define PT_LD 132
+#define PT_MAXROWS 80
+struct PrologueParams {
+  int kind, B, N, G, npacks;
+  const float *emb, *Wproj, *bproj, *QG, *qc0, *wload, *QF1;
+  const int32_t *first;
+  float *SG, *C0, *SLD, *row0, *curs, *SL, *RT, *KKbuf;
+};
+
+template <int RT_, int MODE>
+__global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *wl = lds;                              // [4][48][PT_LD] weight slices of this head
+  float *bl = wl + 4 * 48 * PT_LD;              // [4][48] bias slices
+  int *rowinfo = reinterpret_cast<int *>(bl + 4 * 48);  // [80] row of a pack -> graph << 8 | node
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j16 = lane & 15, q = lane >> 4;
+  const int N = p.N, G = p.G;
+  // blocks b and b + 8 share an XCD (round-robin dispatch): the eight heads of a pack run on
+  // one XCD at about the same time and share its embedding rows through that L2
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int h = jj & 7, sub = jj >> 3, nsub = gridDim.x >> 6;
+  const int stride = 8 * nsub * 4;
+  const int first = (xcd * nsub + sub) * 4 + wave;
+  constexpr int X_LO = (MODE == 1) ? 1 : 0, X_HI = (MODE == 2) ? 1 : 4;  // slices needed
+
+  for (int i = tid; i < (X_HI - X_LO) * 48 * 32; i += 256) {
+    const int c4 = i & 31, row = (i >> 5) % 48, X = X_LO + i / (48 * 32);
+    const float4 v = *reinterpret_cast<const float4 *>(
+        p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
+    *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
+  }
+  if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
+  if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
+  // tile pairs (tm, tn) that contain two nodes of one graph (wave-uniform bit mask)
+  unsigned needmask = 0;
+  {
+    const int rows = G * N;
+#pragma unroll
+    for (int tm = 0; tm < RT_; ++tm) {
+      const int lo_m = (16 * tm) / N, hi_m = min(16 * tm + 15, rows - 1) / N;
+#pragma unroll
+      for (int tn = 0; tn < RT_; ++tn) {
+        const int lo_n = (16 * tn) / N, hi_n = min(16 * tn + 15, rows - 1) / N;
+        if (16 * tm < rows && 16 * tn < rows && lo_m <= hi_n && lo_n <= hi_m)
+          needmask |= 1u << (tm * RT_ + tn);
+      }
+    }
+  }
+  __syncthreads();
+
+  const int koff = 64 * (q & 1) + 32 * (q >> 1);
+  const float c48 = 0.14433756729740643f;  // 1/sqrt(48)
+  float ef[RT_][32];
+  auto load_pack = [&](int pack) {
+    const size_t R0 = (size_t)pack * G * N;
+    const int valid = min(G, p.B - pack * G) * N;
+#pragma unroll
+    for (int r = 0; r < RT_; ++r) {
+      const int row = 16 * r + j16;
+      const float4 *src = reinterpret_cast<const float4 *>(
+          p.emb + (R0 + (row < valid ? row : 0)) * VRP_EMB + koff);
+#pragma unroll
+      for (int k4 = 0; k4 < 8; ++k4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < valid) v = src[k4];
+        ef[r][4 * k4] = v.x; ef[r][4 * k4 + 1] = v.y; ef[r][4 * k4 + 2] = v.z; ef[r][4 * k4 + 3] = v.w;
+      }
+    }
+  };
+  if (first < p.npacks) load_pack(first);
+
+  for (int pack = first; pack < p.npacks; pack += stride) {
+    // (the weight slices are re-read from LDS for every pack: keeping them in registers
+    // across the loop would cost up to 384 VGPRs)
+    asm volatile("" ::: "memory");
+    const int g0 = pack * G;                       // first graph of the pack
+    const int valid = min(G, p.B - g0) * N;        // rows of the pack that exist
+    // Stage 2 computes TRANSPOSED tiles D[n][m] (A = keys/values of node tile tn, B = queries
+    // of node tile tm): lane (j, q) then holds, for query row m = 16tm + j, the four
+    // consecutive key columns n = 16tn + 4q + {0..3} -> one 16-byte store per tile and lane.
+    // mrow*: row m of this lane per tile; ncol*: first of its four columns per tile.
+    int mg[RT_], moff[RT_], mnode[RT_];   // graph of the pack (-2: none), table offset, node
+    int ng[RT_], nn0[RT_];                // graph (-1: none) and node of column 16tn + 4q
+#pragma unroll
+    for (int t = 0; t < RT_; ++t) {
+      const int row = 16 * t + j16;
+      const int ri = rowinfo[row < PT_MAXROWS ? row : 0];
+      mg[t] = (row < valid) ? (ri >> 8) : -2;
+      mnode[t] = ri & 255;
+      moff[t] = (((ri >> 8) * N + (ri & 255)) * 8 + h) * N;
+      const int col = 16 * t + 4 * q;
+      const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
+      ng[t] = (col < valid) ? (ci >> 8) : -1;
+      nn0[t] = ci & 255;
+    }
+    const bool vec = (N & 3) == 0;  // four consecutive columns never straddle two graphs
+    float4 *kkbuf = reinterpret_cast<float4 *>(p.KKbuf) + ((size_t)pack * 8 + h) * (3 * RT_) * 64 + lane;
+    // Every global load of this pack is issued HERE, ahead of the ~15 k cycles of stage-1
+    // MFMAs that separate it from its first use: a SIMD runs one wave of this kernel, so an
+    // exposed memory round trip is a stalled matrix pipe.
+    // extra query rows per graph g of the pack, as B columns 4g + x.
+    // MODE 0/1: x = 0: Wq_g g + bq, 1: step-0 placeholders, 2: load coefficient;
+    // MODE 2:   x = 0: Wq_first e_first
+    const int xg = j16 >> 2, xx = j16 & 3;
+    const bool xon = xx < (MODE == 2 ? 1 : 3) && xg < G && g0 + xg < p.B;
+    float ex[3][4];
+    {
+      const float *src;
+      if (MODE == 2) src = p.QF1 + (size_t)(g0 + (xon ? xg : 0)) * VRP_D;
+      else src = (xx == 0) ? p.QG + (size_t)(g0 + (xon ? xg : 0)) * VRP_D : (xx == 1 ? p.qc0 : p.wload);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (xon) v = *reinterpret_cast<const float4 *>(src + h * VRP_HD + 16 * c + 4 * q);
+        ex[c][0] = v.x; ex[c][1] = v.y; ex[c][2] = v.z; ex[c][3] = v.w;
+      }
+    }
+    f32x4 kk[3][RT_];        // MODE 2: the keys MODE 1 stored
+    float sgv[RT_][4];       // MODE 2: SG of this lane's extra-row graph at its four columns
+    int cursoff[RT_];        // MODE 2: >= 0 where this lane's row is the first chosen node
+    if (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < RT_; ++r) {
+          const float4 v = kkbuf[(size_t)(c * RT_ + r) * 64];
+          kk[c][r] = f32x4{v.x, v.y, v.z, v.w};
+        }
+#pragma unroll
+      for (int tn = 0; tn < RT_; ++tn) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int col = 16 * tn + 4 * q + r4;
+          const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
+          const bool ok = xon && col < valid && (ci >> 8) == xg;
+          sgv[tn][r4] = ok ? p.SG[((size_t)(g0 + xg) * 8 + h) * N + (ci & 255)] : 0.f;
+        }
+        cursoff[tn] = -1;
+        if (mg[tn] >= 0 && mnode[tn] == p.first[g0 + mg[tn]]) cursoff[tn] = (mg[tn] * 8 + h) * N;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int H = 0; H < (MODE == 2 ? 1 : 2); ++H) {
+      // ---- stage 1: transposed projections ----------------------------------------------
+      f32x4 acc[2][3][RT_];
+#pragma unroll
+      for (int Y = 0; Y < 2; ++Y)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int X = 2 * H + Y;
+          if (MODE == 1 && X == 0) continue;    // QL is projected after step 0 (MODE 2)
+          if (MODE == 2 && X == 1) {            // the keys MODE 1 stored
+#pragma unroll
+            for (int r = 0; r < RT_; ++r) acc[Y][c][r] = kk[c][r];
+            continue;
+          }
+          // accumulators start at the bias of their projection columns 16c + 4q + reg (bk
+          // for the keys, bv for the values, zero otherwise)
+          const float4 bb = *reinterpret_cast<const float4 *>(bl + X * 48 + 16 * c + 4 * q);
+#pragma unroll
+          for (int r = 0; r < RT_; ++r) acc[Y][c][r] = f32x4{bb.x, bb.y, bb.z, bb.w};
+          const float *wrow = wl + (X * 48 + 16 * c + j16) * PT_LD + koff;
+          __builtin_amdgcn_sched_barrier(0);  // no hoisting of every slice's LDS reads
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            const float4 a = *reinterpret_cast<const float4 *>(wrow + 4 * k4);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int r = 0; r < RT_; ++r)
+                acc[Y][c][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], ef[r][4 * k4 + e],
+                                                                   acc[Y][c][r], 0, 0, 0);
+          }
+          if (MODE == 1 && X == 1) {
+#pragma unroll
+            for (int r = 0; r < RT_; ++r)
+              kkbuf[(size_t)(c * RT_ + r) * 64] =
+                  make_float4(acc[Y][c][r][0], acc[Y][c][r][1], acc[Y][c][r][2], acc[Y][c][r][3]);
+          }
+        }
+      if (H == (MODE == 2 ? 0 : 1)) {  // the next pack's rows: requested before the last stage 2
+        const int nxt = pack + stride;
+        if (nxt < p.npacks) load_pack(nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // constant part of the score rows for this lane's four columns of every tile
+      float bcol[RT_][4];
+#pragma unroll
+      for (int tn = 0; tn < RT_; ++tn)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) bcol[tn][r4] = 0.f;
+      if (H == 0) {
+        // ---- extra query rows (loaded at the top of the iteration) ------------------------
+        const int g = xg, x = xx;
+        const bool on = xon;
+#pragma unroll
+        for (int tn = 0; tn < RT_; ++tn) {
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              d = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], ex[c][r4], d, 0, 0, 0);
+          // D[n][i]: lane (i = 4g + x, q), register r4 = column n = 16tn + 4q + r4
+          float v[4] = {d[0] * c48, d[1] * c48, d[2] * c48, d[3] * c48};
+          float c0[4];  // the x = 1 row, fetched from the neighbouring lane
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) c0[r4] = __shfl_down(v[r4], 1, 64);
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int col = 16 * tn + 4 * q + r4;
+            int gn = ng[tn], nn = nn0[tn] + r4;
+            if (!vec) {
+              const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
+              gn = (col < valid) ? (ci >> 8) : -1;
+              nn = ci & 255;
+            }
+            const size_t o = ((size_t)(g0 + g) * 8 + h) * N + nn;
+            if (gn == g && on) {
+              if (MODE == 2) {
+                v[r4] += sgv[tn][r4];
+              } else {
+                if (x == 0) { p.SG[o] = v[r4]; p.row0[o] = v[r4] + c0[r4]; }  // row0: step-0 row
+                if (x == 1) p.C0[o] = v[r4];
+                if (x == 2) p.SLD[o] = v[r4];
+              }
+            }
+            // the lane that holds column `col` of its graph gn is (4 gn, q): broadcast over j
+            if (MODE == 2 || (MODE == 0 && p.kind == VRP_KIND_IRP))
+              bcol[tn][r4] = __shfl(v[r4], (q << 4) | (4 * (gn < 0 ? 0 : gn)), 64);
+          }
+        }
+        if (MODE == 1) continue;  // SL is built after step 0
+      }
+      // ---- stage 2: table tiles straight from the accumulators ---------------------------
+      // Addresses: one 64-bit base per pack, 32-bit element offsets inside it (a pack's
+      // slice of a table is at most 4 x 80 x 8 x 80 floats).
+      float *tab = (H ? p.RT : p.SL) + (size_t)g0 * N * 8 * N;
+      float *cursp = p.curs + (size_t)g0 * 8 * N;
+      const float scale = H ? 1.f : c48;
+#pragma unroll
+      for (int tm = 0; tm < RT_; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < RT_; ++tn) {
+          if (!((needmask >> (tm * RT_ + tn)) & 1u)) continue;
+          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              d = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], acc[0][c][tm][r4], d, 0, 0, 0);
+          float v[4];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) v[r4] = fmaf(d[r4], scale, bcol[tn][r4]);
+          if (vec) {
+            if (mg[tm] == ng[tn]) {
+              *reinterpret_cast<float4 *>(tab + moff[tm] + nn0[tn]) = make_float4(v[0], v[1], v[2], v[3]);
+              if (MODE == 2 && cursoff[tm] >= 0)
+                *reinterpret_cast<float4 *>(cursp + cursoff[tm] + nn0[tn]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          } else {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int col = 16 * tn + 4 * q + r4;
+              const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
+              if (col < valid && (ci >> 8) == mg[tm]) {
+                tab[moff[tm] + (ci & 255)] = v[r4];
+                if (MODE == 2 && cursoff[tm] >= 0) cursp[cursoff[tm] + (ci & 255)] = v[r4];
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int RT_, int MODE>
+static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
+  const size_t lds = sizeof(float) * (4 * 48 * PT_LD + 4 * 48) + sizeof(int) * PT_MAXROWS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("prologue_tables: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  // one workgroup per CU (100 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
+  // batch has fewer packs than wave slots
+  int nsub = 4;
+  while (nsub > 1 && 8 * (nsub / 2) * 4 >= p.npacks) nsub /= 2;
+  hipLaunchKernelGGL((prologue_tables_kernel<RT_, MODE>), dim3(64 * nsub), dim3(256), lds, st, p);
+  VRP_CHECK_LAUNCH("prologue_tables");
+  return 0;
+}
+
+template <int MODE>
+static int launch_prologue_mode(const PrologueParams &p, hipStream_t st) {
+  switch ((p.G * p.N + 15) / 16) {
+    case 1: return launch_prologue_tables<1, MODE>(p, st);
+    case 2: return launch_prologue_tables<2, MODE>(p, st);
+    case 3: return launch_prologue_tables<3, MODE>(p, st);
+    case 4: return launch_prologue_tables<4, MODE>(p, st);
+    default: return launch_prologue_tables<5, MODE>(p, st);
+  }
+}
+
+static PrologueParams prologue_params(int kind, int B, int N, const float *emb, const Derived &d,
+                                      const DecWs &w) {
+  PrologueParams p;
+  p.kind = kind; p.B = B; p.N = N;
+  int G = PT_MAXROWS / N;
+  if (G > 4) G = 4;
+  if (G > B) G = B;
+  p.G = G;
+  p.npacks = (B + G - 1) / G;
+  p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
+  p.QF1 = w.QF1; p.first = w.first;
+  p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.curs = w.curs; p.SL = w.SL; p.RT = w.RT;
+  p.KKbuf = w.KKbuf;
+  return p;
+}
+
+// ------------------------------------------------------------------ unfused path (N > 80)
+// Per-(graph, head) products of two (N x 48) row blocks of PROJ on v_mfma_f32_16x16x4_f32,
+// one wave per (graph, head).  The 48-long inner dimension is split over the four 16-lane
+// groups: group q holds k in [12q, 12q+12) of its row (three float4 loads), MFMA step s
+// consumes element s of every group -- a fixed permutation of k applied to both operands.
+template <int NTMAX>
+__device__ __forceinline__ void load_rows12(float (&dst)[12], const float *row_ptr, bool on) {
+  if (on) {
+#pragma unroll
+    for (int d = 0; d < 12; d += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(row_ptr + d);
+      dst[d] = t.x; dst[d + 1] = t.y; dst[d + 2] = t.z; dst[d + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 12; ++d) dst[d] = 0.f;
+  }
+}
+
+template <int NTMAX>  // 16-column tiles per row: ceil(N/16) <= NTMAX
+__global__ __launch_bounds__(256) void pair_tables_kernel(
+    int kind, int N, int P, const float *__restrict__ PROJ, const float *__restrict__ QG,
+    const float *__restrict__ qc0, const float *__restrict__ wload, float *__restrict__ SG,
+    float *__restrict__ C0, float *__restrict__ SLD, float *__restrict__ SL,
+    float *__restrict__ row0, float *__restrict__ RT) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x;
+  const int h = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + (threadIdx.x >> 6));
+  const int i16 = lane & 15, q = lane >> 4;
+  const int NT = (N + 15) >> 4;
+  const int qloff = 0, kkoff = 384, kmoff = 768, vvoff = 1152;
+  const int hq = h * VRP_HD + 12 * q;
+  const float c = 0.14433756729740643f;  // 1/sqrt(48)
+  const float *rows = PROJ + (size_t)b * N * P;
+  const size_t hn = ((size_t)b * 8 + h) * N;
+
+  float bf[NTMAX][12];
+  auto load_b = [&](int off) {
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) {
+      const int n = nt * 16 + i16;
+      load_rows12<NTMAX>(bf[nt], rows + (size_t)(n < N ? n : 0) * P + off + hq, nt < NT && n < N);
+    }
+  };
+  // one 16-row tile of A against every column tile; store(row, column tile, column, value)
+  auto tile_rows = [&](const float (&af)[12], auto &&store) {
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) {
+      if (nt < NT) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < 12; ++s_)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s_], bf[nt][s_], acc, 0, 0, 0);
+        const int n = nt * 16 + i16;  // D: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store(q * 4 + r, nt, n, acc[r]);
+      }
+    }
+  };
+
+  // ---- glimpse score tables: B operand = projected keys -----------------------------
+  load_b(kkoff);
+  float cbase[NTMAX];  // IRP: the constant row SG, folded into every row of SL
+#pragma unroll
+  for (int nt = 0; nt < NTMAX; ++nt) cbase[nt] = 0.f;
+  {
+    float af[12];
+    // three extra query rows: 0 = graph embedding + bq, 1 = step-0 placeholders, 2 = load
+    const float *src = (i16 == 0) ? QG + (size_t)b * VRP_D : (i16 == 1 ? qc0 : wload);
+    load_rows12<NTMAX>(af, src + hq, i16 < 3);
+    float keep[NTMAX];  // row 0 of the tile lives in lanes q == 0, reg 0
+#pragma unroll
+    for (int nt = 0; nt < NTMAX; ++nt) keep[nt] = 0.f;
+    tile_rows(af, [&](int r, int nt, int n, float v) {
+      v *= c;
+      if (r == 0) keep[nt] = v;
+      if (n < N) {
+        if (r == 0) SG[hn + n] = v;
+        if (r == 1) { C0[hn + n] = v; row0[hn + n] = keep[nt] + v; }  // step-0 score row
+        if (r == 2) SLD[hn + n] = v;
+      }
+    });
+    if (kind == VRP_KIND_IRP) {  // no first-node term (graph_decoder.py:90-91)
+#pragma unroll
+      for (int nt = 0; nt < NTMAX; ++nt)
+        if (nt < NT) cbase[nt] = __shfl(keep[nt], i16, 64);  // lane i16 (q == 0) holds column i16
+    }
+  }
+  for (int mt = 0; mt < NT; ++mt) {
+    const int m = mt * 16 + i16;
+    float af[12];
+    load_rows12<NTMAX>(af, rows + (size_t)(m < N ? m : 0) * P + qloff + hq, m < N);
+    tile_rows(af, [&](int r, int nt, int n, float v) {
+      const int mm = mt * 16 + r;
+      if (mm < N && n < N) SL[(((size_t)b * N + mm) * 8 + h) * N + n] = fmaf(v, c, cbase[nt]);
+    });
+  }
+  // ---- pointer-logit table: B operand = projected values ------------------------------
+  load_b(vvoff);
+  for (int mt = 0; mt < NT; ++mt) {
+    const int m = mt * 16 + i16;
+    float af[12];
+    load_rows12<NTMAX>(af, rows + (size_t)(m < N ? m : 0) * P + kmoff + hq, m < N);
+    tile_rows(af, [&](int r, int nt, int n, float v) {
+      const int mm = mt * 16 + r;
+      if (mm < N && n < N) RT[(((size_t)b * N + mm) * 8 + h) * N + n] = v;
+    });
+  }
+}
+
+// ------------------------------------------------------------------ score base after step 0
+// TSP/VRP: base[b][h][n] = SG[b][h][n] + FK[b][h][:] . e_n, FK = AfT e_first (the first chosen
+// node's query part folded through the keys).  One wave per graph: D (16 x 16 per node tile)
+// = FK rows (8 heads, zero-padded to 16) x E^T on v_mfma_f32_16x16x4_f32, k split as in the
+// prologue kernel.  Also hands step 1 its complete row (last = first) for the latency-mode
+// step kernel: curs = SL[b][first] + base.
+template <int NTMAX>
+__global__ __launch_bounds__(256) void score_base_kernel(int B, int N, const float *__restrict__ emb,
+                                                         const float *__restrict__ FK,
+                                                         const float *__restrict__ SG,
+                                                         const float *__restrict__ SL,
+                                                         const int32_t *__restrict__ first,
+                                                         float *__restrict__ base,
+                                                         float *__restrict__ curs) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int j16 = lane & 15, q = lane >> 4;
+  const int koff = 64 * (q & 1) + 32 * (q >> 1);
+  const int NT = (N + 15) >> 4;
+  float af[32];  // A row j16 = head (rows 8..15 are zero)
+  {
+    const float4 *src = reinterpret_cast<const float4 *>(FK + (size_t)b * 1024 + (j16 & 7) * 128 + koff);
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j16 < 8) v = src[k4];
+      af[4 * k4] = v.x; af[4 * k4 + 1] = v.y; af[4 * k4 + 2] = v.z; af[4 * k4 + 3] = v.w;
+    }
+  }
+  const int fb = first[b];
+#pragma unroll
+  for (int nt = 0; nt < NTMAX; ++nt) {
+    if (nt >= NT) break;
+    const int n = 16 * nt + j16;
+    const float4 *src = reinterpret_cast<const float4 *>(
+        emb + ((size_t)b * N + (n < N ? n : 0)) * VRP_EMB + koff);
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) v = src[k4];
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4], v.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4 + 1], v.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4 + 2], v.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4 + 3], v.w, d, 0, 0, 0);
+    }
+    // D: lane (node j, q), register r4 = head 4q + r4 (q < 2)
+    if (q < 2 && n < N) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int h = 4 * q + r4;
+        const size_t o = ((size_t)b * 8 + h) * N + n;
+        const float v = SG[o] + d[r4];
+        base[o] = v;
+        curs[o] = SL[(((size_t)b * N + fb) * 8 + h) * N + n] + v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void gather_first_kernel(const float *__restrict__ emb,
+                                                           const int32_t *__restrict__ first,
+                                                           int N, float *__restrict__ out) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  out[(size_t)b * VRP_EMB + c] = emb[((size_t)b * N + first[b]) * VRP_EMB + c];
+}
+
+extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
+  (void)kind;
+  return decws_bytes(B, N);
+}
+
+extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
+                                   void *workspace, void *stream) {
+  VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
+  VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "decode_prologue: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
+  hipStream_t st = (hipStream_t)stream;
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs w = carve_decws(workspace, B, N);
+  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec);
+  VRP_CHECK_LAUNCH("graph_mean_cvec");
+  if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
+                                 st)) return r;
+  if (use_fused_prologue(N)) {
+    const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
+    return launch_prologue_mode<0>(p, st);
+  }
+  const int P = proj_width(N);
+  float *PROJ = w.PROJ;
+  if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, PROJ, P, B * N, P,
+                                 128, 0, st)) return r;
+  hipLaunchKernelGGL((pair_tables_kernel<8>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ, w.QG,
+                     d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.row0, w.RT);
+  VRP_CHECK_LAUNCH("pair_tables");
+  return 0;
+}
+
+// first_ is known after step 0 (graph_decoder.py:111-113): its query part, folded through the
+// keys, completes the constant part of every later score row
+extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
+                                    void *workspace, void *stream) {
+  VRP_REQUIRE(derived && emb && workspace, "decode_first_row: NULL argument");
+  if (kind == VRP_KIND_IRP) return 0;  // no first-node term: the prologue folded SG into SL
+  hipStream_t st = (hipStream_t)stream;
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs ws = carve_decws(workspace, B, N);
+  // base = SG + FK . e_n with FK = e_first AfT^T, read by the steps as a second row
+  const int gr = vrp_launch_gemm_gather_k128(emb, 128, ws.first, N, d.AfT, 128, ws.FK, 1024, B, 1024, st);
+  if (gr > 0) return gr;
+  if (gr < 0) {
+    hipLaunchKernelGGL(gather_first_kernel, dim3(B), dim3(128), 0, st, emb, ws.first, N, ws.Efirst);
+    VRP_CHECK_LAUNCH("gather_first");
+    if (int r = vrp_launch_gemm_nt(ws.Efirst, 128, d.AfT, 128, nullptr, nullptr, 0, ws.FK, 1024, B,
+                                   1024, 128, 0, st)) return r;
+  }
+  if (N <= 32)
+    hipLaunchKernelGGL((score_base_kernel<2>), dim3((B + 3) / 4), dim3(256), 0, st, B, N, emb, ws.FK,
+                       ws.SG, ws.SL, ws.first, ws.base, ws.curs);
+  else if (N <= 64)
+    hipLaunchKernelGGL((score_base_kernel<4>), dim3((B + 3) / 4), dim3(256), 0, st, B, N, emb, ws.FK,
+                       ws.SG, ws.SL, ws.first, ws.base, ws.curs);
+  else
+    hipLaunchKernelGGL((score_base_kernel<8>), dim3((B + 3) / 4), dim3(256), 0, st, B, N, emb, ws.FK,
+                       ws.SG, ws.SL, ws.first, ws.base, ws.curs);
+  VRP_CHECK_LAUNCH("score_base");
+  return 0;
+}

@@ -1,0 +1,141 @@
+// Layout of the decoder's two device buffers, shared by decoder.hip (weight folds, step
+// kernels) and decoder_prologue.hip (per-episode tables):
+//   Derived  - folded decoder matrices, rebuilt when the parameters change (vrp_decoder_prepare)
+//   DecWs    - per-episode workspace (vrp_decode_prologue / vrp_decode_first_row / steps)
+#pragma once
+#include <stdlib.h>
+#include "common.h"
+
+struct Derived {
+  float *Wproj;  // (1536,128) = [Wq_last | Wk | M^T | Wv]
+  float *bproj;  // (1536)       0 | bk | 0 | bv
+  float *Wqf;    // (384,128)  first-node block of the query projection (TSP/VRP)
+  float *Wqg;    // (384,128)  graph-embedding block of the query projection
+  float *bq;     // (384)
+  float *qc0;    // (384)      query contribution of the step-0 placeholders
+  float *wload;  // (384)      query coefficient of the vehicle load (IRP)
+  float *WvT;    // (128,384)  v_proj_weight transposed
+  float *bv;     // (384)
+  float *MT;     // (384,128)  transpose of M = Wkp^T Watt Wo / sqrt(128)
+  float *mb;     // (128)      Wkp^T Watt bo / sqrt(128)
+  float *tmpA;   // (128,384)  Watt Wo
+  float *tmpv;   // (128)      Watt bo
+  float *AfT;    // (1024,128) row h*128+k: sum_d Wk[48h+d][k] Wq_first[48h+d][:] / sqrt(48): the
+                 //            first-node query folded through the keys (TSP/VRP)
+};
+
+static inline Derived carve_derived(void *base) {
+  float *p = (float *)base;
+  Derived d;
+  d.Wproj = p; p += 1536 * 128;
+  d.bproj = p; p += 1536;
+  d.Wqf = p;   p += 384 * 128;
+  d.Wqg = p;   p += 384 * 128;
+  d.bq = p;    p += 384;
+  d.qc0 = p;   p += 384;
+  d.wload = p; p += 384;
+  d.WvT = p;   p += 128 * 384;
+  d.bv = p;    p += 384;
+  d.MT = p;    p += 384 * 128;
+  d.mb = p;    p += 128;
+  d.tmpA = p;  p += 128 * 384;
+  d.tmpv = p;  p += 128;
+  d.AfT = p;   p += 1024 * 128;
+  return d;
+}
+
+static inline int64_t derived_floats() {
+  return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
+         128 * 384 + 128 + 1024 * 128;
+}
+
+// ------------------------------------------------------------------ per-episode workspace
+// Glimpse score of step t > 0 (graph b, head h, node n) = SL[b][last][h][n] (+ load *
+// SLD[b][h][n] for IRP); step 0 reads row0.  N <= 80: SL holds the complete row (constant
+// parts folded in); N > 80: the steps add base[b][h][n] (a second row).
+struct DecWs {
+  float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
+  float *QG;     // (B,384)     Wq_g g + bq
+  float *PROJ;   // (B*N,1536)  [QL | KK | KM | VV] rows; only the unfused path (N > 80)
+  float *SG, *C0, *SLD, *row0, *curs;  // (B,8,N) each; curs = next step's row (latency mode)
+  float *base;                   // (B,8,N)  constant part of every score row after step 0
+  float *SL;                     // (B,N,8,N)  last-node part of the score: QL_m . KK_n / sqrt(48)
+  float *Efirst;                 // (B,128)  first chosen node (general-GEMM fallback)
+  float *FK;                     // (B,1024) first-node query folded through the keys (N > 80)
+  float *QF1;                    // (B,384)  Wq_first e_first (N <= 80)
+  float *KKbuf;                  // projected keys of the fused prologue, kept for the
+                                 // post-step-0 table build (TSP/VRP, N <= 80)
+  float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:]
+  float *cvec;                   // (B,N)                e_m . mb
+  int32_t *last, *first;         // (B)
+};
+
+#define VRP_RT_MAX_N 128    // above this the tile kernel (one raw-tile read per step) is used
+#define VRP_FUSED_MAX_N 80  // the fused projection+table prologue packs <= 80 rows per wave
+static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
+// A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
+static inline bool prologue_unfused() {
+  static const bool v = getenv("VRP_PROLOGUE_UNFUSED") != nullptr;
+  return v;
+}
+static inline bool use_fused_prologue(int N) { return N <= VRP_FUSED_MAX_N && !prologue_unfused(); }
+static inline int proj_width(int N) { return use_rtable(N) ? 1536 : 768; }
+static inline size_t proj_floats(int B, int N) {
+  return use_fused_prologue(N) ? 0 : (size_t)B * N * proj_width(N);
+}
+// fused prologue: 3 x RT float4 per lane per (pack, head), RT <= 5, pack >= 1 graph
+static inline size_t kkbuf_floats(int B, int N) {
+  if (!use_fused_prologue(N)) return 0;
+  int G = 80 / N;
+  if (G > 4) G = 4;
+  if (G > B) G = B;
+  const size_t npacks = (size_t)(B + G - 1) / G;
+  return npacks * 8 * 15 * 64 * 4;
+}
+static inline size_t rtable_floats(int B, int N) {
+  return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
+}
+
+static inline DecWs carve_decws(void *ws, int B, int N) {
+  char *p = (char *)ws;
+  DecWs w;
+  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
+  w.g = (float *)p;     p += vrp_align_up((size_t)B * 128 * 4);
+  w.QG = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
+  w.PROJ = (float *)p;  p += vrp_align_up(proj_floats(B, N) * 4);
+  w.SG = (float *)p;    p += vrp_align_up(hn);
+  w.C0 = (float *)p;    p += vrp_align_up(hn);
+  w.SLD = (float *)p;   p += vrp_align_up(hn);
+  w.row0 = (float *)p;  p += vrp_align_up(hn);
+  w.curs = (float *)p;  p += vrp_align_up(hn);
+  w.base = (float *)p;  p += vrp_align_up(hn);
+  w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
+  w.FK = (float *)p;     p += vrp_align_up((size_t)B * 1024 * 4);
+  w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
+  w.KKbuf = (float *)p;  p += vrp_align_up(kkbuf_floats(B, N) * 4);
+  w.SL = (float *)p;    p += vrp_align_up(tb);
+  w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
+  w.cvec = (float *)p;  p += vrp_align_up(R * 4);
+  w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
+  w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
+  return w;
+}
+
+static inline int64_t decws_bytes(int B, int N) {
+  const size_t R = (size_t)B * N, hn = (size_t)B * 8 * N * 4, tb = R * 8 * N * 4;
+  return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
+                   vrp_align_up(proj_floats(B, N) * 4) + 6 * vrp_align_up(hn) +
+                   vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 1024 * 4) +
+                   vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(kkbuf_floats(B, N) * 4) +
+                   vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
+                   vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
+                       const float *R, int ldr, float *C, int ldc, int M, int N, int K,
+                       int relu, hipStream_t stream);
+int vrp_launch_gemm_gather_k128(const float *A, int lda, const int32_t *gidx, int gstride,
+                                const float *W, int ldw, float *C, int ldc, int M, int N,
+                                hipStream_t stream);
