@@ -46,20 +46,21 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
 //            registers (B operand, lane = node: 32 contiguous floats of its row).  The
 //            result sits transposed in the accumulators: lane (node j, group q) holds
 //            projection columns 16c + 4q + reg of node j --
-//   stage 2  -- which IS the operand layout of the next product: SL tile = QL KK^T and RT
-//            tile = KM VV^T run as 12 MFMAs per 16 x 16 tile straight from those registers
-//            (k = projection column; both operands use the same column -> (group, step)
-//            map), then go to memory.
+//   stage 2  -- which IS the operand layout of the next product: the tiles of SL^T = KK QL^T
+//            and RT^T = VV KM^T run as 12 MFMAs per 16 x 16 tile straight from those
+//            registers (k = projection column; both operands use the same column ->
+//            (group, step) map).  Transposed, so that a lane ends up with four consecutive
+//            key columns n of one query row m: one 16-byte store per tile and lane (N % 4 == 0;
+//            element-wise stores otherwise).  Two accumulation chains per tile keep the
+//            matrix pipe issuing back to back, and the store of a tile is issued under the
+//            MFMAs of the next one.
 // Two halves -- (QL, KK) -> score tables, (KM, VV) -> logit table -- keep at most 2 x 3 x RT
-// accumulator tiles live.  The next pack's embedding rows are requested before the last
-// stage 2 starts.
-// MODE 0 (IRP): everything in the prologue; the constant score row SG is folded into SL.
-// MODE 1 (TSP/VRP prologue): KK, KM, VV -> SG / C0 / row0 / SLD and RT; the projected keys
-//        (accumulator registers as they stand, 1 KB per store) are kept for MODE 2.
-// MODE 2 (TSP/VRP after step 0, first_ known: graph_decoder.py:111-113): QL + the stored keys
-//        -> base = SG + (Wq_first e_first) . K / sqrt(48), SL = QL K^T / sqrt(48) + base: a
-//        later step reads ONE score row, SL[b][last]; the row of the first node also goes to
-//        `curs` for step 1 of the latency-mode step kernel.
+// accumulator tiles live.  Every global load of a pack is issued before the ~15 k cycles of
+// stage-1 MFMAs that separate it from its first use (a SIMD runs ONE wave of this kernel: an
+// exposed memory round trip is a stalled matrix pipe); the next pack's embedding rows are
+// requested before the last stage 2 starts.
+// IRP (no first-node term, graph_decoder.py:90-91): the constant score row SG is folded into
+// SL here; TSP/VRP: the steps add base[b] (vrp_decode_first_row) to SL[b][last].
 // The 128-long inner dimension of stage 1 is split over the four 16-lane groups as
 // k = koff(q) + s, koff = {0, 64, 32, 96}: with LDS rows of 132 floats the two lane groups
 // that one ds_read_b128 pass serves together (q = 0 with 1, 2 with 3) are 64 floats apart,
@@ -68,12 +69,11 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
 #define PT_MAXROWS 80
 struct PrologueParams {
   int kind, B, N, G, npacks;
-  const float *emb, *Wproj, *bproj, *QG, *qc0, *wload, *QF1;
-  const int32_t *first;
-  float *SG, *C0, *SLD, *row0, *curs, *SL, *RT, *KKbuf;
+  const float *emb, *Wproj, *bproj, *QG, *qc0, *wload;
+  float *SG, *C0, *SLD, *row0, *SL, *RT;
 };
 
-template <int RT_, int MODE>
+template <int RT_, bool VEC>
 __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                              // [4][48][PT_LD] weight slices of this head
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
   const int h = jj & 7, sub = jj >> 3, nsub = gridDim.x >> 6;
   const int stride = 8 * nsub * 4;
   const int first = (xcd * nsub + sub) * 4 + wave;
-  constexpr int X_LO = (MODE == 1) ? 1 : 0, X_HI = (MODE == 2) ? 1 : 4;  // slices needed
+  const bool fold = p.kind == VRP_KIND_IRP;
 
-  for (int i = tid; i < (X_HI - X_LO) * 48 * 32; i += 256) {
-    const int c4 = i & 31, row = (i >> 5) % 48, X = X_LO + i / (48 * 32);
+  for (int i = tid; i < 4 * 48 * 32; i += 256) {
+    const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
     const float4 v = *reinterpret_cast<const float4 *>(
         p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
     *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
@@ -143,39 +143,29 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
     asm volatile("" ::: "memory");
     const int g0 = pack * G;                       // first graph of the pack
     const int valid = min(G, p.B - g0) * N;        // rows of the pack that exist
-    // Stage 2 computes TRANSPOSED tiles D[n][m] (A = keys/values of node tile tn, B = queries
-    // of node tile tm): lane (j, q) then holds, for query row m = 16tm + j, the four
-    // consecutive key columns n = 16tn + 4q + {0..3} -> one 16-byte store per tile and lane.
-    // mrow*: row m of this lane per tile; ncol*: first of its four columns per tile.
-    int mg[RT_], moff[RT_], mnode[RT_];   // graph of the pack (-2: none), table offset, node
-    int ng[RT_], nn0[RT_];                // graph (-1: none) and node of column 16tn + 4q
+    // D[n][m] tiles: lane (j, q) holds query row m = 16tm + j and the four consecutive key
+    // columns n = 16tn + 4q + {0..3}
+    int mg[RT_], moff[RT_];   // row m: graph of the pack (-2: none), element offset of its table row
+    int ng[RT_], nn0[RT_];    // column 16tn + 4q: graph (-1: none) and node
 #pragma unroll
     for (int t = 0; t < RT_; ++t) {
       const int row = 16 * t + j16;
       const int ri = rowinfo[row < PT_MAXROWS ? row : 0];
       mg[t] = (row < valid) ? (ri >> 8) : -2;
-      mnode[t] = ri & 255;
       moff[t] = (((ri >> 8) * N + (ri & 255)) * 8 + h) * N;
       const int col = 16 * t + 4 * q;
       const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
       ng[t] = (col < valid) ? (ci >> 8) : -1;
       nn0[t] = ci & 255;
     }
-    const bool vec = (N & 3) == 0;  // four consecutive columns never straddle two graphs
-    float4 *kkbuf = reinterpret_cast<float4 *>(p.KKbuf) + ((size_t)pack * 8 + h) * (3 * RT_) * 64 + lane;
-    // Every global load of this pack is issued HERE, ahead of the ~15 k cycles of stage-1
-    // MFMAs that separate it from its first use: a SIMD runs one wave of this kernel, so an
-    // exposed memory round trip is a stalled matrix pipe.
-    // extra query rows per graph g of the pack, as B columns 4g + x.
-    // MODE 0/1: x = 0: Wq_g g + bq, 1: step-0 placeholders, 2: load coefficient;
-    // MODE 2:   x = 0: Wq_first e_first
+    // extra query rows per graph g of the pack, as B columns 4g + x: x = 0: Wq_g g + bq,
+    // 1: step-0 placeholders, 2: load coefficient
     const int xg = j16 >> 2, xx = j16 & 3;
-    const bool xon = xx < (MODE == 2 ? 1 : 3) && xg < G && g0 + xg < p.B;
+    const bool xon = xx < 3 && xg < G && g0 + xg < p.B;
     float ex[3][4];
     {
-      const float *src;
-      if (MODE == 2) src = p.QF1 + (size_t)(g0 + (xon ? xg : 0)) * VRP_D;
-      else src = (xx == 0) ? p.QG + (size_t)(g0 + (xon ? xg : 0)) * VRP_D : (xx == 1 ? p.qc0 : p.wload);
+      const float *src = (xx == 0) ? p.QG + (size_t)(g0 + (xon ? xg : 0)) * VRP_D
+                                   : (xx == 1 ? p.qc0 : p.wload);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -183,33 +173,9 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
         ex[c][0] = v.x; ex[c][1] = v.y; ex[c][2] = v.z; ex[c][3] = v.w;
       }
     }
-    f32x4 kk[3][RT_];        // MODE 2: the keys MODE 1 stored
-    float sgv[RT_][4];       // MODE 2: SG of this lane's extra-row graph at its four columns
-    int cursoff[RT_];        // MODE 2: >= 0 where this lane's row is the first chosen node
-    if (MODE == 2) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r = 0; r < RT_; ++r) {
-          const float4 v = kkbuf[(size_t)(c * RT_ + r) * 64];
-          kk[c][r] = f32x4{v.x, v.y, v.z, v.w};
-        }
-#pragma unroll
-      for (int tn = 0; tn < RT_; ++tn) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int col = 16 * tn + 4 * q + r4;
-          const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
-          const bool ok = xon && col < valid && (ci >> 8) == xg;
-          sgv[tn][r4] = ok ? p.SG[((size_t)(g0 + xg) * 8 + h) * N + (ci & 255)] : 0.f;
-        }
-        cursoff[tn] = -1;
-        if (mg[tn] >= 0 && mnode[tn] == p.first[g0 + mg[tn]]) cursoff[tn] = (mg[tn] * 8 + h) * N;
-      }
-    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int H = 0; H < (MODE == 2 ? 1 : 2); ++H) {
+    for (int H = 0; H < 2; ++H) {
       // ---- stage 1: transposed projections ----------------------------------------------
       f32x4 acc[2][3][RT_];
 #pragma unroll
@@ -217,12 +183,6 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const int X = 2 * H + Y;
-          if (MODE == 1 && X == 0) continue;    // QL is projected after step 0 (MODE 2)
-          if (MODE == 2 && X == 1) {            // the keys MODE 1 stored
-#pragma unroll
-            for (int r = 0; r < RT_; ++r) acc[Y][c][r] = kk[c][r];
-            continue;
-          }
           // accumulators start at the bias of their projection columns 16c + 4q + reg (bk
           // for the keys, bv for the values, zero otherwise)
           const float4 bb = *reinterpret_cast<const float4 *>(bl + X * 48 + 16 * c + 4 * q);
@@ -241,118 +201,128 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
                 acc[Y][c][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], ef[r][4 * k4 + e],
                                                                    acc[Y][c][r], 0, 0, 0);
           }
-          if (MODE == 1 && X == 1) {
-#pragma unroll
-            for (int r = 0; r < RT_; ++r)
-              kkbuf[(size_t)(c * RT_ + r) * 64] =
-                  make_float4(acc[Y][c][r][0], acc[Y][c][r][1], acc[Y][c][r][2], acc[Y][c][r][3]);
-          }
         }
-      if (H == (MODE == 2 ? 0 : 1)) {  // the next pack's rows: requested before the last stage 2
+      if (H == 1) {  // the next pack's rows: requested before the last stage 2
         const int nxt = pack + stride;
         if (nxt < p.npacks) load_pack(nxt);
       }
       __builtin_amdgcn_sched_barrier(0);
 
-      // constant part of the score rows for this lane's four columns of every tile
+      // constant part of the score rows for this lane's four columns of every tile (IRP)
       float bcol[RT_][4];
 #pragma unroll
       for (int tn = 0; tn < RT_; ++tn)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) bcol[tn][r4] = 0.f;
       if (H == 0) {
-        // ---- extra query rows (loaded at the top of the iteration) ------------------------
-        const int g = xg, x = xx;
-        const bool on = xon;
+        // ---- extra rows: D[n][i], lane (i = 4g + x, q), register r4 = column n = 16tn + 4q + r4
 #pragma unroll
         for (int tn = 0; tn < RT_; ++tn) {
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
+          f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], ex[c][r4], d, 0, 0, 0);
-          // D[n][i]: lane (i = 4g + x, q), register r4 = column n = 16tn + 4q + r4
-          float v[4] = {d[0] * c48, d[1] * c48, d[2] * c48, d[3] * c48};
-          float c0[4];  // the x = 1 row, fetched from the neighbouring lane
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) c0[r4] = __shfl_down(v[r4], 1, 64);
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int col = 16 * tn + 4 * q + r4;
-            int gn = ng[tn], nn = nn0[tn] + r4;
-            if (!vec) {
-              const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
-              gn = (col < valid) ? (ci >> 8) : -1;
-              nn = ci & 255;
+            for (int r4 = 0; r4 < 4; r4 += 2) {
+              da = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], ex[c][r4], da, 0, 0, 0);
+              db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4 + 1], ex[c][r4 + 1], db, 0, 0, 0);
             }
-            const size_t o = ((size_t)(g0 + g) * 8 + h) * N + nn;
-            if (gn == g && on) {
-              if (MODE == 2) {
-                v[r4] += sgv[tn][r4];
-              } else {
-                if (x == 0) { p.SG[o] = v[r4]; p.row0[o] = v[r4] + c0[r4]; }  // row0: step-0 row
-                if (x == 1) p.C0[o] = v[r4];
-                if (x == 2) p.SLD[o] = v[r4];
+          float v[4], c0[4];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) v[r4] = (da[r4] + db[r4]) * c48;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) c0[r4] = __shfl_down(v[r4], 1, 64);  // the x = 1 row
+          if (VEC) {
+            const size_t o = ((size_t)(g0 + xg) * 8 + h) * N + nn0[tn];
+            if (xon && ng[tn] == xg) {
+              const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+              if (xx == 0) {
+                *reinterpret_cast<float4 *>(p.SG + o) = v4;
+                *reinterpret_cast<float4 *>(p.row0 + o) =   // step-0 score row
+                    make_float4(v[0] + c0[0], v[1] + c0[1], v[2] + c0[2], v[3] + c0[3]);
               }
+              if (xx == 1) *reinterpret_cast<float4 *>(p.C0 + o) = v4;
+              if (xx == 2) *reinterpret_cast<float4 *>(p.SLD + o) = v4;
             }
-            // the lane that holds column `col` of its graph gn is (4 gn, q): broadcast over j
-            if (MODE == 2 || (MODE == 0 && p.kind == VRP_KIND_IRP))
-              bcol[tn][r4] = __shfl(v[r4], (q << 4) | (4 * (gn < 0 ? 0 : gn)), 64);
-          }
-        }
-        if (MODE == 1) continue;  // SL is built after step 0
-      }
-      // ---- stage 2: table tiles straight from the accumulators ---------------------------
-      // Addresses: one 64-bit base per pack, 32-bit element offsets inside it (a pack's
-      // slice of a table is at most 4 x 80 x 8 x 80 floats).
-      float *tab = (H ? p.RT : p.SL) + (size_t)g0 * N * 8 * N;
-      float *cursp = p.curs + (size_t)g0 * 8 * N;
-      const float scale = H ? 1.f : c48;
+            if (fold) {  // the lane that holds these columns of graph gn is (4 gn, q)
+              const int srcl = (q << 4) | (4 * (ng[tn] < 0 ? 0 : ng[tn]));
 #pragma unroll
-      for (int tm = 0; tm < RT_; ++tm) {
-#pragma unroll
-        for (int tn = 0; tn < RT_; ++tn) {
-          if (!((needmask >> (tm * RT_ + tn)) & 1u)) continue;
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-              d = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], acc[0][c][tm][r4], d, 0, 0, 0);
-          float v[4];
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) v[r4] = fmaf(d[r4], scale, bcol[tn][r4]);
-          if (vec) {
-            if (mg[tm] == ng[tn]) {
-              *reinterpret_cast<float4 *>(tab + moff[tm] + nn0[tn]) = make_float4(v[0], v[1], v[2], v[3]);
-              if (MODE == 2 && cursoff[tm] >= 0)
-                *reinterpret_cast<float4 *>(cursp + cursoff[tm] + nn0[tn]) = make_float4(v[0], v[1], v[2], v[3]);
+              for (int r4 = 0; r4 < 4; ++r4) bcol[tn][r4] = __shfl(v[r4], srcl, 64);
             }
           } else {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const int col = 16 * tn + 4 * q + r4;
               const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
-              if (col < valid && (ci >> 8) == mg[tm]) {
-                tab[moff[tm] + (ci & 255)] = v[r4];
-                if (MODE == 2 && cursoff[tm] >= 0) cursp[cursoff[tm] + (ci & 255)] = v[r4];
+              const int gn = (col < valid) ? (ci >> 8) : -1;
+              const size_t o = ((size_t)(g0 + xg) * 8 + h) * N + (ci & 255);
+              if (gn == xg && xon) {
+                if (xx == 0) { p.SG[o] = v[r4]; p.row0[o] = v[r4] + c0[r4]; }  // row0: step-0 row
+                if (xx == 1) p.C0[o] = v[r4];
+                if (xx == 2) p.SLD[o] = v[r4];
               }
+              if (fold) bcol[tn][r4] = __shfl(v[r4], (q << 4) | (4 * (gn < 0 ? 0 : gn)), 64);
             }
           }
         }
       }
+      // ---- stage 2: table tiles straight from the accumulators ---------------------------
+      // Addresses: one 64-bit base per pack, 32-bit element offsets inside it (a pack's
+      // slice of a table is at most 4 x 80 x 8 x 80 floats).
+      float *tab = (H ? p.RT : p.SL) + (size_t)g0 * N * 8 * N;
+      const float scale = H ? 1.f : c48;
+      // the finished tile whose store is still to be issued (under the next tile's MFMAs)
+      f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+      float pc[4] = {0.f, 0.f, 0.f, 0.f};
+      int poff = 0, ptm = -2, ptn = -3;   // table offset; row graph, column graph of the tile
+      auto flush = [&]() {
+        if (VEC) {
+          if (ptm == ptn)
+            *reinterpret_cast<float4 *>(tab + poff) =
+                make_float4(fmaf(pa[0] + pb[0], scale, pc[0]), fmaf(pa[1] + pb[1], scale, pc[1]),
+                            fmaf(pa[2] + pb[2], scale, pc[2]), fmaf(pa[3] + pb[3], scale, pc[3]));
+        }
+      };
+#pragma unroll
+      for (int tm = 0; tm < RT_; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < RT_; ++tn) {
+          if (!((needmask >> (tm * RT_ + tn)) & 1u)) continue;
+          f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4 += 2) {
+              da = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], acc[0][c][tm][r4], da, 0, 0, 0);
+              db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4 + 1], acc[0][c][tm][r4 + 1], db, 0, 0, 0);
+            }
+          if (VEC) {
+            flush();  // previous tile
+            pa = da; pb = db; poff = moff[tm] + nn0[tn]; ptm = mg[tm]; ptn = ng[tn];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) pc[r4] = bcol[tn][r4];
+          } else {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int col = 16 * tn + 4 * q + r4;
+              const int ci = rowinfo[col < PT_MAXROWS ? col : 0];
+              if (col < valid && (ci >> 8) == mg[tm])
+                tab[moff[tm] + (ci & 255)] = fmaf(da[r4] + db[r4], scale, bcol[tn][r4]);
+            }
+          }
+        }
+      }
+      flush();
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-template <int RT_, int MODE>
+template <int RT_, bool VEC>
 static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * (4 * 48 * PT_LD + 4 * 48) + sizeof(int) * PT_MAXROWS;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("prologue_tables: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
@@ -363,19 +333,19 @@ static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
   // batch has fewer packs than wave slots
   int nsub = 4;
   while (nsub > 1 && 8 * (nsub / 2) * 4 >= p.npacks) nsub /= 2;
-  hipLaunchKernelGGL((prologue_tables_kernel<RT_, MODE>), dim3(64 * nsub), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC>), dim3(64 * nsub), dim3(256), lds, st, p);
   VRP_CHECK_LAUNCH("prologue_tables");
   return 0;
 }
 
-template <int MODE>
-static int launch_prologue_mode(const PrologueParams &p, hipStream_t st) {
+template <bool VEC>
+static int launch_prologue_vec(const PrologueParams &p, hipStream_t st) {
   switch ((p.G * p.N + 15) / 16) {
-    case 1: return launch_prologue_tables<1, MODE>(p, st);
-    case 2: return launch_prologue_tables<2, MODE>(p, st);
-    case 3: return launch_prologue_tables<3, MODE>(p, st);
-    case 4: return launch_prologue_tables<4, MODE>(p, st);
-    default: return launch_prologue_tables<5, MODE>(p, st);
+    case 1: return launch_prologue_tables<1, VEC>(p, st);
+    case 2: return launch_prologue_tables<2, VEC>(p, st);
+    case 3: return launch_prologue_tables<3, VEC>(p, st);
+    case 4: return launch_prologue_tables<4, VEC>(p, st);
+    default: return launch_prologue_tables<5, VEC>(p, st);
   }
 }
 
@@ -383,15 +353,13 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
                                       const DecWs &w) {
   PrologueParams p;
   p.kind = kind; p.B = B; p.N = N;
-  int G = PT_MAXROWS / N;
+  int G = fused_max_rows(N) / N;
   if (G > 4) G = 4;
   if (G > B) G = B;
   p.G = G;
   p.npacks = (B + G - 1) / G;
   p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
-  p.QF1 = w.QF1; p.first = w.first;
-  p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.curs = w.curs; p.SL = w.SL; p.RT = w.RT;
-  p.KKbuf = w.KKbuf;
+  p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.SL = w.SL; p.RT = w.RT;
   return p;
 }
 
@@ -592,7 +560,7 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
                                  st)) return r;
   if (use_fused_prologue(N)) {
     const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
-    return launch_prologue_mode<0>(p, st);
+    return (N & 3) == 0 ? launch_prologue_vec<true>(p, st) : launch_prologue_vec<false>(p, st);
   }
   const int P = proj_width(N);
   float *PROJ = w.PROJ;

@@ -50,9 +50,9 @@ static inline int64_t derived_floats() {
 }
 
 // ------------------------------------------------------------------ per-episode workspace
-// Glimpse score of step t > 0 (graph b, head h, node n) = SL[b][last][h][n] (+ load *
-// SLD[b][h][n] for IRP); step 0 reads row0.  N <= 80: SL holds the complete row (constant
-// parts folded in); N > 80: the steps add base[b][h][n] (a second row).
+// Glimpse score of step t > 0 (graph b, head h, node n) = SL[b][last][h][n] + base[b][h][n]
+// (TSP/VRP; IRP: the constant part is folded into SL, + load * SLD[b][h][n]); step 0 reads
+// row0.
 struct DecWs {
   float *g;      // (B,128)     graph embedding            graph_decoder.py:75-77
   float *QG;     // (B,384)     Wq_g g + bq
@@ -62,35 +62,27 @@ struct DecWs {
   float *SL;                     // (B,N,8,N)  last-node part of the score: QL_m . KK_n / sqrt(48)
   float *Efirst;                 // (B,128)  first chosen node (general-GEMM fallback)
   float *FK;                     // (B,1024) first-node query folded through the keys (N > 80)
-  float *QF1;                    // (B,384)  Wq_first e_first (N <= 80)
-  float *KKbuf;                  // projected keys of the fused prologue, kept for the
-                                 // post-step-0 table build (TSP/VRP, N <= 80)
+
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:]
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
 };
 
 #define VRP_RT_MAX_N 128    // above this the tile kernel (one raw-tile read per step) is used
-#define VRP_FUSED_MAX_N 80  // the fused projection+table prologue packs <= 80 rows per wave
+// the fused projection+table prologue packs <= 80 rows (five 16-row tiles) per wave when
+// N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
+#define VRP_FUSED_MAX_N 80
+static inline int fused_max_rows(int N) { return (N & 3) == 0 ? 80 : 64; }
 static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 // A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
 static inline bool prologue_unfused() {
   static const bool v = getenv("VRP_PROLOGUE_UNFUSED") != nullptr;
   return v;
 }
-static inline bool use_fused_prologue(int N) { return N <= VRP_FUSED_MAX_N && !prologue_unfused(); }
+static inline bool use_fused_prologue(int N) { return N <= fused_max_rows(N) && !prologue_unfused(); }
 static inline int proj_width(int N) { return use_rtable(N) ? 1536 : 768; }
 static inline size_t proj_floats(int B, int N) {
   return use_fused_prologue(N) ? 0 : (size_t)B * N * proj_width(N);
-}
-// fused prologue: 3 x RT float4 per lane per (pack, head), RT <= 5, pack >= 1 graph
-static inline size_t kkbuf_floats(int B, int N) {
-  if (!use_fused_prologue(N)) return 0;
-  int G = 80 / N;
-  if (G > 4) G = 4;
-  if (G > B) G = B;
-  const size_t npacks = (size_t)(B + G - 1) / G;
-  return npacks * 8 * 15 * 64 * 4;
 }
 static inline size_t rtable_floats(int B, int N) {
   return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
@@ -111,8 +103,6 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.base = (float *)p;  p += vrp_align_up(hn);
   w.Efirst = (float *)p; p += vrp_align_up((size_t)B * 128 * 4);
   w.FK = (float *)p;     p += vrp_align_up((size_t)B * 1024 * 4);
-  w.QF1 = (float *)p;    p += vrp_align_up((size_t)B * 384 * 4);
-  w.KKbuf = (float *)p;  p += vrp_align_up(kkbuf_floats(B, N) * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
   w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
@@ -126,7 +116,6 @@ static inline int64_t decws_bytes(int B, int N) {
   return (int64_t)(vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 384 * 4) +
                    vrp_align_up(proj_floats(B, N) * 4) + 6 * vrp_align_up(hn) +
                    vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 1024 * 4) +
-                   vrp_align_up((size_t)B * 384 * 4) + vrp_align_up(kkbuf_floats(B, N) * 4) +
                    vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
 }
