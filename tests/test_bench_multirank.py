@@ -81,7 +81,7 @@ def test_bench_single_rank_line_has_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
               "loop_us_per_step", "loop_frac", "rollout_frac", "kernel"):
         assert k in r, k
-    assert r["kernel"].startswith("decode_step_rt_kernel<1, 1>")
+    assert r["kernel"] == "decode_persistent_kernel"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["loop_frac"] <= r["frac"] + 1e-6 and r["rollout_frac"] <= r["loop_frac"] + 1e-6
     for name in ("vrp40_b2048_train", "irp40_b1024_train", "vrp100_b2048"):

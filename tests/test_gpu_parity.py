@@ -905,3 +905,50 @@ def test_full_size_properties_configs_4_5(kind, B, N, greedy, train):
     assert torch.equal(torch.isfinite(u), torch.as_tensor(masks == 0))
     lsm = torch.log_softmax(u.double(), dim=2).gather(2, torch.as_tensor(acts)[:, :, None])[..., 0]
     assert (lsm.float() - slp).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("kind,B,N,greedy,train", [
+    (0, 512, 20, True, False), (0, 512, 20, False, True), (1, 300, 33, True, False),
+    (1, 2048, 40, False, True), (2, 1024, 40, False, True), (2, 37, 63, True, False),
+    (1, 5, 3, False, False), (2, 64, 21, False, False)])
+def test_persistent_steps_equal_per_step_launches(kind, B, N, greedy, train):
+    """The persistent multi-step kernel (one launch for steps 1..T-1: masks handed between
+    graphs as published words, per-graph termination, the forced way back of a graph that
+    finished by leaving the depot counted iff the batch ran on) against one launch per step:
+    same arithmetic, so everything is bit-identical -- actions, traces the backward pass uses,
+    accumulators, step count, final env state."""
+    from agents import runtime
+    env = _envs()[kind](N, B, 1, 13)
+    agent = _agents()[kind](seed=69)
+    agent.model.train(train)
+    steps = runtime.max_steps_for(kind, N)
+    noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
+    out = []
+    for persistent in (False, True):
+        e = deepcopy(env)
+        a = _agents()[kind](seed=69)
+        a.model.train(train)
+        with torch.no_grad():
+            r = runtime.rollout(a.model, e, greedy, train=train, noise=noise, record=True,
+                                step_trace=True, persistent=persistent)
+        out.append((r, e))
+    (r0, e0), (r1, e1) = out
+    T = r0.T
+    assert r1.T == T
+    assert torch.equal(r0.notdone[:steps], r1.notdone[:steps])
+    assert torch.equal(r0.actions[:T], r1.actions[:T])
+    assert torch.equal(r0.step_logp[:T], r1.step_logp[:T])
+    assert torch.equal(r0.mask_trace[:T], r1.mask_trace[:T])
+    if kind == 2:
+        assert torch.equal(r0.load_trace[:T], r1.load_trace[:T])
+    assert torch.equal(r0.acc_loss, r1.acc_loss) and torch.equal(r0.acc_logp, r1.acc_logp)
+    assert torch.equal(e0._visited, e1._visited) and torch.equal(e0._cur, e1._cur)
+    assert torch.equal(e0._load, e1._load)
+    assert np.array_equal(e0.generate_mask(), e1.generate_mask())
+    assert e0.step_count == e1.step_count == T
+    if kind != 0 and not greedy and B >= 8:
+        # the interesting case must occur: graphs that finish at different steps
+        acts = r0.actions[:T].cpu().numpy()
+        dep = e0._depot.cpu().numpy()
+        last_move = np.array([np.flatnonzero(acts[:, b] != dep[b]).max() for b in range(B)])
+        assert last_move.min() < last_move.max()

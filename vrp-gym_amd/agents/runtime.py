@@ -267,7 +267,12 @@ class RolloutResult:
     @property
     def T(self):
         if self._T is None:
-            nd = self.notdone[: self.max_steps].cpu()
+            nd = self.notdone[: self.max_steps + 1].cpu()
+            if int(nd[self.max_steps]) == -1:
+                raise RuntimeError("persistent decode kernel: a wave timed out waiting for another "
+                                   "graph's mask (grid not fully resident?); rerun with "
+                                   "VRP_NO_PERSISTENT=1")
+            nd = nd[: self.max_steps]
             zero = (nd == 0).nonzero()
             self._T = int(zero[0].item()) + 1 if len(zero) else self.max_steps
         return self._T
@@ -389,8 +394,11 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
 
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
             noise_mode="device", tile_kernel=False, use_graph=None, record=False,
-            throughput_kernel=False):
-    """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU."""
+            throughput_kernel=False, persistent=True, step_trace=False):
+    """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU.
+    trace: keep actions, per-step logits and log-probs (the logits trace needs one launch per
+    step); step_trace: actions and per-step log-probs only; persistent=False: one launch per
+    step even where the persistent multi-step kernel applies (A/B and tests)."""
     dev = _require_cuda(model)
     if use_graph is None:
         use_graph = USE_GRAPHS
@@ -431,9 +439,12 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
         if kind == hip.KIND_IRP:
             load_trace = torch.empty((max_steps, B), dtype=torch.float32, device=dev)
             io.load_trace = load_trace.data_ptr()
-    if trace or record or forced is not None:
+    if trace or record or step_trace or forced is not None:
         actions = torch.zeros((max_steps, B), dtype=torch.int64, device=dev)
         io.actions = actions.data_ptr()
+    if step_trace and not trace:
+        step_logp = torch.zeros((max_steps, B), dtype=torch.float32, device=dev)
+        io.step_logp = step_logp.data_ptr()
     if trace:
         logits = torch.zeros((max_steps, B, N), dtype=torch.float32, device=dev)
         step_logp = torch.zeros((max_steps, B), dtype=torch.float32, device=dev)
@@ -466,7 +477,8 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._sync_positions()
     env._parity = 0
     cenv = env._cenv()
-    flags = int(not greedy) | (4 if tile_kernel else 0) | (16 if throughput_kernel else 0)
+    flags = (int(not greedy) | (4 if tile_kernel else 0) | (16 if throughput_kernel else 0) |
+             (0 if persistent else 32))
     tape = x3 = dmask = None
     if record and train:
         # the pieces of vrp_rollout with the taped encoder: the backward pass reuses the

@@ -1,6 +1,6 @@
 // Error reporting and the rollout drivers (R1 of SURVEY.md 8a).
 #include <stdarg.h>
-#include "common.h"
+#include "decoder_step.h"
 
 static thread_local char g_err[512] = "";
 
@@ -31,6 +31,23 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                                        int max_steps, int flags, void *stream) {
   VRP_REQUIRE(0 <= t_begin && t_begin <= t_end && t_end <= max_steps,
               "rollout_steps_range: [%d,%d) outside [0,%d]", t_begin, t_end, max_steps);
+  VRP_REQUIRE(derived && env && emb && dec_workspace && io, "rollout_steps_range: NULL argument");
+  if (t_end == max_steps && t_end - t_begin >= 2 &&
+      vrp_persistent_eligible(kind, env->B, env->N, max_steps, flags, io)) {
+    // latency-bound regime: step 0 as its own launch (the first-node fold follows it), every
+    // later step inside ONE persistent launch (decoder_persistent.hip)
+    if (t_begin == 0) {
+      if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
+                                  flags, stream)) return r;
+      t_begin = 1;
+    }
+    VRP_REQUIRE(env->kind == kind && io->acc_loss && io->acc_logp && io->notdone,
+                "rollout_steps_range: bad env/io");
+    VRP_REQUIRE(!(flags & VRP_STEP_SAMPLE) || io->noise, "rollout_steps_range: sampling needs io.noise");
+    const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
+                                                max_steps, flags);
+    return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream);
+  }
   for (int t = t_begin; t < t_end; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,
                                 flags, stream))
@@ -88,5 +105,5 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
   // `sample` doubles as the step flags
   return rollout_step_loop(kind, derived, dw, env, emb, dec_workspace, io, max_steps,
                            sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL |
-                                     VRP_STEP_THROUGHPUT_KERNEL), stream);
+                                     VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_NO_PERSISTENT), stream);
 }

@@ -23,8 +23,7 @@
 //   * QUIRK D3 reproduced: the float 0/1 mask is ADDED to the glimpse scores and
 //     head h of graph b reads mask row (8b+h) mod B (graph_decoder.py:93-94).
 #include <stdlib.h>
-#include "env_device.h"
-#include "decoder_ws.h"
+#include "decoder_step.h"
 
 // ------------------------------------------------------------------ derived weights
 extern "C" int64_t vrp_decoder_derived_bytes(void) { return (int64_t)sizeof(float) * derived_floats(); }
@@ -162,17 +161,6 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
 __device__ __forceinline__ void flag_notdone(int32_t *flag) { *flag = 1; }
 
 // ------------------------------------------------------------------ the step kernel
-struct StepParams {
-  int kind, B, N, t, max_steps, sample, decode_only;
-  const float *emb;
-  const float *row0, *SLD, *SL, *base;
-  float *curs;
-  int32_t *last, *first;
-  const float *WvT, *bv, *MT, *mb;
-  const float *RT, *cvec;
-  vrp_env env;
-  vrp_rollout_io io;
-};
 
 #define GPW 4  // graphs per workgroup (one wave each)
 
@@ -449,59 +437,6 @@ __global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
 // RT pass: lane = (row slot r = lane>>3, part q = lane&7).  The k-th selectable node
 // (k = 8*pass + r) is found by ballot/prefix; the 8 parts split its row of 2N float4;
 // every wave-level load is 8 x 128 contiguous bytes.
-#ifndef RT_U
-#define RT_U 5  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
-#endif
-#ifndef RT_NB
-#define RT_NB 3  // work items in flight per wave, large-batch mode (114 VGPRs: four waves per SIMD)
-#endif
-#ifndef RT_MINW
-#define RT_MINW 3
-#endif
-
-// lane owns float4 indices part + 8*i (i < cnt) of its row; one work item = RT_U of them
-__device__ __forceinline__ void rt_load(float4 (&r)[RT_U], const float4 *rt, int i0, int cnt,
-                                        bool on) {
-#pragma unroll
-  for (int i = 0; i < RT_U; ++i)
-    r[i] = (on && i0 + i < cnt) ? rt[8 * (i0 + i)] : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-__device__ __forceinline__ float rt_dot(float acc, const float4 (&r)[RT_U], const float4 *a,
-                                        int i0, int cnt) {
-#pragma unroll
-  for (int i = 0; i < RT_U; ++i) {
-    if (i0 + i < cnt) {
-      const float4 w = a[8 * (i0 + i)];
-      acc = fmaf(w.x, r[i].x, acc);
-      acc = fmaf(w.y, r[i].y, acc);
-      acc = fmaf(w.z, r[i].z, acc);
-      acc = fmaf(w.w, r[i].w, acc);
-    }
-  }
-  return acc;
-}
-// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
-// error carried into a first-order correction; ~1 ulp, no range handling needed
-__device__ __forceinline__ float exp_nonpos(float x) {
-  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
-  const float t = x * l2e_hi;
-  float r = fmaf(x, l2e_hi, -t);
-  r = fmaf(x, l2e_lo, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147180559945f, e);
-}
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const long long x = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_readlane((int)x, l);
-  const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-// index of the k-th set bit of `bits` (k < popcount), wave-uniform inputs per lane group
-__device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
-  for (int i = 0; i < k; ++i) bits &= bits - 1;
-  return __ffsll((long long)bits) - 1;
-}
-
 // WPG = waves (= graphs) per workgroup: 4 for large batches; 1 for small ones, where the
 // kernel is latency-bound and single-wave workgroups spread over more CUs and never wait
 // for a sibling wave at the two barriers.
@@ -870,6 +805,27 @@ static int launch_step(const StepParams &p, hipStream_t st) {
 
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st);
 
+StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *env, const float *emb,
+                                void *workspace, const vrp_rollout_io *io, int t, int max_steps,
+                                int flags) {
+  const int B = env->B, N = env->N;
+  Derived d = carve_derived(const_cast<void *>(derived));
+  DecWs ws = carve_decws(workspace, B, N);
+  StepParams p;
+  p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps;
+  p.sample = flags & VRP_STEP_SAMPLE;
+  p.decode_only = (flags & VRP_STEP_DECODE_ONLY) ? 1 : 0;
+  p.emb = emb;
+  p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
+  p.base = (kind == VRP_KIND_IRP) ? nullptr : ws.base;  // IRP: the constant row is inside SL
+  p.last = ws.last; p.first = ws.first;
+  p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
+  p.RT = ws.RT; p.cvec = ws.cvec;
+  p.env = *env;
+  p.io = *io;
+  return p;
+}
+
 extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                                const vrp_env *env, const float *emb, void *workspace,
                                const vrp_rollout_io *io, int t, int max_steps, int flags,
@@ -887,19 +843,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   VRP_REQUIRE(N >= 2 && N <= VRP_MAX_NODES, "decode_step: N=%d unsupported (2..%d)", N, VRP_MAX_NODES);
   VRP_REQUIRE(use_rtable(N) || N <= 104, "decode_step: tile kernel supports N <= 104");
   VRP_REQUIRE(!(flags & VRP_STEP_TILE_KERNEL) || N <= 104, "decode_step: tile kernel supports N <= 104");
-  Derived d = carve_derived(const_cast<void *>(derived));
-  DecWs ws = carve_decws(workspace, B, N);
-  StepParams p;
-  p.kind = kind; p.B = B; p.N = N; p.t = t; p.max_steps = max_steps; p.sample = sample;
-  p.decode_only = decode_only;
-  p.emb = emb;
-  p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
-  p.base = (kind == VRP_KIND_IRP) ? nullptr : ws.base;  // IRP: the constant row is inside SL
-  p.last = ws.last; p.first = ws.first;
-  p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
-  p.RT = ws.RT; p.cvec = ws.cvec;
-  p.env = *env;
-  p.io = *io;
+  const StepParams p = vrp_make_step_params(kind, derived, env, emb, workspace, io, t, max_steps, flags);
   hipStream_t st = (hipStream_t)stream;
   if (int r = launch_step_any(p, flags, st)) return r;
   if (t == 0 && kind != VRP_KIND_IRP && !(flags & VRP_STEP_NO_FIRST_ROW))
@@ -909,7 +853,8 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
-  (void)kind;
+  vrp_rollout_io none = {};
+  if (vrp_persistent_eligible(kind, B, N, 2, flags, &none)) return "decode_persistent_kernel";
   if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
     const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
     if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";

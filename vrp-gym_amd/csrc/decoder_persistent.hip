@@ -1,0 +1,357 @@
+// Steps 1 .. T-1 of an episode in ONE launch, for the latency-bound regime (B <= 2048 graphs,
+// N <= 63): one wave per graph keeps the whole per-graph state of the rollout loop
+// (agents/graph_tsp_agent.py:78-88: GraphDecoder.forward agents/graph_decoder.py:51-115 +
+// env.step gym_vrp/envs/tsp.py:60-101) in registers across steps -- coordinates, visited row,
+// demand, load, current/last node, accumulators -- and only streams the step's score row and
+// the rows of the logit table.  What a kernel boundary per step used to provide is replaced by
+// the two things the algorithm really needs from other graphs:
+//   * QUIRK D3 (graph_decoder.py:93-94): head h of graph b adds the mask row of graph
+//     (8b + h) mod B.  Every graph publishes its mask for step t as ONE 8-byte word
+//     hist[t][b] = bits | 1 << 63, written by one agent-scope (sc1) store; a reader polls the
+//     eight words it needs with agent-scope loads until bit 63 shows -- the data is its own
+//     flag (the naturally aligned 8-byte granule of MI355X_MICROARCH.md, "handoff-1to1"), no
+//     barrier, no fence, no second round trip.  (All-masked rows do not exist: at least one
+//     node is always selectable, and bit 63 is never a node: N <= 63.)
+//   * the batch-wide `done` (tsp.py:95,103-104): `visited` all ones is monotone per graph
+//     (once reached it is re-established by every later step), so T - 1 = max over graphs of
+//     the step ta_b at which a graph first reaches it.  A graph stops at ta_b when it stands on
+//     the depot (or is a TSP graph: the whole batch ends there); a VRP/IRP graph that reached
+//     it by LEAVING the depot for its last customer also computes its forced
+//     way back (the only unmasked node, log-prob exactly 0) and keeps that edge's reward
+//     aside: vrp_persistent_finalize adds it iff the batch ran on (T - 1 > ta_b).  Later steps
+//     of a finished graph are self-loops on the depot with reward 0 and log-prob 0: nothing to
+//     compute; it publishes its (constant) mask for all remaining steps at once.
+// Requires every workgroup of the grid to be resident (B single-wave workgroups, <= 8 per
+// CU); spins are bounded and report through `err`.
+#include "decoder_step.h"
+
+struct PersistParams {
+  StepParams s;               // s.t = first step of the launch (>= 1)
+  unsigned long long *hist;   // (2N, B) >= (max_steps + 1, B), zeroed by vrp_decode_prologue
+  int32_t *ta;                // (B)
+  float *ret;                 // (B) reward of the way back after ta (0 if none)
+  int32_t *wb_cur;            // (B) node the graph stood on before its way back (-1: none)
+  double *wb_load;            // (B) its load there (IRP)
+  int32_t *err;
+};
+
+#define PERSIST_VALID (1ull << 63)
+#define PERSIST_SPIN_LIMIT (1 << 24)
+
+__global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams pp) {
+  const StepParams &p = pp.s;
+  __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
+  __shared__ __attribute__((aligned(16))) float u_s[64];
+  __shared__ int sel_s[64];  // compacted list of selectable nodes
+
+  const int lane = threadIdx.x;
+  const int N = p.N, B = p.B;
+  const int b = blockIdx.x;
+  const int t0 = p.t;
+  if (p.io.notdone[t0 - 1] == 0) return;  // the batch was done before this launch
+  const int n4 = 2 * N;  // float4 per RT row (8N floats)
+  const int rsl = lane >> 3, part = lane & 7;
+  const bool inN = lane < N;
+  const int ln = inN ? lane : 0;
+  const size_t row = (size_t)b * 8 * N;
+
+  // ---- per-graph state, loaded once ----------------------------------------------------
+  const uint8_t *mask0 = p.env.mask + (size_t)(t0 & 1) * B * N;
+  int own_mask = mask0[(size_t)b * N + ln];
+  int msk[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) msk[h] = mask0[(size_t)((b * 8 + h) % B) * N + ln];  // QUIRK D3
+  float sld[8], bs[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    sld[h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln] : 0.f;
+    bs[h] = p.base ? p.base[row + h * N + ln] : 0.f;
+  }
+  const float cv = p.cvec[(size_t)b * N + ln];
+  const double2 xy = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln];
+  int vis = inN ? p.env.visited[(size_t)b * N + ln] : 1;
+  const double dem = (p.kind == VRP_KIND_IRP) ? p.env.demand[(size_t)b * N + ln] : 0.0;
+  int cur = p.env.cur[b];
+  const int dep = p.env.depot[b];
+  double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+  float accl = p.io.acc_loss[b], accp = p.io.acc_logp[b];
+  int last = __builtin_amdgcn_readfirstlane(p.last[b]);
+  float sc[8];  // this step's score row SL[b][last] (requested at the end of the step before)
+  {
+    const float *srow = p.SL + ((size_t)b * N + last) * 8 * N;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) sc[h] = srow[h * N + ln];
+  }
+  const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
+  const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
+  const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
+  constexpr int NB = 2;  // work items in flight
+  int ta = -1, wb_cur = -1;
+  float ret = 0.f;
+  double wb_load = 1.0;
+  int t = t0;
+
+  for (; t < p.max_steps; ++t) {
+    // ---- loads that do not depend on other graphs: noise, first rows of the logit table
+    const float q_noise = p.sample ? p.io.noise[((size_t)t * B + b) * N + ln] : 1.f;
+    const bool s_i = inN && !own_mask;
+    const unsigned long long sel = __ballot(s_i);
+    const int nsel = __popcll(sel);
+    if (s_i) sel_s[__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+    const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
+    float4 rbuf[NB][RT_U];
+    int mrow[NB];
+    const int m_first = (rsl < nsel) ? kth_set_bit(sel, rsl) : -1;  // pass 0 rows
+    auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
+      const int pass = w / nchunk, ch = w - pass * nchunk;
+      const int k = 8 * pass + rsl;
+      const int m = (pass == 0) ? m_first : (k < nsel ? sel_s[k] : -1);
+      m_out = m;
+      rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
+    };
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      mrow[j] = -1;
+      if (j < total) load_item(rbuf[j], j, mrow[j]);
+    }
+    // ---- the eight other graphs' masks of this step (first step: the byte rows in memory)
+    if (t > t0) {
+      unsigned long long w = PERSIST_VALID;
+      if (lane < 8) {
+        const unsigned long long *src = pp.hist + (size_t)t * B + (b * 8 + lane) % B;
+        int spins = 0;
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (!(w & PERSIST_VALID)) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > PERSIST_SPIN_LIMIT) { *pp.err = 1; break; }
+          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const unsigned long long wh =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, h) << 32) |
+            (unsigned)__builtin_amdgcn_readlane((int)lo, h);
+        msk[h] = (int)((wh >> lane) & 1ull);
+      }
+    }
+    // ---- glimpse attention weights (lane = n): one wave-wide shift for all eight heads ----
+    {
+      const float loadf = (float)load0;
+      float s[8], mx = -INFINITY;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float v = sc[h] + bs[h];
+        if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sld[h], v);
+        v = inN ? v + (float)msk[h] : -INFINITY;
+        s[h] = v;
+        mx = fmaxf(mx, v);
+      }
+      const float M = wave_max(mx);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float e = inN ? exp_nonpos(s[h] - M) : 0.f;
+        float sum = wave_sum(e);
+        if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+          const float hm = wave_max(s[h]);
+          e = inN ? exp_nonpos(s[h] - hm) : 0.f;
+          sum = wave_sum(e);
+        }
+        float r = __builtin_amdgcn_rcpf(sum);
+        r = fmaf(fmaf(-sum, r, 1.f), r, r);
+        if (inN) a_s[h * N + lane] = e * r;
+      }
+    }
+    __syncthreads();
+    // ---- u_m = sum_{h,n} a[h][n] * RT[m][h][n] + cvec[m]  for selectable m ---------------
+    {
+      const float4 *aw = reinterpret_cast<const float4 *>(a_s) + part;
+      float acc = 0.f;
+      auto consume = [&](const float4 (&r)[RT_U], int w, int m) {
+        const int ch = w % nchunk;
+        acc = rt_dot(acc, r, aw, ch * RT_U, m >= 0 ? cnt : 0);
+        if (ch == nchunk - 1) {
+          acc = group8_sum(acc);
+          if (part == 0 && m >= 0) u_s[m] = acc;
+          acc = 0.f;
+        }
+      };
+      for (int w = 0; w < total; w += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (w + j < total) {
+            consume(rbuf[j], w + j, mrow[j]);
+            if (w + j + NB < total) load_item(rbuf[j], w + j + NB, mrow[j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float u = -INFINITY;
+    if (inN && !own_mask) u = 10.f * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
+    if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)t * B + b) * N + lane] = (uint8_t)own_mask;
+    if (p.io.load_trace && lane == 0) p.io.load_trace[(size_t)t * B + b] = (float)load0;
+
+    // ---- action: lowest index among the maxima (torch CPU argmax) -------------------------
+    int idx;
+    float logp = 0.f;
+    if (!p.sample) {
+      idx = wave_argmax_lane(u);
+    } else {
+      // Categorical(logits=u): logits - logsumexp, probs = softmax, sample = argmax(p/q)
+      const float m = wave_max(u);
+      const float se = wave_sum(expf(u - m));
+      const float lse = m + logf(se);
+      const float l = u - lse;
+      const float lm = wave_max(l);
+      const float pe = expf(l - lm);
+      const float ps = wave_sum(pe);
+      const float ratio = inN ? (pe / ps) / q_noise : -1.f;
+      idx = wave_argmax_lane(ratio);
+      logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), idx));
+    }
+    idx = __builtin_amdgcn_readfirstlane(idx);
+    // next step's score row: requested now, consumed after the next hand-off
+    {
+      const float *srow = p.SL + ((size_t)b * N + idx) * 8 * N;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) sc[h] = srow[h * N + ln];
+    }
+    // ---- env.step on registers (same operation order as env_device.h) -------------------
+    if (lane == idx) vis = 1;  // tsp.py:86
+    const double dx = readlane_f64(xy.x, cur) - readlane_f64(xy.x, idx);
+    const double dy = readlane_f64(xy.y, cur) - readlane_f64(xy.y, idx);
+    const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+    double load = 1.0;
+    if (p.kind == VRP_KIND_IRP) {                               // irp.py:80-86
+      load = load0 - readlane_f64(dem, idx);
+      if (idx == dep) load = 1.0;
+    }
+    const bool done = __all(vis);                               // before the fix-ups, tsp.py:95
+    if (lane == dep) {
+      if (idx == dep) vis = 1;                                  // tsp.py:141-142
+      else if (p.kind != VRP_KIND_TSP) vis = 0;                 // vrp.py:28-31
+    }
+    if (__all(vis) && lane == dep) vis = 0;                     // tsp.py:145-146
+    int mk = vis;
+    if (p.kind == VRP_KIND_IRP && inN && dem - load > 0.0) mk = 1;  // irp.py:151-153
+    const unsigned long long word = (__ballot(inN && mk) & ~PERSIST_VALID) | PERSIST_VALID;
+    const bool way_back = ta >= 0;  // this step is the forced return after `done`
+    const bool finish = done && (way_back || p.kind == VRP_KIND_TSP || idx == dep);
+    if (lane == 0) {
+      if (p.io.actions) p.io.actions[(size_t)t * B + b] = idx;
+      if (p.io.step_logp) p.io.step_logp[(size_t)t * B + b] = logp;
+      if (!finish)
+        __hip_atomic_store(pp.hist + (size_t)(t + 1) * B + b, word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (way_back) {
+      ret = (float)(-dist);
+      wb_cur = cur;        // where the episode ends if the batch was done at ta
+      wb_load = load0;
+    } else {
+      accl += (float)(-dist);  // fp32 accumulate in step order, tsp_agent:85
+      accp += logp;
+      if (done) ta = t;
+    }
+    own_mask = mk;
+    cur = idx;
+    last = idx;
+    load0 = load;
+    if (finish) {
+      // the mask is constant from here on: publish it for every remaining step, fill the traces
+      // the way the reference's self-loops on the depot would
+      for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
+        __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int tt = t + 1; tt < p.max_steps; ++tt) {
+        if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)tt * B + b) * N + lane] = (uint8_t)mk;
+        if (lane == 0) {
+          if (p.io.load_trace) p.io.load_trace[(size_t)tt * B + b] = (float)load;
+          if (p.io.actions) p.io.actions[(size_t)tt * B + b] = idx;
+          if (p.io.step_logp) p.io.step_logp[(size_t)tt * B + b] = 0.f;
+        }
+      }
+      break;
+    }
+  }
+  // ---- state back to memory ---------------------------------------------------------------
+  if (inN) p.env.visited[(size_t)b * N + lane] = (uint8_t)vis;
+  if (lane == 0) {
+    p.env.cur[b] = cur;
+    if (p.kind == VRP_KIND_IRP) p.env.load[b] = load0;
+    p.io.acc_loss[b] = accl;
+    p.io.acc_logp[b] = accp;
+    p.last[b] = last;
+    pp.ta[b] = ta < 0 ? p.max_steps - 1 : ta;
+    pp.ret[b] = ret;
+    pp.wb_cur[b] = wb_cur;
+    pp.wb_load[b] = wb_load;
+  }
+}
+
+// T - 1 = max_b ta_b; the way back of a graph counts iff the batch ran on after its ta
+// (otherwise the episode ended with the graph on its last customer: location and load are
+// put back); notdone[t] as the per-step launches would have left it.  One workgroup.
+__global__ __launch_bounds__(256) void persistent_finalize_kernel(int B, int t0, int max_steps,
+                                                                  const int32_t *__restrict__ ta,
+                                                                  const float *__restrict__ ret,
+                                                                  const int32_t *__restrict__ wb_cur,
+                                                                  const double *__restrict__ wb_load,
+                                                                  float *__restrict__ acc_loss,
+                                                                  int32_t *__restrict__ env_cur,
+                                                                  double *__restrict__ env_load,
+                                                                  int32_t *__restrict__ notdone,
+                                                                  const int32_t *__restrict__ err) {
+  __shared__ int smax[4];
+  // a wave gave up waiting for another graph's mask (the grid was not fully resident): the
+  // host sees notdone[max_steps] == -1 when it reads the step count
+  if (threadIdx.x == 0 && *err) notdone[max_steps] = -1;
+  if (notdone[t0 - 1] == 0) return;
+  int m = 0;
+  for (int b = threadIdx.x; b < B; b += 256) m = max(m, ta[b]);
+  m = (int)wave_max((float)m);  // step indices are small integers: exact in fp32
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const int last_step = max(max(smax[0], smax[1]), max(smax[2], smax[3]));  // T - 1
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (last_step > ta[b]) {
+      acc_loss[b] += ret[b];
+    } else if (wb_cur[b] >= 0) {
+      env_cur[b] = wb_cur[b];
+      if (env_load) env_load[b] = wb_load[b];
+    }
+  }
+  for (int t = t0 + threadIdx.x; t < max_steps; t += 256) notdone[t] = t < last_step ? 1 : 0;
+}
+
+bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
+                             const vrp_rollout_io *io) {
+  (void)kind;
+  static const bool off = getenv("VRP_NO_PERSISTENT") != nullptr;  // A/B aid
+  return !off && B <= 2048 && N >= 3 && N <= 63 && max_steps >= 2 && !io->logits && !io->forced &&
+         !(flags & (VRP_STEP_TILE_KERNEL | VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_DECODE_ONLY |
+                    VRP_STEP_NO_PERSISTENT));
+}
+
+// steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
+int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st) {
+  DecWs ws = carve_decws(workspace, sp.B, sp.N);
+  PersistParams pp;
+  pp.s = sp;
+  pp.hist = ws.hist;
+  pp.ta = ws.ta;
+  pp.ret = ws.ret;
+  pp.wb_cur = ws.wb_cur;
+  pp.wb_load = ws.wb_load;
+  pp.err = ws.err;
+  // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
+  hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
+  VRP_CHECK_LAUNCH("decode_persistent");
+  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, sp.B, sp.t, sp.max_steps,
+                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.env.cur,
+                     sp.kind == VRP_KIND_IRP ? sp.env.load : nullptr, sp.io.notdone, ws.err);
+  VRP_CHECK_LAUNCH("persistent_finalize");
+  return 0;
+}

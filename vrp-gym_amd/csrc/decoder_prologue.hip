@@ -15,11 +15,17 @@
 // graph embedding = mean over nodes (sum, then divide; graph_decoder.py:75-77) and
 // cvec[b][m] = e_m . mb in one launch: one workgroup per graph, threads 0..127 own an
 // embedding column of the mean, each wave owns every fourth node row of cvec.
+// Also clears the persistent step kernel's hand-off words of this graph (hist[t][b], all t)
+// and its error flag: every episode starts with "nothing published".
 __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__restrict__ emb,
                                                               const float *__restrict__ mb, int N,
                                                               float *__restrict__ g,
-                                                              float *__restrict__ cvec) {
+                                                              float *__restrict__ cvec,
+                                                              unsigned long long *__restrict__ hist,
+                                                              int32_t *__restrict__ err) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 2 * N) hist[(size_t)tid * gridDim.x + b] = 0ull;
+  if (b == 0 && tid == 0) *err = 0;
   const float *eb = emb + (size_t)b * N * VRP_EMB;
   if (tid < VRP_EMB) {
     float s = 0.f;
@@ -554,7 +560,8 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs w = carve_decws(workspace, B, N);
-  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec);
+  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec,
+                     w.hist, w.err);
   VRP_CHECK_LAUNCH("graph_mean_cvec");
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
                                  st)) return r;

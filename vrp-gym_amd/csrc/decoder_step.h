@@ -1,0 +1,78 @@
+// Shared by the per-step decode kernels (decoder.hip) and the persistent multi-step one
+// (decoder_persistent.hip): launch parameters and the row-pipeline helpers.
+#pragma once
+#include "env_device.h"
+#include "decoder_ws.h"
+
+struct StepParams {
+  int kind, B, N, t, max_steps, sample, decode_only;
+  const float *emb;
+  const float *row0, *SLD, *SL, *base;
+  float *curs;
+  int32_t *last, *first;
+  const float *WvT, *bv, *MT, *mb;
+  const float *RT, *cvec;
+  vrp_env env;
+  vrp_rollout_io io;
+};
+
+#ifndef RT_U
+#define RT_U 5  // float4 loads per lane per work item (N = 40: 10 per row share -> 2 items)
+#endif
+#ifndef RT_NB
+#define RT_NB 3  // work items in flight per wave, large-batch mode (114 VGPRs: four waves per SIMD)
+#endif
+#ifndef RT_MINW
+#define RT_MINW 3
+#endif
+
+// lane owns float4 indices part + 8*i (i < cnt) of its row; one work item = RT_U of them
+__device__ __forceinline__ void rt_load(float4 (&r)[RT_U], const float4 *rt, int i0, int cnt,
+                                        bool on) {
+#pragma unroll
+  for (int i = 0; i < RT_U; ++i)
+    r[i] = (on && i0 + i < cnt) ? rt[8 * (i0 + i)] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float rt_dot(float acc, const float4 (&r)[RT_U], const float4 *a,
+                                        int i0, int cnt) {
+#pragma unroll
+  for (int i = 0; i < RT_U; ++i) {
+    if (i0 + i < cnt) {
+      const float4 w = a[8 * (i0 + i)];
+      acc = fmaf(w.x, r[i].x, acc);
+      acc = fmaf(w.y, r[i].y, acc);
+      acc = fmaf(w.z, r[i].z, acc);
+      acc = fmaf(w.w, r[i].w, acc);
+    }
+  }
+  return acc;
+}
+// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
+// error carried into a first-order correction; ~1 ulp, no range handling needed
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147180559945f, e);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const long long x = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane((int)x, l);
+  const int hi = __builtin_amdgcn_readlane((int)(x >> 32), l);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// index of the k-th set bit of `bits` (k < popcount), wave-uniform inputs per lane group
+__device__ __forceinline__ int kth_set_bit(unsigned long long bits, int k) {
+  for (int i = 0; i < k; ++i) bits &= bits - 1;
+  return __ffsll((long long)bits) - 1;
+}
+
+
+StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *env, const float *emb,
+                                void *workspace, const vrp_rollout_io *io, int t, int max_steps,
+                                int flags);
+bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
+                             const vrp_rollout_io *io);
+int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st);

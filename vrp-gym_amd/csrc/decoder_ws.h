@@ -66,6 +66,13 @@ struct DecWs {
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:]
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
+  // persistent multi-step kernel (decoder_persistent.hip)
+  unsigned long long *hist;      // (2N, B) published mask words, one row per step
+  int32_t *ta;                   // (B) step at which a graph's visited row became all ones
+  float *ret;                    // (B) reward of the forced way back after ta
+  int32_t *wb_cur;               // (B) location before the way back
+  double *wb_load;               // (B) load before the way back
+  int32_t *err;                  // spin-limit flag
 };
 
 #define VRP_RT_MAX_N 128    // above this the tile kernel (one raw-tile read per step) is used
@@ -108,6 +115,12 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
   w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
   w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
+  w.hist = (unsigned long long *)p; p += vrp_align_up((size_t)2 * N * B * 8);
+  w.ta = (int32_t *)p;    p += vrp_align_up((size_t)B * 4);
+  w.ret = (float *)p;     p += vrp_align_up((size_t)B * 4);
+  w.wb_cur = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
+  w.wb_load = (double *)p; p += vrp_align_up((size_t)B * 8);
+  w.err = (int32_t *)p;   p += vrp_align_up(4);
   return w;
 }
 
@@ -117,7 +130,9 @@ static inline int64_t decws_bytes(int B, int N) {
                    vrp_align_up(proj_floats(B, N) * 4) + 6 * vrp_align_up(hn) +
                    vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 1024 * 4) +
                    vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
-                   vrp_align_up(R * 4) + 2 * vrp_align_up((size_t)B * 4));
+                   vrp_align_up(R * 4) + 5 * vrp_align_up((size_t)B * 4) +
+                   vrp_align_up((size_t)B * 8) +
+                   vrp_align_up((size_t)2 * N * B * 8) + vrp_align_up(4));
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
