@@ -584,13 +584,14 @@ __device__ __forceinline__ void eb16_mma(f32x4v (&acc)[RT16][2], const float *ab
 
 // The stages of the fused block on a tile already in LDS: bufA = attention output (later the
 // hidden-layer slices), bufB = layer input (y1 in place); wa holds the Wo fragment.  Rows
-// [0, valid_rows) of the result go to y_tile (global, row stride 128).
+// [0, valid_rows) of the result go to y_tile (global, row stride y_ld = 128; or bufB itself
+// with y_ld = EB_LD: every element is read and rewritten by the same thread).
 template <int RT16>
 __device__ __forceinline__ void eb16_block_stages(
     float *bufA, float *bufB, float (&wa)[2][32], const float *__restrict__ bo,
     const float *__restrict__ norm1, const float *__restrict__ W1, const float *__restrict__ b1,
     const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ norm2,
-    float *__restrict__ y_tile, int valid_rows, int hidden, int lane, int wave) {
+    float *y_tile, int valid_rows, int hidden, int lane, int wave, int y_ld = 128) {
   const int i16 = lane & 15, q = lane >> 4;
   const int col[2] = {wave * 32 + i16, wave * 32 + 16 + i16};
   float wb[2][32];
@@ -660,7 +661,7 @@ __device__ __forceinline__ void eb16_block_stages(
         const int row = rt * 16 + 4 * q + r;
         if (row < valid_rows) {
           const float v = gacc[rt][ct][r] + bb + bufB[row * EB_LD + c];
-          y_tile[(size_t)row * 128 + c] = (v - mean) * mult + beta;
+          y_tile[(size_t)row * y_ld + c] = (v - mean) * mult + beta;
         }
       }
   }
@@ -717,6 +718,278 @@ static int launch_encoder_block16(const float *att, const float *x, const vrp_en
                      att, x, L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
                      L.ff2_weight, L.ff2_bias, norm2, y, rows, hidden);
   VRP_CHECK_LAUNCH("encoder_block16");
+  return 0;
+}
+
+// ---- whole encoder in ONE launch (eval mode, small batches) -------------------------------
+// Without batch statistics a graph never meets another graph in the encoder
+// (graph_encoder.py:41-58,95-138,183-198), so a workgroup can take G whole graphs (G*N <= 48
+// rows = three 16-row MFMA tiles; N = 20: two graphs = 40 rows) through ALL layers with the
+// activations in LDS: in_proj -> per-graph attention -> out-proj + BN1 + FF + BN2, three
+// times, one read of the embedded inputs and one write of the result.  Replaces 2 launches
+// per layer (each ~2-3 us of dependent-launch latency at this size) and the global round trips
+// between them.  EIGHT waves per workgroup, two per SIMD: a wave owns 16 output columns of the
+// block stages, one 48-column block of in_proj and one attention head, so that while one wave
+// of a SIMD writes its results to LDS or waits at a barrier the other one keeps the matrix
+// pipe busy (same arithmetic and summation order as the 4-wave kernels above).
+__device__ __forceinline__ void eb8_load_w(float (&w)[32], const float *w0) {
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    const float4 t0 = *reinterpret_cast<const float4 *>(w0 + s);
+    w[s] = t0.x; w[s + 1] = t0.y; w[s + 2] = t0.z; w[s + 3] = t0.w;
+  }
+}
+template <int RT16>
+__device__ __forceinline__ void eb8_mma(f32x4v (&acc)[RT16], const float *abuf, const float (&w)[32],
+                                        int lane) {
+  const int i16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    float4 a[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+      a[rt] = *reinterpret_cast<const float4 *>(abuf + (rt * 16 + i16) * EB_LD + 32 * q + s);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) {
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[s], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[s + 1], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[s + 2], acc[rt], 0, 0, 0);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[s + 3], acc[rt], 0, 0, 0);
+    }
+  }
+}
+
+template <int RT16>
+__device__ __forceinline__ void eb8_block_stages(
+    float *bufA, float *bufB, float (&wa)[32], const float *__restrict__ bo,
+    const float *__restrict__ norm1, const float *__restrict__ W1, const float *__restrict__ b1,
+    const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ norm2,
+    float *y_tile, int valid_rows, int hidden, int lane, int wave, int y_ld) {
+  const int i16 = lane & 15, q = lane >> 4;
+  const int c = wave * 16 + i16;  // this lane's weight row / D column
+  float wb[32];
+  f32x4v acc[RT16], gacc[RT16];
+#pragma unroll
+  for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[rt][r] = 0.f; gacc[rt][r] = 0.f; }
+  // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
+  eb8_load_w(wb, W1 + (size_t)c * 128 + 32 * q);
+  eb8_mma<RT16>(acc, bufA, wa, lane);
+  {
+    const float bb = bo[c], mean = norm1[c], mult = norm1[128 + c], beta = norm1[256 + c];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *p = bufB + (rt * 16 + 4 * q + r) * EB_LD + c;   // D: row = 4*(lane>>4)+r, col = lane&15
+        *p = (acc[rt][r] + bb + *p - mean) * mult + beta;      // x -> y1 in place
+      }
+  }
+  __syncthreads();
+  // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T --------------
+  const int nchunk = hidden / 128;
+  for (int ch = 0; ch < nchunk; ++ch) {
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rt][r] = 0.f;
+    eb8_load_w(wa, W2 + (size_t)c * hidden + ch * 128 + 32 * q);
+    eb8_mma<RT16>(acc, bufB, wb, lane);
+    {
+      const float bb = b1[ch * 128 + c];
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bufA[(rt * 16 + 4 * q + r) * EB_LD + c] = fmaxf(acc[rt][r] + bb, 0.f);
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk) eb8_load_w(wb, W1 + (size_t)((ch + 1) * 128 + c) * 128 + 32 * q);
+    eb8_mma<RT16>(gacc, bufA, wa, lane);
+    __syncthreads();
+  }
+  // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
+  {
+    const float bb = b2[c], mean = norm2[c], mult = norm2[128 + c], beta = norm2[256 + c];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        if (row < valid_rows) {
+          const float v = gacc[rt][r] + bb + bufB[row * EB_LD + c];
+          y_tile[(size_t)row * y_ld + c] = (v - mean) * mult + beta;
+        }
+      }
+  }
+}
+
+// in_proj of the tile: wave w owns column block w (48 columns = q, k or v of two heads)
+template <int NTMAX>
+__device__ __forceinline__ void qa8_stage_project(const float *X_s, float *Q_s,
+                                                  const float *__restrict__ Win,
+                                                  const float *__restrict__ bin, int lane, int wave) {
+  const int i16 = lane & 15, q = lane >> 4;
+  float w[3][32];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const float *wr = Win + (size_t)(wave * 48 + ct * 16 + i16) * VRP_EMB + 32 * q;
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(wr + s);
+      w[ct][s] = t.x; w[ct][s + 1] = t.y; w[ct][s + 2] = t.z; w[ct][s + 3] = t.w;
+    }
+  }
+  f32x4q acc[NTMAX][3];
+#pragma unroll
+  for (int rt = 0; rt < NTMAX; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) {
+    float4 a[NTMAX];
+#pragma unroll
+    for (int rt = 0; rt < NTMAX; ++rt)
+      a[rt] = *reinterpret_cast<const float4 *>(X_s + (rt * 16 + i16) * QA_XLD + 32 * q + s);
+#pragma unroll
+    for (int rt = 0; rt < NTMAX; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[ct][s], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[ct][s + 1], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[ct][s + 2], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[ct][s + 3], acc[rt][ct], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int col = wave * 48 + ct * 16 + i16;
+    const float bb = bin[col];
+#pragma unroll
+    for (int rt = 0; rt < NTMAX; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)  // D: row = 4*(lane>>4) + r, col = lane & 15
+        Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb;
+  }
+}
+
+// attention of the tile's graphs (graph_encoder.py:170-172,196): wave = head, lane = query;
+// N <= 32: two graphs at once, one per 32-lane half
+__device__ __forceinline__ void qa8_stage_attention(const float *Q_s, int N, int graphs, float *out,
+                                                    int lane, int wave) {
+  const int h = wave;
+  const int per = (N <= 32) ? 2 : 1;
+  for (int gb = 0; gb < graphs; gb += per) {
+    const int g = gb + ((N <= 32) ? (lane >> 5) : 0);
+    const int i = (N <= 32) ? (lane & 31) : lane;
+    if (i < N && g < graphs) {
+      const float *Qg = Q_s + (size_t)g * N * QA_QLD;
+      float qv[16];
+#pragma unroll
+      for (int d = 0; d < 16; d += 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(Qg + i * QA_QLD + h * 16 + d);
+        qv[d] = t.x * 0.25f; qv[d + 1] = t.y * 0.25f; qv[d + 2] = t.z * 0.25f; qv[d + 3] = t.w * 0.25f;
+      }
+      float m = -INFINITY, l = 0.f, o[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) o[d] = 0.f;
+      for (int j = 0; j < N; ++j) {
+        float kk[16], vv[16];
+#pragma unroll
+        for (int d = 0; d < 16; d += 4) {
+          const float4 tk = *reinterpret_cast<const float4 *>(Qg + j * QA_QLD + 128 + h * 16 + d);
+          const float4 tv = *reinterpret_cast<const float4 *>(Qg + j * QA_QLD + 256 + h * 16 + d);
+          kk[d] = tk.x; kk[d + 1] = tk.y; kk[d + 2] = tk.z; kk[d + 3] = tk.w;
+          vv[d] = tv.x; vv[d + 1] = tv.y; vv[d + 2] = tv.z; vv[d + 3] = tv.w;
+        }
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) sc = fmaf(qv[d], kk[d], sc);
+        if (sc > m) {
+          const float corr = expf(m - sc);
+          l *= corr;
+#pragma unroll
+          for (int d = 0; d < 16; ++d) o[d] *= corr;
+          m = sc;
+        }
+        const float pw = expf(sc - m);
+        l += pw;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] = fmaf(pw, vv[d], o[d]);
+      }
+      const float inv = 1.f / l;
+      float *dst = out + (size_t)(g * N + i) * EB_LD + h * 16;
+#pragma unroll
+      for (int d = 0; d < 16; d += 4)
+        *reinterpret_cast<float4 *>(dst + d) =
+            make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+  }
+}
+
+template <int RT16>
+__global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights w,
+                                                             const float *__restrict__ x,
+                                                             const float *__restrict__ norms,
+                                                             float *__restrict__ y, int B, int N,
+                                                             int G) {
+  constexpr int RTW = 16 * RT16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *bufB = smem;                          // [RTW][EB_LD]   layer input, y1, layer output
+  float *bufA = bufB + RTW * EB_LD;            // [RTW][EB_LD]   attention output, hidden slices
+  float *Q_s = bufA + RTW * EB_LD;             // [RTW][QA_QLD]  q | k | v of every node
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int c = wave * 16 + i16;
+  const int g0 = blockIdx.x * G;
+  const int graphs = min(G, B - g0);
+  const int rows = graphs * N;                 // valid rows of this workgroup's tile
+  const size_t row0 = (size_t)g0 * N;
+  for (int idx = tid; idx < RTW * 32; idx += 512) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+    *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = v;
+    *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int l = 0; l < w.num_layers; ++l) {
+    const vrp_encoder_layer &L = w.layer[l];
+    float wa[32];  // Wo fragment: in flight while in_proj and the attention run
+    eb8_load_w(wa, L.out_proj_weight + (size_t)c * 128 + 32 * q);
+    qa8_stage_project<RT16>(bufB, Q_s, L.in_proj_weight, L.in_proj_bias, lane, wave);
+    __syncthreads();
+    qa8_stage_attention(Q_s, N, graphs, bufA, lane, wave);
+    __syncthreads();
+    const bool lastl = l + 1 == w.num_layers;
+    eb8_block_stages<RT16>(bufA, bufB, wa, L.out_proj_bias, norms + (2 * l) * 384, L.ff0_weight,
+                           L.ff0_bias, L.ff2_weight, L.ff2_bias, norms + (2 * l + 1) * 384,
+                           lastl ? y + row0 * 128 : bufB, lastl ? rows : RTW, w.hidden, lane, wave,
+                           lastl ? 128 : EB_LD);
+    __syncthreads();
+  }
+}
+
+template <int RT16>
+static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, const float *norms,
+                                float *y, int B, int N, hipStream_t st) {
+  constexpr int RTW = 16 * RT16;
+  const size_t lds = (size_t)RTW * (2 * EB_LD + QA_QLD) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_stack_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_stack: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int G = RTW / N;
+  hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
+                     norms, y, B, N, G);
+  VRP_CHECK_LAUNCH("encoder_stack");
   return 0;
 }
 
@@ -906,6 +1179,11 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
                           float *emb, const EncWs &ws, hipStream_t st) {
   const int R = B * N;
   float *nxt = nullptr;
+  static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
+  if (!train && !stack_off && N <= 48 && w->hidden % 128 == 0 && (B + 48 / N - 1) / (48 / N) <= 512) {
+    // small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
+    return launch_encoder_stack<3>(w, cur, ws.norm, emb, B, N, st);
+  }
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
     // out = bn1(x + MHA(x))
