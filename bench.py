@@ -322,25 +322,41 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
 
 def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
     """The CPU oracle (a port of the reference's algorithm: vectorised numpy env +
-    torch-CPU fp32 policy) on this host's cores, same workload, bounded sample."""
+    torch-CPU fp32 policy) on this host's cores, same workload, bounded sample.  The ops of a
+    rollout at this size are small: more threads than a socket's worth make it SLOWER, so a
+    few thread counts are tried briefly and the sample runs at the best one (`cores`)."""
+    from copy import deepcopy
     from oracle import envs as oenv
     from oracle import policy as opol
     sd, _ = opol.init_state_dicts(kind, 69)
     env = oenv.OracleEnv(kind, N, B, 1, 69)
-    from copy import deepcopy
-    n, node_steps, t0 = 0, 0, time.perf_counter()
+    default_threads = torch.get_num_threads()
+    cands = sorted({t for t in (8, 16, 32, default_threads) if t <= (os.cpu_count() or 1)})
+    best_t, best_dt = default_threads, None
     with torch.no_grad():
-        opol.rollout(sd, deepcopy(env), greedy)  # warm
-        t0 = time.perf_counter()
+        for t in cands:
+            torch.set_num_threads(t)
+            opol.rollout(sd, deepcopy(env), greedy)  # warm
+            t0 = time.perf_counter()
+            opol.rollout(sd, deepcopy(env), greedy)
+            dt = time.perf_counter() - t0
+            if best_dt is None or dt < best_dt:
+                best_t, best_dt = t, dt
+        torch.set_num_threads(best_t)
+        n, node_steps, t0 = 0, 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s:
             _, _, T = opol.rollout(sd, deepcopy(env), greedy)
             node_steps += B * N * T
             n += 1
     dt = time.perf_counter() - t0
+    torch.set_num_threads(default_threads)
     return {"value": round(node_steps / dt, 1), "unit": "node-steps/s",
-            "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{n} greedy rollouts of kind{kind} N={N} B={B} in {dt:.1f}s "
-                      f"(oracle/: numpy env + torch-CPU fp32 policy)"}
+            "cores": best_t, "host_cpus": os.cpu_count(), "kind": "port",
+            "threads_tried": cands,
+            "sample": f"{n} {'greedy' if greedy else 'sampled'} rollouts of kind{kind} N={N} B={B} "
+                      f"in {dt:.1f}s (oracle/: numpy env + torch-CPU fp32 policy; measured 4.8x "
+                      f"(TSP-20) to 7.6x (VRP-40) faster than the reference itself on 8 cores, "
+                      f"BASELINE.md section 3)"}
 
 
 def run_workload(name, steps, warmup, device, dist, rank, world):

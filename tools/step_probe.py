@@ -18,7 +18,7 @@ if len(sys.argv) > 1:
 dev = torch.device("cuda", 0)
 for shp in shapes:
     kind, N, B = shp[:3]
-    extra = 16 if len(shp) > 3 and shp[3] else 0   # 4th field 1 = VRP_STEP_THROUGHPUT_KERNEL
+    extra = shp[3] if len(shp) > 3 else 0   # 4th field: extra step flags (16 = throughput kernel, 4 = tile kernel, 32 = no persistent)
     greedy = not (len(shp) > 4 and shp[4])         # 5th field 1 = sampling
     if os.environ.get("STEP_PROBE_PER_STEP"):
         print(json.dumps({"workload": f"kind{kind}_N{N}_B{B}", "per_step_us":
