@@ -147,6 +147,7 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   // Wproj);  mb = s * Wkp^T tmpv
   b.mm(d.MT, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
   b.mm(d.Wproj + (size_t)768 * 128, 1, 128, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
+  b.mm(d.M, 384, 1, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
   b.mm(d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s);
   if (int r = a.launch(st)) return r;
   return b.launch(st);
@@ -161,263 +162,6 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
 __device__ __forceinline__ void flag_notdone(int32_t *flag) { *flag = 1; }
 
 // ------------------------------------------------------------------ the step kernel
-
-#define GPW 4  // graphs per workgroup (one wave each)
-
-template <int NMAX>
-__global__ __launch_bounds__(256) void decode_step_kernel(StepParams p) {
-  constexpr int NPL = (NMAX + 63) / 64;
-  // Batch-wide done (tsp.py:95,103-104): once the previous step reported every graph
-  // finished, the remaining launches of a fixed-length loop are exact no-ops.
-  if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *a_s = smem;                    // [GPW][NMAX*8]  glimpse attention weights
-  float *zs = a_s + GPW * NMAX * 8;     // [GPW][8*128]   z_h = sum_n a_{h,n} e_n
-  float *os = zs + GPW * 1024;          // [GPW][384]     o = Wv z + bv
-  float *wp = os + GPW * 384;           // [2][GPW][128]  partial sums of M o
-  float *wq = wp + 2 * GPW * 128;       // [GPW][128]     w = M o + mb
-  float *tr = wq + GPW * 128;           // [GPW][NMAX*65] logit partials, transposed
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int N = p.N, B = p.B;
-  const int braw = blockIdx.x * GPW + wave;
-  const bool active = braw < B;
-  const int b = active ? braw : B - 1;
-  const int par = p.t & 1;
-  const uint8_t *mask_in = p.env.mask + (size_t)par * B * N;
-  uint8_t *mask_out = p.env.mask + (size_t)(par ^ 1) * B * N;
-
-  // ---- phase 1: embedding tile -> registers (the only pass over it) -----------------
-  float2 e[NMAX];
-  {
-    const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n)
-      e[n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
-  }
-
-  // glimpse scores = table rows + additive scrambled mask, softmax over nodes
-  {
-    const float loadf = (p.kind == VRP_KIND_IRP) ? (float)p.env.load[b] : 0.f;
-    const int last = (p.t > 0) ? p.last[b] : 0;
-    const float *srow = (p.t == 0) ? p.row0 + (size_t)b * 8 * N
-                                   : p.SL + ((size_t)b * N + last) * 8 * N;
-    const float *sldp = p.SLD + (size_t)b * 8 * N;
-    const float *basep = p.base ? p.base + (size_t)b * 8 * N : nullptr;
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const uint8_t *mrow = mask_in + (size_t)((b * 8 + h) % B) * N;  // QUIRK D3
-      float s[NPL];
-      float m = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int n = lane + 64 * i;
-        s[i] = -INFINITY;
-        if (n < N) {
-          float v = srow[h * N + n];
-          if (p.t > 0 && basep) v += basep[h * N + n];
-          if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sldp[h * N + n], v);
-          s[i] = v + (float)mrow[n];
-        }
-        m = fmaxf(m, s[i]);
-      }
-      m = wave_max(m);
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        s[i] = (lane + 64 * i < N) ? expf(s[i] - m) : 0.f;
-        sum += s[i];
-      }
-      sum = wave_sum(sum);
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int n = lane + 64 * i;
-        if (n < NMAX) a_s[(wave * NMAX + n) * 8 + h] = s[i] / sum;
-      }
-    }
-  }
-  __syncthreads();
-
-  // z_h[2l..2l+1] = sum_n a[h][n] * e[n][2l..2l+1]
-  {
-    float2 z[8];
-#pragma unroll
-    for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
-    const float4 *ap = reinterpret_cast<const float4 *>(a_s + wave * NMAX * 8);
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n) {
-      const float4 a0 = ap[2 * n], a1 = ap[2 * n + 1];
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        z[h].x = fmaf(av[h], e[n].x, z[h].x);
-        z[h].y = fmaf(av[h], e[n].y, z[h].y);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 8; ++h)
-      *reinterpret_cast<float2 *>(zs + wave * 1024 + h * 128 + 2 * lane) = z[h];
-  }
-  __syncthreads();
-
-  // ---- phase 2: o = Wv z + bv  (per head),  w = M o + mb   (shared by the 4 graphs) --
-  for (int j = tid; j < VRP_D; j += 256) {
-    const int h = j / VRP_HD;
-    float acc[GPW];
-    const float bvj = p.bv[j];
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) acc[g] = bvj;
-    for (int k = 0; k < 128; k += 4) {
-      const float w0 = p.WvT[(size_t)(k + 0) * VRP_D + j], w1 = p.WvT[(size_t)(k + 1) * VRP_D + j];
-      const float w2 = p.WvT[(size_t)(k + 2) * VRP_D + j], w3 = p.WvT[(size_t)(k + 3) * VRP_D + j];
-#pragma unroll
-      for (int g = 0; g < GPW; ++g) {
-        const float4 x = *reinterpret_cast<const float4 *>(zs + g * 1024 + h * 128 + k);
-        acc[g] = fmaf(w0, x.x, acc[g]);
-        acc[g] = fmaf(w1, x.y, acc[g]);
-        acc[g] = fmaf(w2, x.z, acc[g]);
-        acc[g] = fmaf(w3, x.w, acc[g]);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) os[g * VRP_D + j] = acc[g];
-  }
-  __syncthreads();
-  {
-    const int c = tid & 127, half = tid >> 7;
-    float acc[GPW];
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) acc[g] = 0.f;
-    for (int k = half * 192; k < half * 192 + 192; k += 4) {
-      const float w0 = p.MT[(size_t)(k + 0) * 128 + c], w1 = p.MT[(size_t)(k + 1) * 128 + c];
-      const float w2 = p.MT[(size_t)(k + 2) * 128 + c], w3 = p.MT[(size_t)(k + 3) * 128 + c];
-#pragma unroll
-      for (int g = 0; g < GPW; ++g) {
-        const float4 x = *reinterpret_cast<const float4 *>(os + g * VRP_D + k);
-        acc[g] = fmaf(w0, x.x, acc[g]);
-        acc[g] = fmaf(w1, x.y, acc[g]);
-        acc[g] = fmaf(w2, x.z, acc[g]);
-        acc[g] = fmaf(w3, x.w, acc[g]);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) wp[(half * GPW + g) * 128 + c] = acc[g];
-  }
-  __syncthreads();
-  for (int i = tid; i < GPW * 128; i += 256) wq[i] = wp[i] + wp[GPW * 128 + i] + p.mb[i & 127];
-  __syncthreads();
-
-  // ---- phase 3: pointer logits u_n = 10 tanh(w . e_n), own mask -> -inf ---------------
-  {
-    const float2 wv = *reinterpret_cast<const float2 *>(wq + wave * 128 + 2 * lane);
-    float *trw = tr + wave * NMAX * 65;
-#pragma unroll
-    for (int n = 0; n < NMAX; ++n) trw[n * 65 + lane] = fmaf(wv.x, e[n].x, wv.y * e[n].y);
-  }
-  __syncthreads();
-  float u[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const int n = lane + 64 * i;
-    u[i] = -INFINITY;
-    if (n < N) {
-      const float *row = tr + wave * NMAX * 65 + n * 65;
-      float x = 0.f;
-#pragma unroll 16
-      for (int j = 0; j < 64; ++j) x += row[j];
-      u[i] = mask_in[(size_t)b * N + n] ? -INFINITY : 10.f * tanhf(x);  // graph_decoder.py:97-98
-    }
-  }
-  if (active && p.io.logits) {
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      if (lane + 64 * i < N) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
-  }
-  if (active && p.io.mask_trace) {
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      if (lane + 64 * i < N)
-        p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] =
-            mask_in[(size_t)b * N + lane + 64 * i];
-  }
-  if (active && p.io.load_trace && lane == 0)
-    p.io.load_trace[(size_t)p.t * B + b] =
-        (p.kind == VRP_KIND_IRP) ? (float)p.env.load[b] : 1.f;
-
-  // ---- action: greedy argmax (lowest index on ties) or argmax(softmax(u)/q) -----------
-  int idx;
-  float logp = 0.f;  // greedy rollouts report log_prob = 0   graph_decoder.py:100-103
-  if (!p.sample) {
-    float bv_ = u[0];
-    int bi = lane;
-#pragma unroll
-    for (int i = 1; i < NPL; ++i)
-      if (u[i] > bv_) { bv_ = u[i]; bi = lane + 64 * i; }
-    wave_argmax(bv_, bi);
-    idx = bi;
-    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
-  } else {
-    // Categorical(logits=u): logits - logsumexp, probs = softmax, sample = argmax(p/q)
-    float m = u[0];
-#pragma unroll
-    for (int i = 1; i < NPL; ++i) m = fmaxf(m, u[i]);
-    m = wave_max(m);
-    float se = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) se += expf(u[i] - m);
-    se = wave_sum(se);
-    const float lse = m + logf(se);
-    float l[NPL], lm = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { l[i] = u[i] - lse; lm = fmaxf(lm, l[i]); }
-    lm = wave_max(lm);
-    float pe[NPL], ps = 0.f;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { pe[i] = expf(l[i] - lm); ps += pe[i]; }
-    ps = wave_sum(ps);
-    float best = -1.f;
-    int bi = lane;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const int n = lane + 64 * i;
-      if (n < N) {
-        const float q = p.io.noise[((size_t)p.t * B + b) * N + n];
-        const float r = (pe[i] / ps) / q;
-        if (r > best) { best = r; bi = n; }
-      }
-    }
-    wave_argmax(best, bi);
-    idx = bi;
-    if (p.io.forced) idx = (int)p.io.forced[(size_t)p.t * B + b];
-    const float lsel = (idx >= 64) ? l[NPL - 1] : l[0];
-    logp = __shfl(lsel, idx & 63, 64);
-  }
-
-  if (!active) return;  // wave-uniform; no barriers below
-
-  if (p.decode_only) {  // GraphDecoder.forward alone (graph_decoder.py:108-113 state update)
-    if (lane == 0) {
-      p.last[b] = idx;
-      if (p.t == 0) p.first[b] = idx;
-      if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
-      if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
-    }
-    return;
-  }
-
-  // ---- environment step on the chosen node + episode accumulators ---------------------
-  EnvStepOut eo = env_step_wave(p.env, b, idx, lane, mask_out);
-  if (lane == 0) {
-    p.io.acc_loss[b] += (float)(-eo.dist);  // fp32 accumulate in step order, tsp_agent:85
-    p.io.acc_logp[b] += logp;
-    p.last[b] = idx;
-    if (p.t == 0) p.first[b] = idx;
-    if (!eo.done) flag_notdone(&p.io.notdone[p.t]);
-    if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
-    if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
-  }
-}
 
 // ---------------------------------------------------------------- table-driven step (N <= 64)
 // One wave per graph, no weight matrix and no embedding tile.  Per step a graph streams
@@ -527,9 +271,11 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     if (s_i) sel_s[wave][nsel + __popcll(sel[i] & ((1ull << lane) - 1ull))] = lane + 64 * i;
     nsel += __popcll(sel[i]);
   }
+  // graphs with many selectable nodes may belong to the raw-tile kernel (decoder_tile.hip)
+  const bool mine = nsel >= p.sel_lo && nsel < p.sel_hi;
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
-  const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
+  const int total = mine ? ((nsel + 7) >> 3) * nchunk : 0;  // work items (pass, chunk), wave-uniform
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
   // measured (tools/step_probe.py): three items in flight are best at 8192 graphs, two in
   // the latency mode (512..2048 graphs)
@@ -636,12 +382,12 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     u[i] = -INFINITY;
     if (inN[i] && !own_mask[i])
       u[i] = 10.f * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
-    if (active && p.io.logits && inN[i])
+    if (active && mine && p.io.logits && inN[i])
       p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
-    if (active && p.io.mask_trace && inN[i])
+    if (active && mine && p.io.mask_trace && inN[i])
       p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] = (uint8_t)own_mask[i];
   }
-  if (active && p.io.load_trace && lane == 0)
+  if (active && mine && p.io.load_trace && lane == 0)
     p.io.load_trace[(size_t)p.t * B + b] = (float)load0;
 
   // lowest node index among the maxima (torch CPU argmax): slot 0 holds nodes < 64
@@ -694,7 +440,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
                                                                idx & 63));
   }
   idx = __builtin_amdgcn_readfirstlane(idx);
-  if (!active || prev_notdone == 0) return;  // wave-uniform; no barriers below
+  if (!active || !mine || prev_notdone == 0) return;  // wave-uniform; no barriers below
 
   // latency mode: next step's score row = SL[b][idx], copied while the env step runs (after
   // step 0 of TSP/VRP the table does not exist yet: its builder writes the row itself)
@@ -780,29 +526,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   }
 }
 
-template <int NMAX>
-static size_t step_lds_bytes() {
-  return sizeof(float) * (GPW * NMAX * 8 + GPW * 1024 + GPW * 384 + 2 * GPW * 128 + GPW * 128 +
-                          GPW * NMAX * 65);
-}
-
-template <int NMAX>
-static int launch_step(const StepParams &p, hipStream_t st) {
-  const size_t lds = step_lds_bytes<NMAX>();
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_kernel<NMAX>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      vrp_set_error("decode_step: cannot raise dynamic LDS to %zu bytes", lds);
-      return 1;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(decode_step_kernel<NMAX>, dim3((p.B + GPW - 1) / GPW), dim3(256), lds, st, p);
-  VRP_CHECK_LAUNCH("decode_step");
-  return 0;
-}
-
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st);
 
 StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *env, const float *emb,
@@ -820,7 +543,11 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.base = (kind == VRP_KIND_IRP) ? nullptr : ws.base;  // IRP: the constant row is inside SL
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
+  p.Wv = d.Wproj + (size_t)1152 * 128; p.M = d.M;
   p.RT = ws.RT; p.cvec = ws.cvec;
+  p.sel_lo = 0; p.sel_hi = 1 << 30;
+  static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
+  p.dbg = dbg;
   p.env = *env;
   p.io = *io;
   return p;
@@ -851,36 +578,72 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   return 0;
 }
 
+// Which kernel takes which graphs at step t.  The raw-tile kernel costs the same whatever the
+// mask, a table step costs one 32 N-byte row per selectable node: tile for graphs with at least
+// `thresh` selectable nodes (measured crossover, large batches), table below.
+static int tile_threshold() {
+  static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 18;
+  return v;
+}
+// OFF by default: measured on MI355X the raw-tile kernel needs 97 us per step
+// at 8192 x 40 (tile loads 44, glimpse sums 15, weight folds 40 -- the 384 KB of folded weights
+// are re-read from L2 by every workgroup of 16 graphs, 24 KB per graph-step, more than the
+// tile itself) against 98 -> 19 us for the table kernel: it only wins the very first steps.
+static bool hybrid_shape(int B, int N) {
+  static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;  // A/B aid
+  return on && B > 2048 && N <= 40 && N > tile_threshold();
+}
+
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none)) return "decode_persistent_kernel";
-  if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
-    const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
-    if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
-    return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";
-  }
-  return N <= 24 ? "decode_step_kernel<24>" : N <= 40 ? "decode_step_kernel<40>"
-       : N <= 64 ? "decode_step_kernel<64>" : "decode_step_kernel<104>";
+  const char *tile = N <= 40 ? "decode_step_tile_mfma_kernel<40, 2>" : "decode_step_tile_mfma_kernel<104, 1>";
+  if (flags & VRP_STEP_TILE_KERNEL) return tile;
+  if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
+      getenv("VRP_TILE_LARGE_N")) return tile;
+  if (hybrid_shape(B, N))
+    return "decode_step_tile_mfma_kernel<40, 2> | decode_step_rt_kernel<1, 4> (by selectable nodes)";
+  const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
+  if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
+  return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";
+}
+
+static int launch_rt(const StepParams &p, int flags, hipStream_t st) {
+  const int B = p.B, N = p.N;
+  const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
+  if (N <= 64 && small)
+    hipLaunchKernelGGL((decode_step_rt_kernel<1, 1>), dim3(B), dim3(64), 0, st, p);
+  else if (N <= 64)
+    hipLaunchKernelGGL((decode_step_rt_kernel<1, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
+  else if (small)
+    hipLaunchKernelGGL((decode_step_rt_kernel<2, 1>), dim3(B), dim3(64), 0, st, p);
+  else
+    hipLaunchKernelGGL((decode_step_rt_kernel<2, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
+  VRP_CHECK_LAUNCH("decode_step_rt");
+  return 0;
 }
 
 static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
   const int B = p.B, N = p.N;
-  if (use_rtable(N) && !(flags & VRP_STEP_TILE_KERNEL)) {
-    const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
-    if (N <= 64 && small)
-      hipLaunchKernelGGL((decode_step_rt_kernel<1, 1>), dim3(B), dim3(64), 0, st, p);
-    else if (N <= 64)
-      hipLaunchKernelGGL((decode_step_rt_kernel<1, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
-    else if (small)
-      hipLaunchKernelGGL((decode_step_rt_kernel<2, 1>), dim3(B), dim3(64), 0, st, p);
-    else
-      hipLaunchKernelGGL((decode_step_rt_kernel<2, 4>), dim3((B + 3) / 4), dim3(256), 0, st, p);
-    VRP_CHECK_LAUNCH("decode_step_rt");
-    return 0;
+  if (flags & VRP_STEP_TILE_KERNEL) return vrp_launch_tile_mfma_step(p, st);  // every graph
+  if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL)) {
+    static const bool on = getenv("VRP_TILE_LARGE_N") != nullptr;  // A/B aid (67 vs 62 us at 2048 x 100)
+    if (on) return vrp_launch_tile_mfma_step(p, st);
   }
-  if (N <= 24) return launch_step<24>(p, st);
-  if (N <= 40) return launch_step<40>(p, st);
-  if (N <= 64) return launch_step<64>(p, st);
-  return launch_step<104>(p, st);
+  if (hybrid_shape(B, N) && !p.decode_only) {
+    const int th = tile_threshold();
+    // most selectable nodes any graph can have at step t (TSP: exactly N-1-t; VRP/IRP: a customer
+    // is served at least every other step, the depot may be open)
+    const int most = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t : N - (p.t + 1) / 2;
+    const int least = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t : 0;
+    if (most < th) return launch_rt(p, flags, st);
+    StepParams pt = p, pr = p;
+    pt.sel_lo = th;
+    pr.sel_hi = th;
+    if (int r = vrp_launch_tile_mfma_step(pt, st)) return r;
+    if (least >= th) return 0;  // every graph was the tile kernel's
+    return launch_rt(pr, flags, st);
+  }
+  return launch_rt(p, flags, st);
 }

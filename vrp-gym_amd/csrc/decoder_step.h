@@ -11,7 +11,10 @@ struct StepParams {
   float *curs;
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
+  const float *Wv, *M;          // (384,128) v_proj rows; (128,384) M = Wkp^T Watt Wo / sqrt(128)
   const float *RT, *cvec;
+  int dbg;                      // tuning aid (VRP_TILE_DBG): stop the tile kernel after phase dbg
+  int sel_lo, sel_hi;           // a kernel handles the graphs with sel_lo <= selectable nodes < sel_hi
   vrp_env env;
   vrp_rollout_io io;
 };
@@ -76,3 +79,5 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
                              const vrp_rollout_io *io);
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st);
+bool vrp_tile_mfma_supported(int N);
+int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st);

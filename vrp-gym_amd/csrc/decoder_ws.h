@@ -20,6 +20,7 @@ struct Derived {
   float *mb;     // (128)      Wkp^T Watt bo / sqrt(128)
   float *tmpA;   // (128,384)  Watt Wo
   float *tmpv;   // (128)      Watt bo
+  float *M;      // (128,384)  M itself (row-major: the tile kernel's B operand)
   float *AfT;    // (1024,128) row h*128+k: sum_d Wk[48h+d][k] Wq_first[48h+d][:] / sqrt(48): the
                  //            first-node query folded through the keys (TSP/VRP)
 };
@@ -40,13 +41,14 @@ static inline Derived carve_derived(void *base) {
   d.mb = p;    p += 128;
   d.tmpA = p;  p += 128 * 384;
   d.tmpv = p;  p += 128;
+  d.M = p;     p += 128 * 384;
   d.AfT = p;   p += 1024 * 128;
   return d;
 }
 
 static inline int64_t derived_floats() {
   return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
-         128 * 384 + 128 + 1024 * 128;
+         128 * 384 + 128 + 128 * 384 + 1024 * 128;
 }
 
 // ------------------------------------------------------------------ per-episode workspace
