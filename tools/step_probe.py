@@ -26,4 +26,4 @@ for shp in shapes:
                                                      extra_flags=extra, per_step=True)}))
         continue
     r = bench.step_kernel_roofline(kind, N, B, greedy, dev, reps=3, extra_flags=extra)
-    print(json.dumps({k: r[k] for k in ("workload", "kernel", "avg_launch_us", "event_pair_per_launch_us", "loop_us_per_step", "loop_us", "rollout_us", "achieved", "frac", "loop_frac", "rollout_frac")}))
+    print(json.dumps({k: r[k] for k in ("workload", "kernel", "steps_per_episode", "avg_launch_us", "event_pair_per_launch_us", "loop_us_per_step", "loop_us", "rollout_us", "achieved", "frac", "loop_frac", "rollout_frac")}))

@@ -78,7 +78,11 @@ extern "C" int vrp_rollout_steps(int kind, const void *derived, const vrp_decode
 
 int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const vrp_env *env,
                                  float *emb, void *workspace, float *acc_loss, float *acc_logp,
-                                 int32_t *notdone, int nflags, hipStream_t st);
+                                 int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
+                                 float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
+                                 int *decoder_constants_done, hipStream_t st);
+int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
+                           void *workspace, int constants_done, void *stream);
 
 extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
                            void *derived, const vrp_env *env, int train, int sample, float *emb,
@@ -98,10 +102,17 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
   // the embedding and the zeroed accumulators come from one set-up launch; depot_mask: TSP
   // none, VRP = the state's mask column (QUIRK graph_vrp_agent.py:67), IRP = is_depot
   // (graph_irp_agent.py:77-79)
-  if (int r = vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
-                                           io->acc_logp, io->notdone, max_steps + 1,
-                                           (hipStream_t)stream)) return r;
-  if (int r = vrp_decode_prologue(kind, derived, B, N, emb, dec_workspace, stream)) return r;
+  int constants_done = 0;
+  {
+    Derived d = carve_derived(derived);
+    DecWs w = carve_decws(dec_workspace, B, N);
+    if (int r = vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
+                                             io->acc_logp, io->notdone, max_steps + 1, d.mb, w.g,
+                                             w.cvec, w.hist, w.err, &constants_done,
+                                             (hipStream_t)stream)) return r;
+  }
+  if (int r = vrp_decode_prologue_ex(kind, derived, B, N, emb, dec_workspace, constants_done,
+                                     stream)) return r;
   // `sample` doubles as the step flags
   return rollout_step_loop(kind, derived, dw, env, emb, dec_workspace, io, max_steps,
                            sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL |

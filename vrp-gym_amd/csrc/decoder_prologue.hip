@@ -552,17 +552,28 @@ extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   return decws_bytes(B, N);
 }
 
+int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
+                           void *workspace, int constants_done, void *stream);
 extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
                                    void *workspace, void *stream) {
+  return vrp_decode_prologue_ex(kind, derived, B, N, emb, workspace, 0, stream);
+}
+
+// constants_done: the graph mean, cvec and the cleared hand-off words were already produced by
+// the encoder's stack kernel (vrp_rollout, small batches)
+int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
+                           void *workspace, int constants_done, void *stream) {
   VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "decode_prologue: bad shape B=%d N=%d", B, N);
   VRP_REQUIRE(use_rtable(N), "decode_prologue: N=%d above the table limit %d", N, VRP_RT_MAX_N);
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs w = carve_decws(workspace, B, N);
-  hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec,
-                     w.hist, w.err);
-  VRP_CHECK_LAUNCH("graph_mean_cvec");
+  if (!constants_done) {
+    hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec,
+                       w.hist, w.err);
+    VRP_CHECK_LAUNCH("graph_mean_cvec");
+  }
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
                                  st)) return r;
   if (use_fused_prologue(N)) {

@@ -721,6 +721,90 @@ static int launch_encoder_block16(const float *att, const float *x, const vrp_en
   return 0;
 }
 
+// One graph of the rollout set-up, by one wave: generate_mask on the fresh episode
+// (tsp.py:106-148 via get_state) into mask buffer 0, the network inputs of E3 in registers, the
+// node/depot embedding (graph_encoder.py:54,110-132) to `orow` (row stride `ld`: global
+// memory or an LDS tile), zeroed episode accumulators.  lane = node for the env part, lane =
+// embedding column (x2) after.
+// `part` of `parts` waves share the embedding rows of one graph (rows part, part + parts, ...);
+// part 0 also commits the mask and the accumulators.
+__device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_encoder_weights &w,
+                                                 int b, int lane, float *orow0, int ld,
+                                                 float *__restrict__ acc_loss,
+                                                 float *__restrict__ acc_logp, int part = 0,
+                                                 int parts = 1) {
+  const int N = e.N;
+  if (lane == 0 && part == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
+  // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
+  const uint8_t *vis = e.visited + (size_t)b * N;
+  int v0 = (lane < N) ? vis[lane] : 1;
+  int v1 = (lane + 64 < N) ? vis[lane + 64] : 1;
+  const double load = (e.kind == VRP_KIND_IRP) ? e.load[b] : 1.0;
+  const int dep = e.depot[b];
+  if (part == 0) {
+    env_fixups_and_mask(e, b, lane, e.cur[b] == dep, v0, v1, load, e.mask);
+  } else {  // the same flag fix-ups in registers only (tsp.py:141-146, vrp.py:28-31)
+    const int n0 = lane, n1 = lane + 64;
+    if (e.cur[b] == dep) { if (n0 == dep) v0 = 1; if (n1 == dep) v1 = 1; }
+    else if (e.kind != VRP_KIND_TSP) { if (n0 == dep) v0 = 0; if (n1 == dep) v1 = 0; }
+    if (__all((n0 >= N || v0) && (n1 >= N || v1))) { if (n0 == dep) v0 = 0; if (n1 == dep) v1 = 0; }
+  }
+  // depot flag per node: VRP = the mask column just written (QUIRK graph_vrp_agent.py:67),
+  // IRP = the is_depot column (graph_irp_agent.py:77-79), TSP = none.  For VRP the mask
+  // equals the visited flags (no capacity overlay).
+  const unsigned long long d0 = __ballot(e.kind == VRP_KIND_VRP ? (lane < N && v0) : lane == dep);
+  const unsigned long long d1 =
+      __ballot(e.kind == VRP_KIND_VRP ? (lane + 64 < N && v1) : lane + 64 == dep);
+  // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
+  float fx[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = lane + 64 * i;
+    const size_t r = (size_t)b * N + (n < N ? n : 0);
+    fx[i][0] = (float)e.pos[2 * r];
+    fx[i][1] = (float)e.pos[2 * r + 1];
+    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
+  }
+  // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
+  float wn[2][3], bnv[2], wd[2][2], bdv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
+    bnv[j] = w.node_embed_bias[c];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
+    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
+  }
+  const bool has_depot = w.depot_embed_weight != nullptr && e.kind != VRP_KIND_TSP;
+  for (int n = part; n < N; n += parts) {
+    const int src = n & 63;
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[0][d]), src));
+      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[1][d]), src));
+      x[d] = n < 64 ? lo : hi;
+    }
+    const bool isdep = has_depot && (((n < 64 ? d0 : d1) >> src) & 1ull);
+    float *orow = orow0 + (size_t)n * ld;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v;
+      if (isdep) {
+        v = bdv[j];
+        for (int d = 0; d < w.depot_dim; ++d) v = fmaf(x[d], wd[j][d], v);
+      } else {
+        v = bnv[j];
+        for (int d = 0; d < w.node_dim; ++d) v = fmaf(x[d], wn[j][d], v);
+      }
+      orow[lane + 64 * j] = v;
+    }
+  }
+}
+
 // ---- whole encoder in ONE launch (eval mode, small batches) -------------------------------
 // Without batch statistics a graph never meets another graph in the encoder
 // (graph_encoder.py:41-58,95-138,183-198), so a workgroup can take G whole graphs (G*N <= 48
@@ -928,17 +1012,34 @@ __device__ __forceinline__ void qa8_stage_attention(const float *Q_s, int N, int
   }
 }
 
+// What the decoder prologue needs from the finished embeddings (graph_decoder.py:75-77 and the
+// constant part of the logits): written by the stack kernel's epilogue when it runs inside
+// vrp_rollout, so that no separate pass over the embeddings is needed.
+struct StackEpilogue {
+  const float *mb;             // (128)  decoder's folded bias vector
+  float *g, *cvec;             // (B,128) graph mean, (B,N) e_m . mb
+  unsigned long long *hist;    // (2N,B) persistent step kernel's hand-off words (cleared here)
+  int32_t *err;
+};
+struct StackSetup {            // rollout set-up fused in front (vrp_rollout): env may be null
+  vrp_env env;
+  float *acc_loss, *acc_logp;
+  int32_t *notdone;
+  int nflags, from_env;
+};
+
 template <int RT16>
 __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights w,
                                                              const float *__restrict__ x,
-                                                             const float *__restrict__ norms,
+                                                             const float *__restrict__ norms_in,
                                                              float *__restrict__ y, int B, int N,
-                                                             int G) {
+                                                             int G, StackSetup su, StackEpilogue ep) {
   constexpr int RTW = 16 * RT16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *bufB = smem;                          // [RTW][EB_LD]   layer input, y1, layer output
   float *bufA = bufB + RTW * EB_LD;            // [RTW][EB_LD]   attention output, hidden slices
   float *Q_s = bufA + RTW * EB_LD;             // [RTW][QA_QLD]  q | k | v of every node
+  float *norm_s = Q_s + RTW * QA_QLD;          // [16][384]      eval-mode BN affines (from_env)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
@@ -947,12 +1048,39 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
   const int graphs = min(G, B - g0);
   const int rows = graphs * N;                 // valid rows of this workgroup's tile
   const size_t row0 = (size_t)g0 * N;
+  const float *norms = norms_in;
   for (int idx = tid; idx < RTW * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) v = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+    if (!su.from_env && r < rows) v = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
     *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = v;
     *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (su.from_env) {
+    // rollout set-up of this workgroup's graphs (one wave each), BN affines into LDS
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < su.nflags) su.notdone[tid] = 0;
+    {
+      const int parts = graphs >= 8 ? 1 : 8 / graphs;  // waves per graph
+      for (int gw = wave; gw < graphs * parts; gw += 8) {
+        const int g = gw / parts, part = gw - g * parts;
+        setup_graph_wave(su.env, w, g0 + g, lane, bufB + g * N * EB_LD, EB_LD, su.acc_loss,
+                         su.acc_logp, part, parts);
+      }
+    }
+    for (int i = tid; i < 2 * w.num_layers * 128; i += 512) {
+      const int blk = i >> 7, cc = i & 127, l = blk >> 1, second = blk & 1;
+      const vrp_encoder_layer &L = w.layer[l];
+      const float *rm = second ? L.bn2_running_mean : L.bn1_running_mean;
+      const float *rv = second ? L.bn2_running_var : L.bn1_running_var;
+      const float *wt = second ? L.bn2_weight : L.bn1_weight;
+      const float *bs = second ? L.bn2_bias : L.bn1_bias;
+      float *o = norm_s + blk * 384;
+      o[cc] = rm[cc];
+      o[128 + cc] = wt[cc] / sqrtf(rv[cc] + 1e-5f);
+      o[256 + cc] = bs[cc];
+    }
+    norms = norm_s;
   }
   __syncthreads();
   for (int l = 0; l < w.num_layers; ++l) {
@@ -963,20 +1091,46 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
     __syncthreads();
     qa8_stage_attention(Q_s, N, graphs, bufA, lane, wave);
     __syncthreads();
-    const bool lastl = l + 1 == w.num_layers;
     eb8_block_stages<RT16>(bufA, bufB, wa, L.out_proj_bias, norms + (2 * l) * 384, L.ff0_weight,
                            L.ff0_bias, L.ff2_weight, L.ff2_bias, norms + (2 * l + 1) * 384,
-                           lastl ? y + row0 * 128 : bufB, lastl ? rows : RTW, w.hidden, lane, wave,
-                           lastl ? 128 : EB_LD);
+                           bufB, RTW, w.hidden, lane, wave, EB_LD);
     __syncthreads();
+  }
+  // ---- result: coalesced 16-byte stores; the decoder's per-graph constants on the way -------
+  for (int idx = tid; idx < rows * 32; idx += 512) {
+    const int r = idx >> 5, c4 = (idx & 31) * 4;
+    *reinterpret_cast<float4 *>(y + (row0 + r) * VRP_EMB + c4) =
+        *reinterpret_cast<const float4 *>(bufB + r * EB_LD + c4);
+  }
+  if (ep.g) {
+    // graph embedding = mean over nodes (sum in node order, then divide; graph_decoder.py:75-77)
+    for (int i = tid; i < graphs * 128; i += 512) {
+      const int g = i >> 7, cc = i & 127;
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += bufB[(g * N + n) * EB_LD + cc];
+      ep.g[(size_t)(g0 + g) * VRP_EMB + cc] = s / (float)N;
+    }
+    // cvec[b][m] = e_m . mb: a wave per row, lane = two columns
+    const float2 m = reinterpret_cast<const float2 *>(ep.mb)[lane];
+    for (int r = wave; r < rows; r += 8) {
+      const float2 ev = *reinterpret_cast<const float2 *>(bufB + r * EB_LD + 2 * lane);
+      const float s = wave_sum(fmaf(ev.x, m.x, ev.y * m.y));
+      if (lane == 0) ep.cvec[row0 + r] = s;
+    }
+    for (int i = tid; i < graphs * 2 * N; i += 512) {
+      const int g = i / (2 * N), t = i - g * 2 * N;
+      ep.hist[(size_t)t * B + g0 + g] = 0ull;
+    }
+    if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
   }
 }
 
 template <int RT16>
 static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, const float *norms,
-                                float *y, int B, int N, hipStream_t st) {
+                                float *y, int B, int N, const StackSetup &su, const StackEpilogue &ep,
+                                hipStream_t st) {
   constexpr int RTW = 16 * RT16;
-  const size_t lds = (size_t)RTW * (2 * EB_LD + QA_QLD) * sizeof(float);
+  const size_t lds = ((size_t)RTW * (2 * EB_LD + QA_QLD) + 16 * 384) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_stack_kernel<RT16>),
@@ -988,9 +1142,16 @@ static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, co
   }
   const int G = RTW / N;
   hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
-                     norms, y, B, N, G);
+                     norms, y, B, N, G, su, ep);
   VRP_CHECK_LAUNCH("encoder_stack");
   return 0;
+}
+
+// small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
+static bool encoder_stack_applies(const vrp_encoder_weights *w, int train, int B, int N) {
+  static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
+  return !train && !stack_off && N <= 48 && w->hidden % 128 == 0 && w->num_layers <= 8 &&
+         (B + 48 / N - 1) / (48 / N) <= 512;
 }
 
 struct EncWs {
@@ -1057,69 +1218,7 @@ __global__ __launch_bounds__(256) void rollout_setup_kernel(
   if (blockIdx.x == 0 && (int)threadIdx.x < nflags) notdone[threadIdx.x] = 0;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= e.B) return;
-  const int N = e.N;
-  if (lane == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
-  // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
-  const uint8_t *vis = e.visited + (size_t)b * N;
-  int v0 = (lane < N) ? vis[lane] : 1;
-  int v1 = (lane + 64 < N) ? vis[lane + 64] : 1;
-  const double load = (e.kind == VRP_KIND_IRP) ? e.load[b] : 1.0;
-  const int dep = e.depot[b];
-  env_fixups_and_mask(e, b, lane, e.cur[b] == dep, v0, v1, load, e.mask);
-  // depot flag per node: VRP = the mask column just written (QUIRK graph_vrp_agent.py:67),
-  // IRP = the is_depot column (graph_irp_agent.py:77-79), TSP = none.  For VRP the mask
-  // equals the visited flags (no capacity overlay).
-  const unsigned long long d0 = __ballot(e.kind == VRP_KIND_VRP ? (lane < N && v0) : lane == dep);
-  const unsigned long long d1 =
-      __ballot(e.kind == VRP_KIND_VRP ? (lane + 64 < N && v1) : lane + 64 == dep);
-  // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
-  float fx[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = lane + 64 * i;
-    const size_t r = (size_t)b * N + (n < N ? n : 0);
-    fx[i][0] = (float)e.pos[2 * r];
-    fx[i][1] = (float)e.pos[2 * r + 1];
-    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
-  }
-  // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
-  float wn[2][3], bnv[2], wd[2][2], bdv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = lane + 64 * j;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
-    bnv[j] = w.node_embed_bias[c];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
-    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
-  }
-  const bool has_depot = w.depot_embed_weight != nullptr && e.kind != VRP_KIND_TSP;
-  for (int n = 0; n < N; ++n) {
-    const int src = n & 63;
-    float x[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[0][d]), src));
-      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[1][d]), src));
-      x[d] = n < 64 ? lo : hi;
-    }
-    const bool isdep = has_depot && (((n < 64 ? d0 : d1) >> src) & 1ull);
-    float *orow = out + ((size_t)b * N + n) * VRP_EMB;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float v;
-      if (isdep) {
-        v = bdv[j];
-        for (int d = 0; d < w.depot_dim; ++d) v = fmaf(x[d], wd[j][d], v);
-      } else {
-        v = bnv[j];
-        for (int d = 0; d < w.node_dim; ++d) v = fmaf(x[d], wn[j][d], v);
-      }
-      orow[lane + 64 * j] = v;
-    }
-  }
+  setup_graph_wave(e, w, b, lane, out + (size_t)b * e.N * VRP_EMB, VRP_EMB, acc_loss, acc_logp);
 }
 
 static int encoder_check(const vrp_encoder_weights *w, int B, int N) {
@@ -1159,13 +1258,25 @@ extern "C" int vrp_encoder_forward(const vrp_encoder_weights *w, int train, int 
 // one launch (rollout_setup_kernel), then the attention layers.
 int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const vrp_env *env,
                                  float *emb, void *workspace, float *acc_loss, float *acc_logp,
-                                 int32_t *notdone, int nflags, hipStream_t st) {
+                                 int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
+                                 float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
+                                 int *decoder_constants_done, hipStream_t st) {
   const int B = env->B, N = env->N;
   if (int r = encoder_check(w, B, N)) return r;
   VRP_REQUIRE(env->kind == VRP_KIND_TSP || w->depot_embed_weight,
               "encoder: VRP/IRP rollout needs depot_embed");
   VRP_REQUIRE(nflags <= 256, "rollout: more than 255 steps");
   EncWs ws = carve_encoder(workspace, B, N, w->hidden);
+  *decoder_constants_done = 0;
+  if (encoder_stack_applies(w, train, B, N)) {
+    // one launch: set-up, all layers, and the decoder's per-graph constants
+    StackSetup su;
+    su.env = *env; su.acc_loss = acc_loss; su.acc_logp = acc_logp; su.notdone = notdone;
+    su.nflags = nflags; su.from_env = 1;
+    StackEpilogue ep = {dec_mb, dec_g, dec_cvec, dec_hist, dec_err};
+    *decoder_constants_done = dec_g != nullptr;
+    return launch_encoder_stack<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
+  }
   float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;
   const int env_blocks = (B + 3) / 4;
   hipLaunchKernelGGL(rollout_setup_kernel, dim3(env_blocks + 2 * w->num_layers), dim3(256), 0, st,
@@ -1179,10 +1290,10 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
                           float *emb, const EncWs &ws, hipStream_t st) {
   const int R = B * N;
   float *nxt = nullptr;
-  static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
-  if (!train && !stack_off && N <= 48 && w->hidden % 128 == 0 && (B + 48 / N - 1) / (48 / N) <= 512) {
-    // small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
-    return launch_encoder_stack<3>(w, cur, ws.norm, emb, B, N, st);
+  if (encoder_stack_applies(w, train, B, N)) {
+    StackSetup su = {};
+    StackEpilogue ep = {};
+    return launch_encoder_stack<3>(w, cur, ws.norm, emb, B, N, su, ep, st);
   }
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
