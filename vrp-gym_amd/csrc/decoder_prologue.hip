@@ -510,17 +510,36 @@ __global__ __launch_bounds__(256) void score_base_kernel(int B, int N, const flo
     }
   }
   const int fb = first[b];
+  // every load of the graph (embedding rows as B fragments, SG, the first node's SL row) is
+  // issued before the first MFMA: one wave per graph has nothing else to hide a round trip
+  float4 ev[NTMAX][8];
+  float sgv[NTMAX][4], slv[NTMAX][4];
+#pragma unroll
+  for (int nt = 0; nt < NTMAX; ++nt) {
+    const int n = 16 * nt + j16;
+    const bool on = nt < NT && n < N;
+    const float4 *src = reinterpret_cast<const float4 *>(
+        emb + ((size_t)b * N + (on ? n : 0)) * VRP_EMB + koff);
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) ev[nt][k4] = on ? src[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int h = 4 * q + r4;
+      const bool ok = on && q < 2;
+      const size_t o = ((size_t)b * 8 + (ok ? h : 0)) * N + (ok ? n : 0);
+      sgv[nt][r4] = ok ? SG[o] : 0.f;
+      slv[nt][r4] = ok ? SL[(((size_t)b * N + fb) * 8 + h) * N + n] : 0.f;
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NTMAX; ++nt) {
     if (nt >= NT) break;
     const int n = 16 * nt + j16;
-    const float4 *src = reinterpret_cast<const float4 *>(
-        emb + ((size_t)b * N + (n < N ? n : 0)) * VRP_EMB + koff);
-    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N) v = src[k4];
+      const float4 v = ev[nt][k4];
+      f32x4 &d = (k4 & 1) ? d1 : d0;
       d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4], v.x, d, 0, 0, 0);
       d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4 + 1], v.y, d, 0, 0, 0);
       d = __builtin_amdgcn_mfma_f32_16x16x4f32(af[4 * k4 + 2], v.z, d, 0, 0, 0);
@@ -532,9 +551,9 @@ __global__ __launch_bounds__(256) void score_base_kernel(int B, int N, const flo
       for (int r4 = 0; r4 < 4; ++r4) {
         const int h = 4 * q + r4;
         const size_t o = ((size_t)b * 8 + h) * N + n;
-        const float v = SG[o] + d[r4];
+        const float v = sgv[nt][r4] + (d0[r4] + d1[r4]);
         base[o] = v;
-        curs[o] = SL[(((size_t)b * N + fb) * 8 + h) * N + n] + v;
+        curs[o] = slv[nt][r4] + v;
       }
     }
   }
