@@ -54,6 +54,26 @@ __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, VRP_DPP(v, v, 0x143, 0xC));
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Eight wave-wide sums at once: the DPP steps of the eight values are interleaved, so that
+// every DPP read is separated from the VALU write of its source by the other seven chains
+// (no s_nop wait states); each value goes through exactly the tree of wave_sum.
+__device__ __forceinline__ void wave_sum8(float (&v)[8]) {
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x111, 0xF);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x112, 0xF);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x114, 0xF);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x118, 0xF);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x142, 0xA);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) v[h] += VRP_DPP(0.f, v[h], 0x143, 0xC);
+#pragma unroll
+  for (int h = 0; h < 8; ++h)
+    v[h] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[h]), 63));
+}
 // sum over the 8 lanes that share lane>>3 (quad swaps + half-row mirror); every lane of
 // the group ends with the group total
 __device__ __forceinline__ float group8_sum(float v) {

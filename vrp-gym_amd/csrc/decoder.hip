@@ -326,27 +326,31 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
         mx = fmaxf(mx, v);
       }
     const float M = wave_max(mx);
+    float e[NPL][8], sum[8];
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
-      float e[NPL], es = 0.f;
+      sum[h] = 0.f;
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? exp_nonpos(s[i][h] - M) : 0.f; es += e[i]; }
-      float sum = wave_sum(es);
-      if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+      for (int i = 0; i < NPL; ++i) { e[i][h] = inN[i] ? exp_nonpos(s[i][h] - M) : 0.f; sum[h] += e[i][h]; }
+    }
+    wave_sum8(sum);  // eight interleaved reductions
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      if (!(sum[h] > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
         float hm = -INFINITY;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) hm = fmaxf(hm, s[i][h]);
         hm = wave_max(hm);
-        es = 0.f;
+        float es = 0.f;
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) { e[i] = inN[i] ? exp_nonpos(s[i][h] - hm) : 0.f; es += e[i]; }
-        sum = wave_sum(es);
+        for (int i = 0; i < NPL; ++i) { e[i][h] = inN[i] ? exp_nonpos(s[i][h] - hm) : 0.f; es += e[i][h]; }
+        sum[h] = wave_sum(es);
       }
-      float r = __builtin_amdgcn_rcpf(sum);
-      r = fmaf(fmaf(-sum, r, 1.f), r, r);
+      float r = __builtin_amdgcn_rcpf(sum[h]);
+      r = fmaf(fmaf(-sum[h], r, 1.f), r, r);
 #pragma unroll
       for (int i = 0; i < NPL; ++i)
-        if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i] * r;
+        if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i][h] * r;
     }
   }
   __syncthreads();

@@ -149,18 +149,20 @@ __global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams 
         mx = fmaxf(mx, v);
       }
       const float M = wave_max(mx);
+      float e[8], sum[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) { e[h] = inN ? exp_nonpos(s[h] - M) : 0.f; sum[h] = e[h]; }
+      wave_sum8(sum);  // eight interleaved reductions
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        float e = inN ? exp_nonpos(s[h] - M) : 0.f;
-        float sum = wave_sum(e);
-        if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+        if (!(sum[h] > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
           const float hm = wave_max(s[h]);
-          e = inN ? exp_nonpos(s[h] - hm) : 0.f;
-          sum = wave_sum(e);
+          e[h] = inN ? exp_nonpos(s[h] - hm) : 0.f;
+          sum[h] = wave_sum(e[h]);
         }
-        float r = __builtin_amdgcn_rcpf(sum);
-        r = fmaf(fmaf(-sum, r, 1.f), r, r);
-        if (inN) a_s[h * N + lane] = e * r;
+        float r = __builtin_amdgcn_rcpf(sum[h]);
+        r = fmaf(fmaf(-sum[h], r, 1.f), r, r);
+        if (inN) a_s[h * N + lane] = e[h] * r;
       }
     }
     __syncthreads();
