@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
   const float *eb = emb + (size_t)b * N * VRP_EMB;
   if (tid < VRP_EMB) {
     float s = 0.f;
+#pragma unroll 8  // eight rows in flight; the adds stay in node order
     for (int n = 0; n < N; ++n) s += eb[(size_t)n * VRP_EMB + tid];
     g[(size_t)b * VRP_EMB + tid] = s / (float)N;
   }
