@@ -30,6 +30,17 @@ void vrp_set_error(const char *fmt, ...);
 
 static inline size_t vrp_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
+// error carried into a first-order correction; ~1 ulp, no range handling needed
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147180559945f, e);
+}
+
 // ---- wave-level reductions (all 64 lanes participate) -----------------------
 // DPP row shifts + row broadcasts (no LDS crossbar): after the six steps lane 63 holds
 // the reduction of the whole wave; readlane(63) hands it back as a wave-uniform value.

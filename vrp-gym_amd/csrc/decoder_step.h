@@ -50,16 +50,6 @@ __device__ __forceinline__ float rt_dot(float acc, const float4 (&r)[RT_U], cons
   }
   return acc;
 }
-// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
-// error carried into a first-order correction; ~1 ulp, no range handling needed
-__device__ __forceinline__ float exp_nonpos(float x) {
-  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
-  const float t = x * l2e_hi;
-  float r = fmaf(x, l2e_hi, -t);
-  r = fmaf(x, l2e_lo, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147180559945f, e);
-}
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const long long x = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)x, l);

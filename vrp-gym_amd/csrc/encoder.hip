@@ -816,39 +816,107 @@ __device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_enc
 // block stages, one 48-column block of in_proj and one attention head, so that while one wave
 // of a SIMD writes its results to LDS or waits at a barrier the other one keeps the matrix
 // pipe busy (same arithmetic and summation order as the 4-wave kernels above).
-__device__ __forceinline__ void eb8_load_w(float (&w)[32], const float *w0) {
-#pragma unroll
-  for (int s = 0; s < 32; s += 4) {
-    const float4 t0 = *reinterpret_cast<const float4 *>(w0 + s);
-    w[s] = t0.x; w[s + 1] = t0.y; w[s + 2] = t0.z; w[s + 3] = t0.w;
-  }
+// The A fragments of k-step s + 1 are read from LDS before the MFMAs of k-step s are issued
+// (the scheduling fences keep the compiler from sinking the reads next to their use, where
+// every group of MFMAs would start with an LDS round trip).  Per accumulator the k order is
+// unchanged.
+// `pre(s)` runs once per k-step ahead of its MFMAs: the callers use it to request the NEXT
+// stage's weight fragments one 16-byte load at a time.  (Eight waves issuing all their loads
+// at a stage boundary queue up behind the vector memory pipe -- a fragment load touches 64
+// cache lines -- and no wave issues an MFMA until its own loads are accepted.)
+// How the 128-long inner dimension of the 8-wave kernels is spread over the four 16-lane
+// groups q and the eight k-steps S (element e of the lane's float4):
+//   KL 0: k = 32 q + 4 S + e          a weight-fragment load touches 64 cache lines
+//   KL 2: k = 64 (S / 4) + 32 (q / 2) + 8 (S % 4) + 4 (q % 2) + e
+//         32 lines per load (two lanes of a row share a 32-byte sector pair), and the lane
+//         pairs (l, l + 32) that one ds_read_b128 pass serves are 32 banks apart
+// The vector memory pipe looks lines up one by one, so for kernels that re-read their weights
+// every stage (the stack kernel) the line count of a fragment load is what the loads cost:
+// 172 -> 156 us at 512 x 20.  The large-batch kernel below loads its fragments once per
+// workgroup and keeps KL 0 (408 vs 415 us per layer at 8192 x 40).
+#ifndef VRP_KLAYOUT
+#define VRP_KLAYOUT 2
+#endif
+template <int KL = VRP_KLAYOUT>
+__device__ __forceinline__ constexpr int kq8(int q) {
+  return KL == 0 ? 32 * q : KL == 1 ? 4 * q : 32 * (q >> 1) + 4 * (q & 1);
 }
-template <int RT16>
+template <int KL = VRP_KLAYOUT>
+__device__ __forceinline__ constexpr int ks8(int s) {   // s = 4 S: register index of the k-step
+  return KL == 0 ? s : KL == 1 ? 4 * s : 64 * (s >> 4) + 2 * (s & 15);
+}
+struct NoPre { __device__ __forceinline__ void operator()(int) const {} };
+__device__ __forceinline__ void load_w4(float *w, const float *w0, int s) {
+  const float4 t = *reinterpret_cast<const float4 *>(w0 + ks8(s));
+  w[s] = t.x; w[s + 1] = t.y; w[s + 2] = t.z; w[s + 3] = t.w;
+}
+template <int RT16, typename Pre = NoPre>
 __device__ __forceinline__ void eb8_mma(f32x4v (&acc)[RT16], const float *abuf, const float (&w)[32],
-                                        int lane) {
+                                        int lane, Pre pre = Pre()) {
   const int i16 = lane & 15, q = lane >> 4;
+  const float *ap = abuf + i16 * EB_LD + kq8(q);
+  float4 a[2][RT16];
+#pragma unroll
+  for (int rt = 0; rt < RT16; ++rt) a[0][rt] = *reinterpret_cast<const float4 *>(ap + rt * 16 * EB_LD);
 #pragma unroll
   for (int s = 0; s < 32; s += 4) {
-    float4 a[RT16];
+    const int cur = (s >> 2) & 1;
+    if (s + 4 < 32) {
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+        a[cur ^ 1][rt] = *reinterpret_cast<const float4 *>(ap + rt * 16 * EB_LD + ks8(s + 4));
+    }
+    pre(s);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt)
-      a[rt] = *reinterpret_cast<const float4 *>(abuf + (rt * 16 + i16) * EB_LD + 32 * q + s);
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rt].x, w[s], acc[rt], 0, 0, 0);
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) {
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[s], acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[s + 1], acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[s + 2], acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[s + 3], acc[rt], 0, 0, 0);
-    }
+    for (int rt = 0; rt < RT16; ++rt)
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rt].y, w[s + 1], acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rt].z, w[s + 2], acc[rt], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][rt].w, w[s + 3], acc[rt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
+// Developer aid (make EXTRA=-DVRP_STACK_TRACE): shader-clock timestamps of every wave at the
+// phase boundaries of the stack kernel, printed for two workgroups after each launch.
+#ifdef VRP_STACK_TRACE
+#define ST_SLOTS 96
+__device__ unsigned long long g_stack_trace[512 * 8 * ST_SLOTS];
+#define ST_MARK(i)                                                                      \
+  if (lane == 0) g_stack_trace[((size_t)blockIdx.x * 8 + wave) * ST_SLOTS + (i)] =      \
+      ((i) == 0 || (i) == ST_SLOTS - 1) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime()
+#else
+#define ST_MARK(i)
+#endif
+
+// one half of the fragments (k-steps [16 half, 16 half + 16) of every column tile)
+__device__ __forceinline__ void qa8_load_w_half(float (&w)[3][32], const float *__restrict__ Win,
+                                                int lane, int wave, int half) {
+  const int i16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const float *wr = Win + (size_t)(wave * 48 + ct * 16 + i16) * VRP_EMB + kq8(q);
+#pragma unroll
+    for (int s = 16 * half; s < 16 * half + 16; s += 4) {
+      const float4 t = *reinterpret_cast<const float4 *>(wr + ks8(s));
+      w[ct][s] = t.x; w[ct][s + 1] = t.y; w[ct][s + 2] = t.z; w[ct][s + 3] = t.w;
+    }
+  }
+}
 template <int RT16>
 __device__ __forceinline__ void eb8_block_stages(
-    float *bufA, float *bufB, float (&wa)[32], const float *__restrict__ bo,
+    float *bufA, float *bufA2, float *bufB, float (&wa)[32], const float *__restrict__ bo,
     const float *__restrict__ norm1, const float *__restrict__ W1, const float *__restrict__ b1,
     const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ norm2,
-    float *y_tile, int valid_rows, int hidden, int lane, int wave, int y_ld) {
+    float *y_tile, int valid_rows, int hidden, int lane, int wave, int y_ld,
+    float (&win)[3][32], const float *Win_next, int st_base = 0) {
   const int i16 = lane & 15, q = lane >> 4;
   const int c = wave * 16 + i16;  // this lane's weight row / D column
   float wb[32];
@@ -858,10 +926,13 @@ __device__ __forceinline__ void eb8_block_stages(
 #pragma unroll
     for (int r = 0; r < 4; ++r) { acc[rt][r] = 0.f; gacc[rt][r] = 0.f; }
   // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
-  eb8_load_w(wb, W1 + (size_t)c * 128 + 32 * q);
-  eb8_mma<RT16>(acc, bufA, wa, lane);
+  const float bb_o = bo[c], mean1 = norm1[c], mult1 = norm1[128 + c], beta1 = norm1[256 + c];
   {
-    const float bb = bo[c], mean = norm1[c], mult = norm1[128 + c], beta = norm1[256 + c];
+    const float *w1c = W1 + (size_t)c * 128 + kq8(q);   // W1 slice 0 for the first way up
+    eb8_mma<RT16>(acc, bufA, wa, lane, [&](int s) { load_w4(wb, w1c, s); });
+  }
+  {
+    const float bb = bb_o, mean = mean1, mult = mult1, beta = beta1;
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
@@ -870,32 +941,65 @@ __device__ __forceinline__ void eb8_block_stages(
         *p = (acc[rt][r] + bb + *p - mean) * mult + beta;      // x -> y1 in place
       }
   }
+  ST_MARK(st_base + 5);
   __syncthreads();
+  ST_MARK(st_base + 6);
   // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T --------------
+  // Slice ch goes up (y1 -> hidden slice in LDS) and comes down (slice -> g, in registers).
+  // The slices alternate between two LDS buffers, so the way down of slice ch and the way up
+  // of slice ch + 1 run back to back without a barrier between them: ONE barrier per slice,
+  // and a wave that finishes a stage early finds its next 96 MFMAs ready instead of a barrier
+  // (the SIMD's matrix pipe serves its two waves oldest first: whatever one wave does not
+  // issue, the other one fills in).
   const int nchunk = hidden / 128;
-  for (int ch = 0; ch < nchunk; ++ch) {
+  auto slice_up = [&](int ch, float *hb) {
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[rt][r] = 0.f;
-    eb8_load_w(wa, W2 + (size_t)c * hidden + ch * 128 + 32 * q);
-    eb8_mma<RT16>(acc, bufB, wb, lane);
-    {
-      const float bb = b1[ch * 128 + c];
+    const float bb = b1[ch * 128 + c];
+    const float *w2c = W2 + (size_t)c * hidden + ch * 128 + kq8(q);   // needed on the way down
+    eb8_mma<RT16>(acc, bufB, wb, lane, [&](int s) { load_w4(wa, w2c, s); });
 #pragma unroll
-      for (int rt = 0; rt < RT16; ++rt)
+    for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          bufA[(rt * 16 + 4 * q + r) * EB_LD + c] = fmaxf(acc[rt][r] + bb, 0.f);
-    }
+      for (int r = 0; r < 4; ++r)
+        hb[(rt * 16 + 4 * q + r) * EB_LD + c] = fmaxf(acc[rt][r] + bb, 0.f);
+  };
+  slice_up(0, bufA);
+  ST_MARK(st_base + 7);
+  __syncthreads();
+  ST_MARK(st_base + 8);
+  for (int ch = 0; ch + 1 < nchunk; ++ch) {
+    float *hcur = (ch & 1) ? bufA2 : bufA, *hnext = (ch & 1) ? bufA : bufA2;
+    const float *w1c = W1 + (size_t)((ch + 1) * 128 + c) * 128 + kq8(q);
+    eb8_mma<RT16>(gacc, hcur, wa, lane, [&](int s) { load_w4(wb, w1c, s); });
+    ST_MARK(st_base + 9 + 3 * ch);
+    slice_up(ch + 1, hnext);
+    ST_MARK(st_base + 10 + 3 * ch);
     __syncthreads();
-    if (ch + 1 < nchunk) eb8_load_w(wb, W1 + (size_t)((ch + 1) * 128 + c) * 128 + 32 * q);
-    eb8_mma<RT16>(gacc, bufA, wa, lane);
-    __syncthreads();
+    ST_MARK(st_base + 11 + 3 * ch);
   }
+  // way down of the last slice: the first half (k-steps 0..15) of the next layer's in_proj
+  // fragments is fetched behind it; the other half follows at the start of that layer, behind
+  // the first half's MFMAs (all 96 registers at once do not fit beside this stage)
+  const float bb_2 = b2[c], mean2 = norm2[c], mult2 = norm2[128 + c], beta2 = norm2[256 + c];
+  {
+    const float *wn = Win_next ? Win_next + (size_t)(wave * 48 + i16) * VRP_EMB + kq8(q) : nullptr;
+    eb8_mma<RT16>(gacc, ((nchunk - 1) & 1) ? bufA2 : bufA, wa, lane, [&](int s) {
+      // twelve loads over the first six k-steps: column tile ct = s / 8, k-steps (s % 8) * 2 ..
+      if (wn && s < 24) {
+        const int ct = s / 8, k0 = (s % 8) * 2;
+        load_w4(win[ct], wn + (size_t)ct * 16 * VRP_EMB, k0);
+        load_w4(win[ct], wn + (size_t)ct * 16 * VRP_EMB, k0 + 4);
+      }
+    });
+  }
+  ST_MARK(st_base + 21);
+  // (no barrier: the rest touches only this thread's own elements of bufB)
   // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
   {
-    const float bb = b2[c], mean = norm2[c], mult = norm2[128 + c], beta = norm2[256 + c];
+    const float bb = bb_2, mean = mean2, mult = mult2, beta = beta2;
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt)
 #pragma unroll
@@ -910,106 +1014,229 @@ __device__ __forceinline__ void eb8_block_stages(
 }
 
 // in_proj of the tile: wave w owns column block w (48 columns = q, k or v of two heads)
-template <int NTMAX>
-__device__ __forceinline__ void qa8_stage_project(const float *X_s, float *Q_s,
-                                                  const float *__restrict__ Win,
-                                                  const float *__restrict__ bin, int lane, int wave) {
+// ALIAS: Q_s overlays X_s (large tiles): every wave finishes reading X_s (workgroup barrier)
+// before any projection result is written.
+template <int KL = VRP_KLAYOUT>
+__device__ __forceinline__ void qa8_load_w(float (&w)[3][32], const float *__restrict__ Win,
+                                           int lane, int wave) {
   const int i16 = lane & 15, q = lane >> 4;
-  float w[3][32];
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
-    const float *wr = Win + (size_t)(wave * 48 + ct * 16 + i16) * VRP_EMB + 32 * q;
+    const float *wr = Win + (size_t)(wave * 48 + ct * 16 + i16) * VRP_EMB + kq8<KL>(q);
 #pragma unroll
     for (int s = 0; s < 32; s += 4) {
-      const float4 t = *reinterpret_cast<const float4 *>(wr + s);
+      const float4 t = *reinterpret_cast<const float4 *>(wr + ks8<KL>(s));
       w[ct][s] = t.x; w[ct][s + 1] = t.y; w[ct][s + 2] = t.z; w[ct][s + 3] = t.w;
     }
   }
+}
+template <int NTMAX, bool ALIAS = false, typename Pre = NoPre, int KL = VRP_KLAYOUT>
+__device__ __forceinline__ void qa8_project(const float *X_s, float *Q_s, const float (&w)[3][32],
+                                            const float *__restrict__ bin, int lane, int wave,
+                                            Pre pre = Pre()) {
+  const int i16 = lane & 15, q = lane >> 4;
   f32x4q acc[NTMAX][3];
 #pragma unroll
   for (int rt = 0; rt < NTMAX; ++rt)
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) acc[rt][ct] = {0.f, 0.f, 0.f, 0.f};
+  float bb[3];  // fetched ahead of the MFMAs, not behind them
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) bb[ct] = bin[wave * 48 + ct * 16 + i16];
+  const float *xp = X_s + i16 * QA_XLD + kq8<KL>(q);
+  float4 a[2][NTMAX];
+#pragma unroll
+  for (int rt = 0; rt < NTMAX; ++rt) a[0][rt] = *reinterpret_cast<const float4 *>(xp + rt * 16 * QA_XLD);
 #pragma unroll
   for (int s = 0; s < 32; s += 4) {
-    float4 a[NTMAX];
+    const int cur = (s >> 2) & 1;
+    if (s + 4 < 32) {
 #pragma unroll
-    for (int rt = 0; rt < NTMAX; ++rt)
-      a[rt] = *reinterpret_cast<const float4 *>(X_s + (rt * 16 + i16) * QA_XLD + 32 * q + s);
+      for (int rt = 0; rt < NTMAX; ++rt)
+        a[cur ^ 1][rt] = *reinterpret_cast<const float4 *>(xp + rt * 16 * QA_XLD + ks8<KL>(s + 4));
+    }
+    pre(s);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int rt = 0; rt < NTMAX; ++rt)
+    for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w[ct][s], acc[rt][ct], 0, 0, 0);
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w[ct][s + 1], acc[rt][ct], 0, 0, 0);
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w[ct][s + 2], acc[rt][ct], 0, 0, 0);
-        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w[ct][s + 3], acc[rt][ct], 0, 0, 0);
+      for (int rt = 0; rt < NTMAX; ++rt) {
+        const float av = k4 == 0 ? a[cur][rt].x : k4 == 1 ? a[cur][rt].y : k4 == 2 ? a[cur][rt].z : a[cur][rt].w;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[ct][s + k4], acc[rt][ct], 0, 0, 0);
       }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (ALIAS) __syncthreads();
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
     const int col = wave * 48 + ct * 16 + i16;
-    const float bb = bin[col];
 #pragma unroll
     for (int rt = 0; rt < NTMAX; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)  // D: row = 4*(lane>>4) + r, col = lane & 15
-        Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb;
+        Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb[ct];
   }
 }
 
-// attention of the tile's graphs (graph_encoder.py:170-172,196): wave = head, lane = query;
-// N <= 32: two graphs at once, one per 32-lane half
-__device__ __forceinline__ void qa8_stage_attention(const float *Q_s, int N, int graphs, float *out,
-                                                    int lane, int wave) {
-  const int h = wave;
-  const int per = (N <= 32) ? 2 : 1;
-  for (int gb = 0; gb < graphs; gb += per) {
-    const int g = gb + ((N <= 32) ? (lane >> 5) : 0);
-    const int i = (N <= 32) ? (lane & 31) : lane;
-    if (i < N && g < graphs) {
-      const float *Qg = Q_s + (size_t)g * N * QA_QLD;
-      float qv[16];
+// Attention of the tile's graphs on the matrix cores (graph_encoder.py:170-172,196): wave = head,
+// one graph at a time.  With q|k|v in LDS (Q_s) both products run as v_mfma_f32_16x16x4_f32:
+//   S^T tile (tn, tm) = K(tn) Q(tm)^T: operands are one ds_read_b128 per 16-row tile (k = 4q + s,
+//                the head's 16 columns split over the four lane groups); D[n][m] puts query row
+//                m on the lane and its key columns n = 16tn + 4q + reg in registers -- so the
+//                softmax over n is in-lane plus two cross-group steps, and
+//   O^T (16 x m) = V^T P^T: P^T is ALREADY the B operand (k = key n = 16tn + 4q + reg, the
+//                accumulator layout of the first product), V comes from LDS one float per MFMA.
+// The result D[d][m] gives a lane four consecutive head columns of its query row: one 16-byte
+// store.  NT = row tiles per graph (N <= 16 NT).
+template <int NT>
+__device__ __forceinline__ void qa8_stage_attention_mfma(const float *Q_s, int N, int graphs,
+                                                         int max_row, float *out, int lane,
+                                                         int wave, int out_ld) {
+  const int h = wave, i16 = lane & 15, q = lane >> 4;
+  for (int g = 0; g < graphs; ++g) {
+    const int r0 = g * N;
+    float4 qf[NT], kf[NT];
 #pragma unroll
-      for (int d = 0; d < 16; d += 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(Qg + i * QA_QLD + h * 16 + d);
-        qv[d] = t.x * 0.25f; qv[d + 1] = t.y * 0.25f; qv[d + 2] = t.z * 0.25f; qv[d + 3] = t.w * 0.25f;
+    for (int t = 0; t < NT; ++t) {
+      const int row = min(r0 + 16 * t + i16, max_row);
+      const float4 a = *reinterpret_cast<const float4 *>(Q_s + row * QA_QLD + h * 16 + 4 * q);
+      qf[t] = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
+      kf[t] = *reinterpret_cast<const float4 *>(Q_s + row * QA_QLD + 128 + h * 16 + 4 * q);
+    }
+    float vv[NT][4];  // V[16tn + 4q + r4][d = i16]: the A operand of the second product
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        vv[tn][r4] = Q_s[min(r0 + 16 * tn + 4 * q + r4, max_row) * QA_QLD + 256 + h * 16 + i16];
+    f32x4v st[NT][NT];  // st[tn][tm][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < NT; ++tm) {
+        f32x4v d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].x, qf[tm].x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].y, qf[tm].y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].z, qf[tm].z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].w, qf[tm].w, d, 0, 0, 0);
+        st[tn][tm] = d;
       }
-      float m = -INFINITY, l = 0.f, o[16];
 #pragma unroll
-      for (int d = 0; d < 16; ++d) o[d] = 0.f;
-      for (int j = 0; j < N; ++j) {
-        float kk[16], vv[16];
+    for (int tm = 0; tm < NT; ++tm) {
+      // softmax over the keys of query row m = 16tm + i16 (graph_encoder.py:172: no mask)
+      float mx = -INFINITY;
 #pragma unroll
-        for (int d = 0; d < 16; d += 4) {
-          const float4 tk = *reinterpret_cast<const float4 *>(Qg + j * QA_QLD + 128 + h * 16 + d);
-          const float4 tv = *reinterpret_cast<const float4 *>(Qg + j * QA_QLD + 256 + h * 16 + d);
-          kk[d] = tk.x; kk[d + 1] = tk.y; kk[d + 2] = tk.z; kk[d + 3] = tk.w;
-          vv[d] = tv.x; vv[d + 1] = tv.y; vv[d + 2] = tv.z; vv[d + 3] = tv.w;
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          if (16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[tn][tm][r4]);
         }
-        float sc = 0.f;
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) sc = fmaf(qv[d], kk[d], sc);
-        if (sc > m) {
-          const float corr = expf(m - sc);
-          l *= corr;
+      for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-          for (int d = 0; d < 16; ++d) o[d] *= corr;
-          m = sc;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float pw = (16 * tn + 4 * q + r4 < N) ? exp_nonpos(st[tn][tm][r4] - mx) : 0.f;
+          st[tn][tm][r4] = pw;
+          sum += pw;
         }
-        const float pw = expf(sc - m);
-        l += pw;
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      f32x4v o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = fmaf(pw, vv[d], o[d]);
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[tn][r4], st[tn][tm][r4], o, 0, 0, 0);
+      // D[d = 4q + r4][m = i16]
+      const int m = 16 * tm + i16;
+      if (m < N) {
+        const float inv = 1.f / sum;
+        *reinterpret_cast<float4 *>(out + (size_t)(r0 + m) * out_ld + h * 16 + 4 * q) =
+            make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
       }
-      const float inv = 1.f / l;
-      float *dst = out + (size_t)(g * N + i) * EB_LD + h * 16;
-#pragma unroll
-      for (int d = 0; d < 16; d += 4)
-        *reinterpret_cast<float4 *>(dst + d) =
-            make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
     }
   }
+}
+
+// ---- in_proj + attention of whole graphs in one launch, LARGE batches (eval mode) ----------
+// The projection GEMM wrote q|k|v (B*N x 384 fp32: 503 MB at 8192 x 40) only for the attention
+// kernel to read it back; here a workgroup takes G = 80 / N whole graphs (N = 40: two graphs =
+// five 16-row MFMA tiles, no padded rows) from the layer input to the attention output with
+// q|k|v in LDS: 8 waves, wave w projects column block w (48 columns) and then runs head w.
+// X_s and Q_s share the LDS (124 KB), so one workgroup per CU: the workgroups are persistent
+// (grid = CUs), keep their weight fragments in registers across tiles and fetch the next
+// tile's rows into registers while the current tile is in the matrix cores.
+template <int RT16>
+__global__ __launch_bounds__(512) void encoder_qkv_attn8_kernel(const float *__restrict__ x,
+                                                                 const float *__restrict__ Win,
+                                                                 const float *__restrict__ bin,
+                                                                 float *__restrict__ att, int B,
+                                                                 int N, int G, int ntiles) {
+  constexpr int RTW = 16 * RT16, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Q_s = smem;   // [RTW][QA_QLD]; the first RTW * QA_XLD floats hold the input tile first
+  float *X_s = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float w[3][32];
+  qa8_load_w<0>(w, Win, lane, wave);
+  float4 pf[PF];
+  auto fetch = [&](int tile) {
+    const int g0 = tile * G;
+    const int rows = min(G, B - g0) * N;
+    const size_t row0 = (size_t)g0 * N;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int g0 = tile * G;
+    const int graphs = min(G, B - g0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = pf[u];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    qa8_project<RT16, true, NoPre, 0>(X_s, Q_s, w, bin, lane, wave);
+    __syncthreads();
+    float *o = att + (size_t)g0 * N * VRP_EMB;
+    if (N <= 32) qa8_stage_attention_mfma<2>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    else if (N <= 48) qa8_stage_attention_mfma<3>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    else qa8_stage_attention_mfma<4>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    __syncthreads();   // everybody done with Q_s before the next tile lands in X_s
+  }
+}
+
+static int launch_qkv_attn8(const float *x, const float *Win, const float *bin, float *att, int B,
+                            int N, hipStream_t st) {
+  constexpr int RT16 = 5, RTW = 80;
+  const size_t lds = (size_t)RTW * QA_QLD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_qkv_attn8_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("qkv_attn8: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int G = RTW / N, ntiles = (B + G - 1) / G;
+  hipLaunchKernelGGL(encoder_qkv_attn8_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512),
+                     lds, st, x, Win, bin, att, B, N, G, ntiles);
+  VRP_CHECK_LAUNCH("encoder_qkv_attn8");
+  return 0;
 }
 
 // What the decoder prologue needs from the finished embeddings (graph_decoder.py:75-77 and the
@@ -1049,6 +1276,8 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
   const int rows = graphs * N;                 // valid rows of this workgroup's tile
   const size_t row0 = (size_t)g0 * N;
   const float *norms = norms_in;
+  ST_MARK(0);
+  ST_MARK(1);
   for (int idx = tid; idx < RTW * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1082,20 +1311,49 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
     }
     norms = norm_s;
   }
+  float win[3][32];  // in_proj fragments of the coming layer
+  qa8_load_w_half(win, w.layer[0].in_proj_weight, lane, wave, 0);
+  ST_MARK(2);
   __syncthreads();
   for (int l = 0; l < w.num_layers; ++l) {
     const vrp_encoder_layer &L = w.layer[l];
+    ST_MARK(4 + 24 * l);
     float wa[32];  // Wo fragment: in flight while in_proj and the attention run
-    eb8_load_w(wa, L.out_proj_weight + (size_t)c * 128 + 32 * q);
-    qa8_stage_project<RT16>(bufB, Q_s, L.in_proj_weight, L.in_proj_bias, lane, wave);
+    {
+      // behind the MFMAs of k-steps 0..15 (fragments already here): the other half of the
+      // in_proj fragments (k-steps 16..31, three column tiles), then the Wo fragment
+      const float *wi = L.in_proj_weight + (size_t)(wave * 48 + i16) * VRP_EMB + kq8(q);
+      const float *wo = L.out_proj_weight + (size_t)c * 128 + kq8(q);
+      qa8_project<RT16, false>(bufB, Q_s, win, L.in_proj_bias, lane, wave, [&](int s) {
+        if (s < 12) {
+          const int ct = s / 4;
+#pragma unroll
+          for (int k = 16; k < 32; k += 4) load_w4(win[ct], wi + (size_t)ct * 16 * VRP_EMB, k);
+        } else if (s < 28) {
+          load_w4(wa, wo, 2 * (s - 12));
+          load_w4(wa, wo, 2 * (s - 12) + 4);
+        }
+      });
+    }
+    ST_MARK(4 + 24 * l + 1);
     __syncthreads();
-    qa8_stage_attention(Q_s, N, graphs, bufA, lane, wave);
+    ST_MARK(4 + 24 * l + 2);
+    if (N <= 16) qa8_stage_attention_mfma<1>(Q_s, N, graphs, RTW - 1, bufA, lane, wave, EB_LD);
+    else if (N <= 32) qa8_stage_attention_mfma<2>(Q_s, N, graphs, RTW - 1, bufA, lane, wave, EB_LD);
+    else if (N <= 48) qa8_stage_attention_mfma<3>(Q_s, N, graphs, RTW - 1, bufA, lane, wave, EB_LD);
+    else qa8_stage_attention_mfma<4>(Q_s, N, graphs, RTW - 1, bufA, lane, wave, EB_LD);
+    ST_MARK(4 + 24 * l + 3);
     __syncthreads();
-    eb8_block_stages<RT16>(bufA, bufB, wa, L.out_proj_bias, norms + (2 * l) * 384, L.ff0_weight,
+    ST_MARK(4 + 24 * l + 4);
+    eb8_block_stages<RT16>(bufA, Q_s, bufB, wa, L.out_proj_bias, norms + (2 * l) * 384, L.ff0_weight,
                            L.ff0_bias, L.ff2_weight, L.ff2_bias, norms + (2 * l + 1) * 384,
-                           bufB, RTW, w.hidden, lane, wave, EB_LD);
+                           bufB, RTW, w.hidden, lane, wave, EB_LD, win,
+                           l + 1 < w.num_layers ? w.layer[l + 1].in_proj_weight : nullptr,
+                           4 + 24 * l);
+    ST_MARK(4 + 24 * l + 23);
     __syncthreads();
   }
+  ST_MARK(ST_SLOTS - 3);
   // ---- result: coalesced 16-byte stores; the decoder's per-graph constants on the way -------
   for (int idx = tid; idx < rows * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
@@ -1123,6 +1381,8 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
     }
     if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
   }
+  ST_MARK(ST_SLOTS - 2);
+  ST_MARK(ST_SLOTS - 1);
 }
 
 template <int RT16>
@@ -1144,6 +1404,36 @@ static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, co
   hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
                      norms, y, B, N, G, su, ep);
   VRP_CHECK_LAUNCH("encoder_stack");
+#ifdef VRP_STACK_TRACE
+  {
+    static int calls = 0;
+    if (++calls == 8) {   // a warm launch
+      hipDeviceSynchronize();
+      static unsigned long long h[512 * 8 * ST_SLOTS];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stack_trace), sizeof(h));
+      for (int blk : {100}) {
+        for (int wv = 0; wv < 8; ++wv) {
+          const unsigned long long *t = h + ((size_t)blk * 8 + wv) * ST_SLOTS;
+          const double mhz = 100.0 * (double)(t[ST_SLOTS - 2] - t[1]) / (double)(t[ST_SLOTS - 1] - t[0]);
+          fprintf(stderr, "[stack trace] block %d wave %d: shader clock %.0f MHz, total %llu cyc\n", blk,
+                  wv, mhz, t[ST_SLOTS - 2] - t[1]);
+          fprintf(stderr, "  setup %llu\n", t[2] - t[1]);
+          for (int l = 0; l < 3; ++l) {
+            const unsigned long long *u = t + 4 + 24 * l;
+            fprintf(stderr, "  L%d proj %llu bar %llu att %llu bar %llu out %llu bar %llu | up0 %llu bar %llu |", l,
+                    u[1] - u[0], u[2] - u[1], u[3] - u[2], u[4] - u[3], u[5] - u[4], u[6] - u[5],
+                    u[7] - u[6], u[8] - u[7]);
+            for (int ch = 0; ch < 3; ++ch)
+              fprintf(stderr, " dn %llu up %llu bar %llu |", u[9 + 3 * ch] - u[8 + 3 * ch],
+                      u[10 + 3 * ch] - u[9 + 3 * ch], u[11 + 3 * ch] - u[10 + 3 * ch]);
+            fprintf(stderr, " dn %llu bn2 %llu\n", u[21] - u[17], u[23] - u[21]);
+          }
+          fprintf(stderr, "  epilogue %llu\n", t[ST_SLOTS - 2] - t[ST_SLOTS - 3]);
+        }
+      }
+    }
+  }
+#endif
   return 0;
 }
 
@@ -1306,6 +1596,10 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       else if (N <= 48) r = launch_qkv_attention<3>(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st);
       else r = launch_qkv_attention<4>(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st);
       if (r) return r;
+    } else if (!train && N <= 64 && (80 / N) * N * 4 >= 3 * 80 && !qa_off) {
+      // large batches, eval mode: in_proj + attention of 80 / N whole graphs per workgroup
+      // (only when the graphs fill at least three quarters of the five row tiles)
+      if (int r = launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
     } else {
       if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
                                      ws.qkv, 384, R, 384, 128, 0, st)) return r;
