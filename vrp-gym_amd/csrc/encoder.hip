@@ -401,28 +401,57 @@ __global__ __launch_bounds__(256) void bn_train_apply_kernel(
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define EB_LD 132
 
+// The K = 128 inner dimension is split between the two 32-lane halves g as k = 8 S + 4 g + e
+// (S = k-step 0..15, e = element of the lane's float4): the two lanes that read one weight row
+// in one instruction take 32 consecutive bytes, so a fragment load touches 32 cache lines,
+// not 64 (the vector memory pipe looks lines up one at a time; the weights are re-read by
+// every workgroup at every stage).  The same permutation applies to the LDS operand.
+#ifndef VRP_EB_KLAYOUT
+#define VRP_EB_KLAYOUT 1
+#endif
+__device__ __forceinline__ constexpr int eb_kg(int g) { return VRP_EB_KLAYOUT ? 4 * g : 64 * g; }
+__device__ __forceinline__ constexpr int eb_ks(int s) { return VRP_EB_KLAYOUT ? 2 * s : s; }  // s = 4 S
+__device__ __forceinline__ void eb_load_w4(float (&w)[64], const float *wrow, int s) {
+  const float4 t = *reinterpret_cast<const float4 *>(wrow + eb_ks(s));
+  w[s] = t.x; w[s + 1] = t.y; w[s + 2] = t.z; w[s + 3] = t.w;
+}
 template <int MI>
 __device__ __forceinline__ void eb_load_w(float (&w)[64], const float *wrow) {
 #pragma unroll
-  for (int s = 0; s < 64; s += 4) {
-    const float4 t = *reinterpret_cast<const float4 *>(wrow + s);
-    w[s] = t.x; w[s + 1] = t.y; w[s + 2] = t.z; w[s + 3] = t.w;
-  }
+  for (int s = 0; s < 64; s += 4) eb_load_w4(w, wrow, s);
 }
-template <int MI>
+struct EbNoPre { __device__ __forceinline__ void operator()(int) const {} };
+// A fragments of k-step S + 1 are read from LDS before the MFMAs of k-step S are issued;
+// `pre(s)` runs once per k-step ahead of its MFMAs (the callers request the next stage's
+// weight fragment there, one 16-byte load per step, instead of sixteen loads per wave queueing
+// up behind the vector memory pipe at a stage boundary).
+template <int MI, typename Pre = EbNoPre>
 __device__ __forceinline__ void eb_mma(f32x16 (&acc)[MI], const float *abuf, const float (&w)[64],
-                                       int lane) {
+                                       int lane, Pre pre = Pre()) {
   const int i = lane & 31, g = lane >> 5;
+  const float *ap = abuf + i * EB_LD + eb_kg(g);
+  float4 a[2][MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) a[0][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * EB_LD);
 #pragma unroll
   for (int s = 0; s < 64; s += 4) {
+    const int cur = (s >> 2) & 1;
+    if (s + 4 < 64) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const float4 a = *reinterpret_cast<const float4 *>(abuf + (mi * 32 + i) * EB_LD + 64 * g + s);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[s], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[s + 1], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[s + 2], acc[mi], 0, 0, 0);
-      acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[s + 3], acc[mi], 0, 0, 0);
+      for (int mi = 0; mi < MI; ++mi)
+        a[cur ^ 1][mi] = *reinterpret_cast<const float4 *>(ap + mi * 32 * EB_LD + eb_ks(s + 4));
     }
+    pre(s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].x, w[s], acc[mi], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].y, w[s + 1], acc[mi], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].z, w[s + 2], acc[mi], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi].w, w[s + 3], acc[mi], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -445,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
   // loads of stage k+1 are issued before the MFMAs of stage k, so every weight fetch has a
   // whole MFMA stage to land.
   float wa[64], wb[64];
-  eb_load_w<MI>(wa, Wo + (size_t)ncol * 128 + 64 * g);   // in flight while the tiles land
+  eb_load_w<MI>(wa, Wo + (size_t)ncol * 128 + eb_kg(g));   // in flight while the tiles land
   for (int idx = tid; idx < RTW * 32; idx += 256) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vx = va;
@@ -465,10 +494,10 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
     for (int r = 0; r < 16; ++r) { acc[mi][r] = 0.f; gacc[mi][r] = 0.f; }
 
   // ---- y1 = BN1(x + att Wo^T + bo) ------------------------------------------------------
-  eb_load_w<MI>(wb, W1 + (size_t)ncol * 128 + 64 * g);   // W1 slice 0, lands during this stage
-  eb_mma<MI>(acc, bufA, wa, lane);
   {
     const float bb = bo[ncol], mean = norm1[ncol], mult = norm1[128 + ncol], beta = norm1[256 + ncol];
+    const float *w1c = W1 + (size_t)ncol * 128 + eb_kg(g);   // W1 slice 0, lands during this stage
+    eb_mma<MI>(acc, bufA, wa, lane, [&](int s) { eb_load_w4(wb, w1c, s); });
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -482,15 +511,16 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
 
   // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T --------------
   const int nchunk = hidden / 128;
+  const float bb2 = b2[ncol], mean2 = norm2[ncol], mult2 = norm2[128 + ncol], beta2 = norm2[256 + ncol];
   for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
-    eb_load_w<MI>(wa, W2 + (size_t)ncol * hidden + c * 128 + 64 * g);   // W2[:, slice c]
-    eb_mma<MI>(acc, bufB, wb, lane);                                     // wb = W1 slice c
     {
       const float bb = b1[c * 128 + ncol];
+      const float *w2c = W2 + (size_t)ncol * hidden + c * 128 + eb_kg(g);   // W2[:, slice c]
+      eb_mma<MI>(acc, bufB, wb, lane, [&](int s) { eb_load_w4(wa, w2c, s); });   // wb = W1 slice c
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -500,14 +530,18 @@ __global__ __launch_bounds__(256, 1) void encoder_block_kernel(
         }
     }
     __syncthreads();  // slice c of the hidden layer is in bufA
-    if (c + 1 < nchunk) eb_load_w<MI>(wb, W1 + (size_t)((c + 1) * 128 + ncol) * 128 + 64 * g);
-    eb_mma<MI>(gacc, bufA, wa, lane);                                    // wa = W2[:, slice c]
+    if (c + 1 < nchunk) {
+      const float *w1c = W1 + (size_t)((c + 1) * 128 + ncol) * 128 + eb_kg(g);
+      eb_mma<MI>(gacc, bufA, wa, lane, [&](int s) { eb_load_w4(wb, w1c, s); });   // wa = W2[:, slice c]
+    } else {
+      eb_mma<MI>(gacc, bufA, wa, lane);
+    }
     __syncthreads();  // everybody done with bufA before the next slice overwrites it
   }
 
   // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
   {
-    const float bb = b2[ncol], mean = norm2[ncol], mult = norm2[128 + ncol], beta = norm2[256 + ncol];
+    const float bb = bb2, mean = mean2, mult = mult2, beta = beta2;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -910,13 +944,16 @@ __device__ __forceinline__ void qa8_load_w_half(float (&w)[3][32], const float *
     }
   }
 }
-template <int RT16>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `last_hook` runs ahead of the MFMAs of the last stage (the large-batch kernel requests its
+// next tile there).
+template <int RT16, typename Last = NoHook, bool NEXT = true>
 __device__ __forceinline__ void eb8_block_stages(
     float *bufA, float *bufA2, float *bufB, float (&wa)[32], const float *__restrict__ bo,
     const float *__restrict__ norm1, const float *__restrict__ W1, const float *__restrict__ b1,
     const float *__restrict__ W2, const float *__restrict__ b2, const float *__restrict__ norm2,
     float *y_tile, int valid_rows, int hidden, int lane, int wave, int y_ld,
-    float (&win)[3][32], const float *Win_next, int st_base = 0) {
+    float (&win)[3][32], const float *Win_next, int st_base = 0, Last last_hook = Last()) {
   const int i16 = lane & 15, q = lane >> 4;
   const int c = wave * 16 + i16;  // this lane's weight row / D column
   float wb[32];
@@ -984,11 +1021,12 @@ __device__ __forceinline__ void eb8_block_stages(
   // fragments is fetched behind it; the other half follows at the start of that layer, behind
   // the first half's MFMAs (all 96 registers at once do not fit beside this stage)
   const float bb_2 = b2[c], mean2 = norm2[c], mult2 = norm2[128 + c], beta2 = norm2[256 + c];
+  last_hook();
   {
     const float *wn = Win_next ? Win_next + (size_t)(wave * 48 + i16) * VRP_EMB + kq8(q) : nullptr;
     eb8_mma<RT16>(gacc, ((nchunk - 1) & 1) ? bufA2 : bufA, wa, lane, [&](int s) {
       // twelve loads over the first six k-steps: column tile ct = s / 8, k-steps (s % 8) * 2 ..
-      if (wn && s < 24) {
+      if (NEXT && wn && s < 24) {
         const int ct = s / 8, k0 = (s % 8) * 2;
         load_w4(win[ct], wn + (size_t)ct * 16 * VRP_EMB, k0);
         load_w4(win[ct], wn + (size_t)ct * 16 * VRP_EMB, k0 + 4);
@@ -1161,6 +1199,168 @@ __device__ __forceinline__ void qa8_stage_attention_mfma(const float *Q_s, int N
       }
     }
   }
+}
+
+// ---- out-proj + BN1 + FF + BN2 for LARGE row counts, eight waves on 16x16x4 MFMAs ---------
+// The stack kernel's block stages (a wave owns 16 output columns; hidden slices alternate
+// between two LDS buffers, one barrier per slice) on 80-row tiles, persistent workgroups, one
+// per CU (three 80-row buffers = 127 KB of LDS).  Nothing of a tile's traffic is exposed:
+//   * the attention rows of the NEXT tile are requested ahead of the last stage's MFMAs and
+//     written behind them into the hidden buffer that stage does not read;
+//   * the residual x is not staged at all: a lane fetches the 4 x RT16 elements of its
+//     accumulator layout straight from global memory ahead of the out-proj MFMAs;
+//   * y leaves in the BN2 epilogue.
+template <int RT16>
+__global__ __launch_bounds__(512) void encoder_block8_kernel(
+    const float *__restrict__ att, const float *__restrict__ x, const float *__restrict__ Wo_,
+    const float *__restrict__ bo_, const float *__restrict__ norm1_, const float *__restrict__ W1_,
+    const float *__restrict__ b1_, const float *__restrict__ W2_, const float *__restrict__ b2_,
+    const float *__restrict__ norm2_, float *__restrict__ y, int rows, int hidden, int ntiles) {
+  constexpr int RTW = 16 * RT16, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *hb0 = smem;                   // attention tile / hidden slices (roles alternate)
+  float *hb1 = hb0 + RTW * EB_LD;
+  float *bufB = hb1 + RTW * EB_LD;     // y1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int c = wave * 16 + i16;
+  const int nchunk = hidden / 128;
+  float4 pa[PF];
+  auto fetch_att = [&](int tile) {
+    const int row0 = tile * RTW;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < rows) pa[u] = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+    }
+  };
+  auto store_att = [&](float *dst) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(dst + r * EB_LD + c4) = pa[u];
+    }
+  };
+  int tile = blockIdx.x;
+  float *abuf = hb0, *other = hb1;     // abuf: this tile's attention rows
+  if (tile < ntiles) { fetch_att(tile); store_att(abuf); }
+  float wa[32], wb[32];   // wb enters a tile holding the Wo fragment
+  {
+    const float *wo = Wo_ + (size_t)c * 128 + kq8(q);
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) load_w4(wb, wo, s);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    // (the weights do not change from tile to tile; an opaque zero keeps the compiler from
+    // hoisting their loads out of this loop into registers it does not have)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const float *Wo = Wo_ + zero, *bo = bo_ + zero, *norm1 = norm1_ + zero, *W1 = W1_ + zero,
+                *b1 = b1_ + zero, *W2 = W2_ + zero, *b2 = b2_ + zero, *norm2 = norm2_ + zero;
+    const int row0 = tile * RTW, valid = rows - row0;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) wa[s] = wb[s];
+    // residual rows of this lane's accumulator elements (row = 16 rt + 4 q + r, column c)
+    float xr[RT16][4];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        xr[rt][r] = row < valid ? x[(size_t)(row0 + row) * 128 + c] : 0.f;
+      }
+    f32x4v acc[RT16], gacc[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[rt][r] = 0.f; gacc[rt][r] = 0.f; }
+    // ---- y1 = BN1(x + att Wo^T + bo) -> bufB ----------------------------------------------
+    {
+      const float bb = bo[c], mean = norm1[c], mult = norm1[128 + c], beta = norm1[256 + c];
+      const float *w1c = W1 + (size_t)c * 128 + kq8(q);
+      eb8_mma<RT16>(acc, abuf, wa, lane, [&](int s) { load_w4(wb, w1c, s); });
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bufB[(rt * 16 + 4 * q + r) * EB_LD + c] = (acc[rt][r] + bb + xr[rt][r] - mean) * mult + beta;
+    }
+    __syncthreads();
+    // ---- hidden slices: up (y1 -> slice in LDS), down (slice -> g in registers) ------------
+    auto slice_up = [&](int ch, float *hb) {
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][r] = 0.f;
+      const float bb = b1[ch * 128 + c];
+      const float *w2c = W2 + (size_t)c * hidden + ch * 128 + kq8(q);
+      eb8_mma<RT16>(acc, bufB, wb, lane, [&](int s) { load_w4(wa, w2c, s); });
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          hb[(rt * 16 + 4 * q + r) * EB_LD + c] = fmaxf(acc[rt][r] + bb, 0.f);
+    };
+    // slice ch lives in abuf (even ch) / other (odd ch): the attention rows are dead by now
+    slice_up(0, abuf);
+    __syncthreads();
+    for (int ch = 0; ch + 1 < nchunk; ++ch) {
+      float *hcur = (ch & 1) ? other : abuf, *hnext = (ch & 1) ? abuf : other;
+      const float *w1c = W1 + (size_t)((ch + 1) * 128 + c) * 128 + kq8(q);
+      eb8_mma<RT16>(gacc, hcur, wa, lane, [&](int s) { load_w4(wb, w1c, s); });
+      slice_up(ch + 1, hnext);
+      __syncthreads();
+    }
+    // last way down; the next tile's attention rows travel behind it into the free buffer
+    float *hlast = ((nchunk - 1) & 1) ? other : abuf, *hfree = ((nchunk - 1) & 1) ? abuf : other;
+    const float bb2 = b2[c], mean2 = norm2[c], mult2 = norm2[128 + c], beta2 = norm2[256 + c];
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch_att(next);
+    {
+      const float *wo = Wo + (size_t)c * 128 + kq8(q);   // Wo fragment for the next tile
+      eb8_mma<RT16>(gacc, hlast, wa, lane, [&](int s) { load_w4(wb, wo, s); });
+    }
+    if (next < ntiles) store_att(hfree);
+    // ---- y = BN2(y1 + g + b2) ----------------------------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        if (row < valid) {
+          const float v = gacc[rt][r] + bb2 + bufB[row * EB_LD + c];
+          y[(size_t)(row0 + row) * 128 + c] = (v - mean2) * mult2 + beta2;
+        }
+      }
+    __syncthreads();   // next tile's attention rows complete, bufB and hlast free
+    abuf = hfree; other = hlast;
+  }
+}
+
+template <int RT16>
+static int launch_encoder_block8(const float *att, const float *x, const vrp_encoder_layer &L,
+                                 const float *norm1, const float *norm2, float *y, int rows,
+                                 int hidden, hipStream_t st) {
+  constexpr int RTW = 16 * RT16;
+  const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block8_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_block8: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int ntiles = (rows + RTW - 1) / RTW;
+  hipLaunchKernelGGL(encoder_block8_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, att, x,
+                     L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
+                     L.ff2_weight, L.ff2_bias, norm2, y, rows, hidden, ntiles);
+  VRP_CHECK_LAUNCH("encoder_block8");
+  return 0;
 }
 
 // ---- in_proj + attention of whole graphs in one launch, LARGE batches (eval mode) ----------
@@ -1614,13 +1814,17 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       const float *n1 = ws.norm + (2 * l) * 384, *n2 = ws.norm + (2 * l + 1) * 384;
       // row tile: enough workgroups to occupy all 256 CUs at every batch size
       int r;
-      static const char *rtw_env = getenv("VRP_BLOCK_RTW");  // A/B aid: "64" or "128"
+      static const char *rtw_env = getenv("VRP_BLOCK_RTW");  // A/B aid: "64", "128" or "8"
       if (rtw_env && rtw_env[0] == '6')
         r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (rtw_env && rtw_env[0] == '1')
         r = launch_encoder_block<128>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
-      else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows (8.83 vs
-        r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);  // 8.95 ms per 8192x40 rollout)
+      else if ((rtw_env && rtw_env[0] == '8') || (!rtw_env && R >= 256 * 80))
+        // >= one 80-row tile per CU: persistent 8-wave kernel (827 vs 914 us per layer for
+        // the 64-row kernel at 8192 x 40)
+        r = launch_encoder_block8<5>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+      else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows
+        r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 12 * 1024)   // small batches: at most one workgroup per CU (256 CUs)
         r = launch_encoder_block16<4>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 8 * 1024)
