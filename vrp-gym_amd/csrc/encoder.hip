@@ -1485,6 +1485,9 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
     *reinterpret_cast<float4 *>(bufB + r * EB_LD + c4) = v;
     *reinterpret_cast<float4 *>(bufA + r * EB_LD + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float win[3][32];  // in_proj fragments of the coming layer (the first: behind the set-up)
+  qa8_load_w_half(win, w.layer[0].in_proj_weight, lane, wave, 0);
+  __builtin_amdgcn_sched_barrier(0);
   if (su.from_env) {
     // rollout set-up of this workgroup's graphs (one wave each), BN affines into LDS
     __syncthreads();
@@ -1511,8 +1514,6 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
     }
     norms = norm_s;
   }
-  float win[3][32];  // in_proj fragments of the coming layer
-  qa8_load_w_half(win, w.layer[0].in_proj_weight, lane, wave, 0);
   ST_MARK(2);
   __syncthreads();
   for (int l = 0; l < w.num_layers; ++l) {
