@@ -80,6 +80,7 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
                                  float *emb, void *workspace, float *acc_loss, float *acc_logp,
                                  int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
                                  float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
+                                 const float *dec_warm, int dec_warm_floats,
                                  int *decoder_constants_done, hipStream_t st);
 int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
                            void *workspace, int constants_done, void *stream);
@@ -108,7 +109,9 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
     DecWs w = carve_decws(dec_workspace, B, N);
     if (int r = vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
                                              io->acc_logp, io->notdone, max_steps + 1, d.mb, w.g,
-                                             w.cvec, w.hist, w.err, &constants_done,
+                                             w.cvec, w.hist, w.err,
+                                             use_fused_prologue(N) ? d.Wproj : nullptr, 1536 * 128,
+                                             &constants_done,
                                              (hipStream_t)stream)) return r;
   }
   if (int r = vrp_decode_prologue_ex(kind, derived, B, N, emb, dec_workspace, constants_done,

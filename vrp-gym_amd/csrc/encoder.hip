@@ -1447,6 +1447,9 @@ struct StackEpilogue {
   float *g, *cvec;             // (B,128) graph mean, (B,N) e_m . mb
   unsigned long long *hist;    // (2N,B) persistent step kernel's hand-off words (cleared here)
   int32_t *err;
+  const float *warm;           // the decoder prologue's projection weights (786 KB): touched here,
+  int warm_floats;             // one share per workgroup, so that they wait in every XCD's L2
+                               // when the prologue starts (58 -> 55 us at 512 x 20)
 };
 struct StackSetup {            // rollout set-up fused in front (vrp_rollout): env may be null
   vrp_env env;
@@ -1581,6 +1584,14 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
       ep.hist[(size_t)t * B + g0 + g] = 0ull;
     }
     if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
+    if (ep.warm) {
+      // workgroups b, b + 8, ... share an XCD: together they touch every 128-byte line once
+      const int per_xcd = (gridDim.x + 7) >> 3, slot = blockIdx.x >> 3;
+      const int lines = ep.warm_floats >> 5;
+      float sink = 0.f;
+      for (int ln = slot * 512 + tid; ln < lines; ln += per_xcd * 512) sink += ep.warm[(size_t)ln * 32];
+      if (sink == 1.2345678e-30f) y[0] = sink;   // never true: the loads must not be elided
+    }
   }
   ST_MARK(ST_SLOTS - 2);
   ST_MARK(ST_SLOTS - 1);
@@ -1751,6 +1762,7 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
                                  float *emb, void *workspace, float *acc_loss, float *acc_logp,
                                  int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
                                  float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
+                                 const float *dec_warm, int dec_warm_floats,
                                  int *decoder_constants_done, hipStream_t st) {
   const int B = env->B, N = env->N;
   if (int r = encoder_check(w, B, N)) return r;
@@ -1764,7 +1776,9 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
     StackSetup su;
     su.env = *env; su.acc_loss = acc_loss; su.acc_logp = acc_logp; su.notdone = notdone;
     su.nflags = nflags; su.from_env = 1;
-    StackEpilogue ep = {dec_mb, dec_g, dec_cvec, dec_hist, dec_err};
+    static const bool no_warm = getenv("VRP_NO_WARM") != nullptr;  // A/B aid
+    StackEpilogue ep = {dec_mb, dec_g, dec_cvec, dec_hist, dec_err, no_warm ? nullptr : dec_warm,
+                        dec_warm_floats};
     *decoder_constants_done = dec_g != nullptr;
     return launch_encoder_stack<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
   }
