@@ -1363,6 +1363,156 @@ static int launch_encoder_block8(const float *att, const float *x, const vrp_enc
   return 0;
 }
 
+// ---- C = epilogue(A W^T) for tall problems (M >= 20480 rows; N, K multiples of 128) ---------
+// The train-mode encoder, the decoder backward and the N > 80 prologue run plain GEMMs; the
+// LDS-tiled kernel in gemm.hip reaches 50-60 TFLOP/s on them at M = 81920.  This one reuses the
+// block kernels' scheme: persistent workgroups on 80-row tiles, a wave owns 16 of the 128
+// columns of a pass, the stages of a tile are (column pass, 128-wide K chunk); the A chunk of
+// a stage sits in LDS (two buffers: the next chunk travels behind the current stage's MFMAs,
+// one barrier per stage, none while K = 128 keeps the chunk), the W fragment of the next stage
+// is requested one 16-byte load per k-step.  Same epilogue as gemm_nt_kernel (bias, residual,
+// BatchNorm affine, ReLU, gate), applied in the accumulator layout.
+template <int RT16>
+__global__ __launch_bounds__(512) void gemm_rows_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ W_, int ldw,
+    const float *__restrict__ bias_, const float *__restrict__ R, int ldr,
+    const float *__restrict__ norm_, const float *__restrict__ gate, float *__restrict__ C, int ldc,
+    int M, int N, int K, int relu, int ntiles) {
+  constexpr int RTW = 16 * RT16, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *const Abuf0 = smem, *const Abuf1 = smem + RTW * EB_LD, *const Cs = smem + 2 * RTW * EB_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int ncb = N >> 7, nkc = K >> 7, nst = ncb * nkc;
+  float4 pa[PF];
+  auto fetchA = [&](int tile, int kc) {
+    const int row0 = tile * RTW;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < M) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)(row0 + r) * lda + kc * 128 + c4);
+    }
+  };
+  auto storeA = [&](float *dst) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(dst + r * EB_LD + c4) = pa[u];
+    }
+  };
+  int tile = blockIdx.x;
+  int cur = 0;
+  float w[32], wn[32];
+  if (tile < ntiles) { fetchA(tile, 0); storeA(Abuf0); }
+  {
+    const float *w0 = W_ + (size_t)(wave * 16 + i16) * ldw + kq8(q);
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) load_w4(w, w0, s);
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    int zero;   // (keeps the tile-invariant weight loads inside the loop, see encoder_block8_kernel)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const float *W = W_ + zero, *bias = bias_ ? bias_ + zero : nullptr, *norm = norm_ ? norm_ + zero : nullptr;
+    const int row0 = tile * RTW, valid = M - row0;
+    const int next_tile = tile + gridDim.x;
+    f32x4v acc[RT16];
+    for (int st = 0; st < nst; ++st) {
+      const int cb = st / nkc, kc = st - cb * nkc;
+      const int col = cb * 128 + wave * 16 + i16;
+      if (kc == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool last_stage = st + 1 == nst;
+      const bool tile_left = next_tile < ntiles;
+      // the A chunk of the next stage (same chunk while K = 128 and the tile lasts)
+      const bool fetch = (nkc > 1) ? (!last_stage || tile_left) : (last_stage && tile_left);
+      if (fetch) fetchA(last_stage ? next_tile : tile, last_stage ? 0 : (kc + 1 == nkc ? 0 : kc + 1));
+      const bool epi = kc + 1 == nkc;
+      // residual / gate pieces of this pass (whole rows, 16 bytes per thread), requested ahead
+      // of the last chunk's MFMAs
+      float4 rv[PF], gv[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+        rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (epi && r < valid) {
+          if (R) rv[u] = *reinterpret_cast<const float4 *>(R + (size_t)(row0 + r) * ldr + cb * 128 + c4);
+          if (gate) gv[u] = *reinterpret_cast<const float4 *>(gate + (size_t)(row0 + r) * ldc + cb * 128 + c4);
+        }
+      }
+      {
+        // next stage's W fragment: stage st + 1 of this tile, or stage 0 of the next tile
+        const int sn = last_stage ? 0 : st + 1;
+        const int cbn = sn / nkc, kcn = sn - cbn * nkc;
+        const float *wp = W + (size_t)(cbn * 128 + wave * 16 + i16) * ldw + kcn * 128 + kq8(q);
+        eb8_mma<RT16>(acc, cur ? Abuf1 : Abuf0, w, lane, [&](int s) { load_w4(wn, wp, s); });
+      }
+      if (fetch) storeA(cur ? Abuf0 : Abuf1);
+      if (epi) {
+        // the 80 x 128 block of this pass goes through LDS so that residual, gate and result
+        // move as 16-byte pieces of whole rows (in the accumulator layout a store instruction
+        // writes four 64-byte fragments)
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(rt * 16 + 4 * q + r) * EB_LD + wave * 16 + i16] = acc[rt][r];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+          if (r < valid) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(Cs + r * EB_LD + c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float rr[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+            const float gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int n = cb * 128 + c4 + e;
+              if (bias) v[e] += bias[n];
+              if (R) v[e] += rr[e];
+              if (norm) v[e] = (v[e] - norm[n]) * norm[128 + n] + norm[256 + n];
+              if (relu) v[e] = fmaxf(v[e], 0.f);
+              if (gate && !(gg[e] > 0.f)) v[e] = 0.f;
+            }
+            *reinterpret_cast<float4 *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) w[s] = wn[s];
+      if (fetch || epi) __syncthreads();   // next A chunk in place / everybody done with Cs
+      if (fetch) cur ^= 1;
+    }
+  }
+}
+
+int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const float *bias,
+                         const float *R, int ldr, const float *norm, const float *gate, float *C,
+                         int ldc, int M, int N, int K, int relu, hipStream_t st) {
+  constexpr int RT16 = 5, RTW = 80;
+  const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_rows_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("gemm_rows: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int ntiles = (M + RTW - 1) / RTW;
+  hipLaunchKernelGGL(gemm_rows_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, A, lda, W,
+                     ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, ntiles);
+  VRP_CHECK_LAUNCH("gemm_rows");
+  return 0;
+}
+
 // ---- in_proj + attention of whole graphs in one launch, LARGE batches (eval mode) ----------
 // The projection GEMM wrote q|k|v (B*N x 384 fp32: 503 MB at 8192 x 40) only for the attention
 // kernel to read it back; here a workgroup takes G = 80 / N whole graphs (N = 40: two graphs =

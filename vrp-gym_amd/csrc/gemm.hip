@@ -207,6 +207,10 @@ __global__ __launch_bounds__(256) void gemm_nt_m16_k128_kernel(
   }
 }
 
+int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const float *bias,
+                         const float *R, int ldr, const float *norm, const float *gate, float *C,
+                         int ldc, int M, int N, int K, int relu, hipStream_t st);  // encoder.hip
+
 // norm: optional BatchNorm affine (only for N == 128): [mean | mult | beta]
 int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, const float *bias,
                             const float *R, int ldr, const float *norm, const float *gate, float *C,
@@ -217,7 +221,7 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
   VRP_REQUIRE((lda % 4) == 0 && (ldw % 4) == 0, "gemm: lda/ldw must be multiples of 4");
   VRP_REQUIRE(!norm || N == 128, "gemm: fused BatchNorm needs N == 128");
   const long tiles128 = (long)(N / BN) * ((M + 127) / 128);
-  static const char *force = getenv("VRP_GEMM_VARIANT");  // tuning aid: "64x32", "64x64", "128x32"
+  static const char *force = getenv("VRP_GEMM_VARIANT");  // tuning aid: "64x32", "64x64", "128x32", "rows", "default" (LDS-tiled kernels only)
   if (force && force[0] == '6') {
     dim3 grid(N / BN, (M + 63) / 64);
     if (force[3] == '3')
@@ -234,6 +238,13 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, gate, C, ldc, M, N, K, relu);
+  } else if ((force && force[0] == 'r') || (!force && (R || gate) && M >= 256 * 80 && K % 128 == 0)) {
+    // a residual or a gate to read, at least one 80-row tile per CU: persistent A-stationary
+    // kernel (encoder.hip), whose epilogue moves whole rows.  Measured (tools/gemm_rows_probe.py,
+    // bias + residual + ReLU): 132 vs 209 us at 81920 x 384 x 128, 123 vs 156 at
+    // 81920 x 128 x 512, 273 vs 318 at 81920 x 384 x 384.  Without residual the LDS-tiled
+    // kernels below win (120 vs 125 us, 911 vs 1059 at 204800 x 1536 x 128).
+    return vrp_launch_gemm_rows(A, lda, W, ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, stream);
   } else if ((long)M * N <= (3L << 20) && K == 128 && !R && !norm && !gate && !relu) {
     // measured (tools/gemm_small_probe.py): 5.7 vs 15.5 us at 512x384, 20 vs 21 at 2048x1536,
     // 35 vs 28 at 4096x1536
