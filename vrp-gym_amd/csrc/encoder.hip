@@ -1365,7 +1365,8 @@ static int launch_encoder_block8(const float *att, const float *x, const vrp_enc
 
 // ---- C = epilogue(A W^T) for tall problems (M >= 20480 rows; N, K multiples of 128) ---------
 // The train-mode encoder, the decoder backward and the N > 80 prologue run plain GEMMs; the
-// LDS-tiled kernel in gemm.hip reaches 50-60 TFLOP/s on them at M = 81920.  This one reuses the
+// LDS-tiled kernel in gemm.hip reaches 40-75 TFLOP/s on them at M = 81920 (its residual reads
+// and result writes are 4-byte accesses in the accumulator layout).  This one reuses the
 // block kernels' scheme: persistent workgroups on 80-row tiles, a wave owns 16 of the 128
 // columns of a pass, the stages of a tile are (column pass, 128-wide K chunk); the A chunk of
 // a stage sits in LDS (two buffers: the next chunk travels behind the current stage's MFMAs,
@@ -1445,6 +1446,18 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
           if (gate) gv[u] = *reinterpret_cast<const float4 *>(gate + (size_t)(row0 + r) * ldc + cb * 128 + c4);
         }
       }
+      // bias / BatchNorm affine of this thread's four columns (the same for its PF rows)
+      const int cq = cb * 128 + (tid & 31) * 4;
+      float4 bz = make_float4(0.f, 0.f, 0.f, 0.f), nmean = bz, nbeta = bz;
+      float4 nmult = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (epi) {
+        if (bias) bz = *reinterpret_cast<const float4 *>(bias + cq);
+        if (norm) {
+          nmean = *reinterpret_cast<const float4 *>(norm + cq);
+          nmult = *reinterpret_cast<const float4 *>(norm + 128 + cq);
+          nbeta = *reinterpret_cast<const float4 *>(norm + 256 + cq);
+        }
+      }
       {
         // next stage's W fragment: stage st + 1 of this tile, or stage 0 of the next tile
         const int sn = last_stage ? 0 : st + 1;
@@ -1470,17 +1483,20 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const float rr[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
             const float gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
+            const float nm[4] = {nmean.x, nmean.y, nmean.z, nmean.w};
+            const float nu[4] = {nmult.x, nmult.y, nmult.z, nmult.w};
+            const float nb[4] = {nbeta.x, nbeta.y, nbeta.z, nbeta.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int n = cb * 128 + c4 + e;
-              if (bias) v[e] += bias[n];
+              v[e] += bb[e];
               if (R) v[e] += rr[e];
-              if (norm) v[e] = (v[e] - norm[n]) * norm[128 + n] + norm[256 + n];
+              if (norm) v[e] = (v[e] - nm[e]) * nu[e] + nb[e];
               if (relu) v[e] = fmaxf(v[e], 0.f);
               if (gate && !(gg[e] > 0.f)) v[e] = 0.f;
             }
-            *reinterpret_cast<float4 *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4) =
-                make_float4(v[0], v[1], v[2], v[3]);
+            f32x4v out = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(out, reinterpret_cast<f32x4v *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4));
           }
         }
       }

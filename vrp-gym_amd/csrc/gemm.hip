@@ -238,12 +238,13 @@ int vrp_launch_gemm_nt_full(const float *A, int lda, const float *W, int ldw, co
     dim3 grid(N / BN, (M + 127) / 128);
     hipLaunchKernelGGL((gemm_nt_kernel<128, 32>), grid, dim3(256), 0, stream, A, lda, W, ldw, bias, R,
                        ldr, norm, gate, C, ldc, M, N, K, relu);
-  } else if ((force && force[0] == 'r') || (!force && (R || gate) && M >= 256 * 80 && K % 128 == 0)) {
-    // a residual or a gate to read, at least one 80-row tile per CU: persistent A-stationary
-    // kernel (encoder.hip), whose epilogue moves whole rows.  Measured (tools/gemm_rows_probe.py,
-    // bias + residual + ReLU): 132 vs 209 us at 81920 x 384 x 128, 123 vs 156 at
-    // 81920 x 128 x 512, 273 vs 318 at 81920 x 384 x 384.  Without residual the LDS-tiled
-    // kernels below win (120 vs 125 us, 911 vs 1059 at 204800 x 1536 x 128).
+  } else if ((force && force[0] == 'r') || (!force && M >= 256 * 80 && K % 128 == 0)) {
+    // at least one 80-row tile per CU: persistent A-stationary kernel (encoder.hip), whose
+    // epilogue moves whole rows.  Measured (tools/gemm_rows_probe.py) against the LDS-tiled
+    // kernels below, bias + residual + ReLU: 116 vs 209 us at 81920 x 384 x 128, 131 vs 268 at
+    // 81920 x 512 x 128, 119 vs 156 at 81920 x 128 x 512, 253 vs 318 at 81920 x 384 x 384; bias
+    // only: 104 vs 120, 126 vs 137, 828 vs 911 at 204800 x 1536 x 128, 399 vs 396 at
+    // 327680 x 128 x 512.
     return vrp_launch_gemm_rows(A, lda, W, ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, stream);
   } else if ((long)M * N <= (3L << 20) && K == 128 && !R && !norm && !gate && !relu) {
     // measured (tools/gemm_small_probe.py): 5.7 vs 15.5 us at 512x384, 20 vs 21 at 2048x1536,
