@@ -1495,8 +1495,8 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
               if (relu) v[e] = fmaxf(v[e], 0.f);
               if (gate && !(gg[e] > 0.f)) v[e] = 0.f;
             }
-            f32x4v out = {v[0], v[1], v[2], v[3]};
-            __builtin_nontemporal_store(out, reinterpret_cast<f32x4v *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4));
+            *reinterpret_cast<float4 *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4) =
+                make_float4(v[0], v[1], v[2], v[3]);
           }
         }
       }
