@@ -38,19 +38,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int lr = tid >> 5, lc = tid & 31;  // 8 rows x 32 float4 columns per pass
   const int fi = lane & 31, fk = lane >> 5;
-  for (int r0 = r_begin; r0 < r_end; r0 += TN_BR) {
+  // the next 32-row slab travels in registers while the current one feeds the MFMAs
+  float4 xv[TN_BR / 8], yv[TN_BR / 8];
+  auto fetch = [&](int r0) {
 #pragma unroll
     for (int s = 0; s < TN_BR / 8; ++s) {
       const int r = r0 + lr + 8 * s;
-      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), yv = xv;
+      xv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      yv[s] = xv[s];
       if (r < r_end) {
-        xv = *reinterpret_cast<const float4 *>(X + (size_t)r * ldx + i0 + 4 * lc);
-        yv = *reinterpret_cast<const float4 *>(Y + (size_t)r * ldy + j0 + 4 * lc);
+        xv[s] = *reinterpret_cast<const float4 *>(X + (size_t)r * ldx + i0 + 4 * lc);
+        yv[s] = *reinterpret_cast<const float4 *>(Y + (size_t)r * ldy + j0 + 4 * lc);
       }
-      Xs[(lr + 8 * s) * 32 + lc] = xv;
-      Ys[(lr + 8 * s) * 32 + lc] = yv;
+    }
+  };
+  fetch(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += TN_BR) {
+#pragma unroll
+    for (int s = 0; s < TN_BR / 8; ++s) {
+      Xs[(lr + 8 * s) * 32 + lc] = xv[s];
+      Ys[(lr + 8 * s) * 32 + lc] = yv[s];
     }
     __syncthreads();
+    if (r0 + TN_BR < r_end) fetch(r0 + TN_BR);
     const float *xs = reinterpret_cast<const float *>(Xs);
     const float *ys = reinterpret_cast<const float *>(Ys);
 #pragma unroll
