@@ -216,11 +216,16 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
   // The weight fragments come from L2 (~600 cycles): they are requested PF k-steps ahead of
   // their MFMAs, and the first ones of the second product before the barrier in between.
   constexpr int PF = 3;
-  const int koff2 = 192 * (q & 1) + 96 * (q >> 1);  // K = 384 split over the four lane groups
+  // Inner dimensions are spread over the four 16-lane groups as k = 16 S + 4 q + e (S = k-step,
+  // e = element of the lane's float4): the four lanes that read one weight row in one
+  // instruction cover 64 consecutive bytes, so a fragment load touches 16 cache lines instead
+  // of 64 (the vector memory pipe looks lines up one by one, and eight waves stream 384 KB of
+  // weights through it in this phase).  Same permutation on the LDS operand.
+  const int koff2 = 4 * q;
   const float *mrow = p.M + (size_t)(wave * 16 + i16) * VRP_D + koff2;
   float4 mw[PF];
   {
-    const int koff = 64 * (q & 1) + 32 * (q >> 1);
+    const int koff = 4 * q;
     const int h = wave;
     const float *wbase = p.Wv + (size_t)(h * VRP_HD + i16) * VRP_EMB + koff;  // + 16c rows, + 4k4
     float4 wq[PF][3];
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     for (int j = 0; j < PF; ++j)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        wq[j][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 4 * j);
+        wq[j][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 16 * j);
     f32x4 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -238,17 +243,17 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     const float *arow = zs + i16 * TL_ZG + h * 128 + koff;   // A row = graph i16
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
-      const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * k4);
+      const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
       const float av[4] = {a.x, a.y, a.z, a.w};
       float4 w[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         w[c] = wq[k4 % PF][c];
         if (k4 + PF < 8)
-          wq[k4 % PF][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 4 * (k4 + PF));
+          wq[k4 % PF][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 16 * (k4 + PF));
       }
       if (k4 + PF >= 8 && k4 + PF < 8 + PF)  // tail: start the second product's fragments
-        mw[k4 + PF - 8] = *reinterpret_cast<const float4 *>(mrow + 4 * (k4 + PF - 8));
+        mw[k4 + PF - 8] = *reinterpret_cast<const float4 *>(mrow + 16 * (k4 + PF - 8));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w[c].x, acc[c], 0, 0, 0);
@@ -270,9 +275,9 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     const float *arow = os + i16 * TL_OS + koff2;
 #pragma unroll
     for (int k4 = 0; k4 < 24; ++k4) {
-      const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * k4);
+      const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
       const float4 w = mw[k4 % PF];
-      if (k4 + PF < 24) mw[k4 % PF] = *reinterpret_cast<const float4 *>(mrow + 4 * (k4 + PF));
+      if (k4 + PF < 24) mw[k4 % PF] = *reinterpret_cast<const float4 *>(mrow + 16 * (k4 + PF));
       f32x4 &acc = (k4 & 1) ? acc1 : acc0;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
