@@ -192,17 +192,23 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
 #pragma unroll
       for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
       const float4 *ap = reinterpret_cast<const float4 *>(a_s + (size_t)g * NMAX * 8);
+      // the weights of node n + 1 are read (LDS broadcast) before node n's sixteen FMAs are
+      // issued: left to the compiler, every node started with an LDS round trip
+      float4 a0 = ap[0], a1 = ap[1];
 #pragma unroll
       for (int n = 0; n < NMAX; ++n) {
+        const float4 c0 = a0, c1 = a1;
+        if (n + 1 < NMAX) { a0 = ap[2 * n + 2]; a1 = ap[2 * n + 3]; }
+        __builtin_amdgcn_sched_barrier(0);
         if (n < N) {
-          const float4 a0 = ap[2 * n], a1 = ap[2 * n + 1];
-          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
           for (int h = 0; h < 8; ++h) {
             z[h].x = fmaf(av[h], e[gi][n].x, z[h].x);
             z[h].y = fmaf(av[h], e[gi][n].y, z[h].y);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int h = 0; h < 8; ++h)
