@@ -585,17 +585,27 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
 // Which kernel takes which graphs at step t.  The raw-tile kernel costs the same whatever the
 // mask, a table step costs one 32 N-byte row per selectable node: tile for graphs with at least
 // `thresh` selectable nodes (measured crossover, large batches), table below.
-static int tile_threshold() {
-  static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 18;
-  return v;
+static int tile_threshold(int N) {
+  static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 0;
+  if (v > 0) return v;
+  // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
+  // selectable node at B = 2048 against 56 us flat for the raw-tile kernel; N = 40 (large
+  // batches): 2.45 us per node against 87 us
+  return N > 64 ? (46 * N + 50) / 100 : 36;
 }
-// OFF by default: measured on MI355X the raw-tile kernel needs 97 us per step
-// at 8192 x 40 (tile loads 44, glimpse sums 15, weight folds 40 -- the 384 KB of folded weights
-// are re-read from L2 by every workgroup of 16 graphs, 24 KB per graph-step, more than the
-// tile itself) against 98 -> 19 us for the table kernel: it only wins the very first steps.
-static bool hybrid_shape(int B, int N) {
-  static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;  // A/B aid
-  return on && B > 2048 && N <= 40 && N > tile_threshold();
+// N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
+// bytes whatever the mask, and since its weight folds stream their fragments line by line
+// (decoder_tile.hip) the tile kernel wins the first half of an episode: VRP-100 x 2048
+// sampling 63 -> 49 us per step (each graph goes to one kernel by its own count; while the batch
+// straddles the threshold both kernels run, about seven steps of an episode).  N <= 40: off (VRP_TILE_HYBRID=1 turns it on for large
+// batches): 87 us flat against 98 -> 19 us for the table kernel, it would win five steps.
+// IRP stays with the table kernel: its capacity overlay leaves few nodes selectable and spreads
+// the graphs over the whole range, so both kernels would run at every step (64 vs 57 us).
+static bool hybrid_shape(int kind, int B, int N) {
+  static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
+  static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
+  if (N > 64) return !off && kind != VRP_KIND_IRP && vrp_tile_mfma_supported(N);
+  return on && B > 2048 && N <= 40 && N > tile_threshold(N);
 }
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
@@ -606,8 +616,11 @@ extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
-  if (hybrid_shape(B, N))
-    return "decode_step_tile_mfma_kernel<40, 2> | decode_step_rt_kernel<1, 4> (by selectable nodes)";
+  if (hybrid_shape(kind, B, N))
+    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
+                   : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
+                          ? "decode_step_tile_mfma_kernel<104, 1> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
+                          : "decode_step_tile_mfma_kernel<104, 1> | decode_step_rt_kernel<2, 4> (by selectable nodes)");
   const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
   if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
   return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";
@@ -635,12 +648,15 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     static const bool on = getenv("VRP_TILE_LARGE_N") != nullptr;  // A/B aid (67 vs 62 us at 2048 x 100)
     if (on) return vrp_launch_tile_mfma_step(p, st);
   }
-  if (hybrid_shape(B, N) && !p.decode_only) {
-    const int th = tile_threshold();
+  if (hybrid_shape(p.kind, B, N) && !p.decode_only) {
+    const int th = tile_threshold(N);
     // most selectable nodes any graph can have at step t (TSP: exactly N-1-t; VRP/IRP: a customer
-    // is served at least every other step, the depot may be open)
+    // is served at least every other step, the depot may be open), and fewest (VRP: the mask is
+    // the visited row and a step visits at most one customer; IRP: the capacity overlay can
+    // close any number of them)
     const int most = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t : N - (p.t + 1) / 2;
-    const int least = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t : 0;
+    const int least = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t
+                      : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - p.t) : 0);
     if (most < th) return launch_rt(p, flags, st);
     StepParams pt = p, pr = p;
     pt.sel_lo = th;

@@ -98,25 +98,37 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     if (!p.decode_only) { accl[gi] = p.io.acc_loss[b]; accp[gi] = p.io.acc_logp[b]; }
   };
 
+  // selectable nodes decide which kernel handles a graph at this step; a workgroup none of
+  // whose graphs is this kernel's leaves at once (hybrid dispatch launches both kernels while
+  // the batch straddles the threshold)
+  {
+    int any = 0;
+#pragma unroll
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int braw = blockIdx.x * GPB + wave * GPW + gi;
+      const bool active = braw < B;
+      const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
+      bg[gi] = b;
+      int nsel = 0;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const bool in = lane + 64 * i < N;
+        own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
+        nsel += __popcll(__ballot(in && !own_mask[gi][i]));
+      }
+      proc[gi] = active && nsel >= p.sel_lo && nsel < p.sel_hi;
+      any |= proc[gi] ? 1 : 0;
+    }
+    if (!__syncthreads_or(any)) return;
+  }
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
     const int g = wave * GPW + gi;
-    const int braw = blockIdx.x * GPB + g;
-    const bool active = braw < B;
-    const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
-    bg[gi] = b;
+    const int b = bg[gi];
     bool inN[NPL];
     int ln[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
-    // selectable nodes decide which kernel handles this graph at this step
-    int nsel = 0;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      own_mask[gi][i] = mask_in[(size_t)b * N + ln[i]];
-      nsel += __popcll(__ballot(inN[i] && !own_mask[gi][i]));
-    }
-    proc[gi] = active && nsel >= p.sel_lo && nsel < p.sel_hi;
     if (!proc[gi]) continue;  // wave-uniform
     // ---- loads: the tile (512-byte rows), score rows, masks, env row -----------------------
     {
