@@ -22,6 +22,7 @@ DECODE = ("decode_step_rt_kernel", "decode_persistent_kernel", "decode_step_tile
 def counter_sum(d, name):
     """(sum of the counter over all decode kernels, number of env steps they cover)"""
     total, launches, persistent = 0.0, 0, 0
+    tile_ids, rt_ids = set(), set()
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name or not any(k in r["Kernel_Name"] for k in DECODE):
@@ -31,6 +32,10 @@ def counter_sum(d, name):
                 persistent += 1
             elif "finalize" not in r["Kernel_Name"]:
                 launches += 1
+                (tile_ids if "tile" in r["Kernel_Name"] else rt_ids).add(int(r["Dispatch_Id"]))
+    # hybrid dispatch (N > 64) launches the raw-tile and the table kernel back to back for ONE
+    # env step while the batch straddles the threshold: such a pair is one step
+    launches -= sum(1 for i in tile_ids if i + 1 in rt_ids)
     return total, launches, persistent
 
 
