@@ -1529,6 +1529,98 @@ int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const
   return 0;
 }
 
+// ---- attention straight from the q|k|v rows in global memory (N > 64, and train mode) -----
+// Same products and softmax as qa8_stage_attention_mfma, one workgroup per graph, wave = head,
+// query tiles outermost so that only one row of score tiles is live (N <= 128: eight tiles).
+// K and V fragments of the head are loaded once per graph (16-byte / 4-byte pieces of the
+// 1536-byte q|k|v rows), Q per query tile.
+template <int NT>
+__global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float *__restrict__ qkv,
+                                                                      float *__restrict__ att, int N) {
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const float *base = qkv + (size_t)blockIdx.x * N * 384;
+  float *out = att + (size_t)blockIdx.x * N * VRP_EMB;
+  float4 kf[NT];
+  float vv[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    kf[t] = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * t + i16, N - 1) * 384 + 128 + h * 16 + 4 * q);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+      vv[t][r4] = base[(size_t)min(16 * t + 4 * q + r4, N - 1) * 384 + 256 + h * 16 + i16];
+  }
+#pragma unroll
+  for (int tm = 0; tm < NT; ++tm) {
+    if (16 * tm >= N) break;
+    const float4 a = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * tm + i16, N - 1) * 384 + h * 16 + 4 * q);
+    const float4 qf = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
+    f32x4v st[NT];  // st[tn][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      f32x4v d = {0.f, 0.f, 0.f, 0.f};
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].x, qf.x, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].y, qf.y, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].z, qf.z, d, 0, 0, 0);
+      d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].w, qf.w, d, 0, 0, 0);
+      st[tn] = d;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        if (16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[tn][r4]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float pw = (16 * tn + 4 * q + r4 < N) ? exp_nonpos(st[tn][r4] - mx) : 0.f;
+        st[tn][r4] = pw;
+        sum += pw;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // two chains (even / odd key tiles): a wave is alone with its dependent MFMAs here
+    f32x4v o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        f32x4v &o = (tn & 1) ? o1 : o0;
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[tn][r4], st[tn][r4], o, 0, 0, 0);
+      }
+    const int m = 16 * tm + i16;   // D[d = 4q + r4][m = i16]
+    if (m < N) {
+      const float inv = 1.f / sum;
+      *reinterpret_cast<float4 *>(out + (size_t)m * VRP_EMB + h * 16 + 4 * q) =
+          make_float4((o0[0] + o1[0]) * inv, (o0[1] + o1[1]) * inv, (o0[2] + o1[2]) * inv,
+                      (o0[3] + o1[3]) * inv);
+    }
+  }
+}
+
+static int launch_attention_mfma(const float *qkv, float *att, int B, int N, hipStream_t st) {
+  switch ((N + 15) / 16) {
+#define VRP_ATT_CASE(NT_)                                                                       \
+    case NT_:                                                                                   \
+      hipLaunchKernelGGL(encoder_attention_mfma_kernel<NT_>, dim3(B), dim3(512), 0, st, qkv, att, N); \
+      break;
+    VRP_ATT_CASE(1) VRP_ATT_CASE(2) VRP_ATT_CASE(3) VRP_ATT_CASE(4)
+    VRP_ATT_CASE(5) VRP_ATT_CASE(6) VRP_ATT_CASE(7) VRP_ATT_CASE(8)
+#undef VRP_ATT_CASE
+    default:
+      vrp_set_error("encoder attention: N=%d unsupported", N);
+      return 2;
+  }
+  VRP_CHECK_LAUNCH("encoder_attention_mfma");
+  return 0;
+}
+
 // ---- in_proj + attention of whole graphs in one launch, LARGE batches (eval mode) ----------
 // The projection GEMM wrote q|k|v (B*N x 384 fp32: 503 MB at 8192 x 40) only for the attention
 // kernel to read it back; here a workgroup takes G = 80 / N whole graphs (N = 40: two graphs =
@@ -1984,9 +2076,14 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
     } else {
       if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
                                      ws.qkv, 384, R, 384, 128, 0, st)) return r;
-      const size_t lds = (size_t)4 * N * 32 * sizeof(float);
-      hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
-      VRP_CHECK_LAUNCH("encoder_attention");
+      static const char *valu_att = getenv("VRP_ATTENTION_VALU");  // A/B aid
+      if (!valu_att) {
+        if (int r = launch_attention_mfma(ws.qkv, ws.att, B, N, st)) return r;
+      } else {
+        const size_t lds = (size_t)4 * N * 32 * sizeof(float);
+        hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
+        VRP_CHECK_LAUNCH("encoder_attention");
+      }
     }
     static const char *unfused = getenv("VRP_ENCODER_UNFUSED");  // A/B aid
     if (!train && !unfused) {
@@ -2155,9 +2252,14 @@ extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int
     float *out = (l + 1 < L_) ? t.layer[l + 1].X : emb;
     if (int r = vrp_launch_gemm_nt(T.X, 128, P.in_proj_weight, 128, P.in_proj_bias, nullptr, 0,
                                    T.QKV, 384, R, 384, 128, 0, st)) return r;
-    const size_t lds = (size_t)4 * N * 32 * sizeof(float);
-    hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, T.QKV, T.ATT, N);
-    VRP_CHECK_LAUNCH("encoder_attention");
+    static const char *valu_att = getenv("VRP_ATTENTION_VALU");  // A/B aid
+    if (!valu_att) {
+      if (int r = launch_attention_mfma(T.QKV, T.ATT, B, N, st)) return r;
+    } else {
+      const size_t lds = (size_t)4 * N * 32 * sizeof(float);
+      hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, T.QKV, T.ATT, N);
+      VRP_CHECK_LAUNCH("encoder_attention");
+    }
     if (int r = vrp_launch_gemm_nt(T.ATT, 128, P.out_proj_weight, 128, P.out_proj_bias, T.X, 128,
                                    T.Z1, 128, R, 128, 128, 0, st)) return r;
     if (int r = bn_train_taped(T.Z1, T.Y1, R, P.bn1_weight, P.bn1_bias, T.stats1,
