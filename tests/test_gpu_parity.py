@@ -176,10 +176,11 @@ def test_encoder_large_against_oracle():
     tiling of the fused eval-mode block kernel (16-row tiles x 2/3/4 up to 16384 rows, the
     64-row tile above); from 20480 rows on the persistent 80-row block kernel (ragged last
     tile) behind the fused in_proj+attention kernel (N = 37: two graphs per tile, N = 64: one,
-    four key tiles) or behind the GEMM + attention pair (N = 50)."""
+    four key tiles) or behind the GEMM + attention pair (N = 50); N = 113 / 128: seven / eight key
+    tiles of the attention kernel that reads q|k|v from global memory."""
     from oracle import policy as opol
     for kind, B, N in [(0, 37, 20), (2, 5, 100), (1, 300, 40), (0, 350, 40), (1, 901, 20),
-                       (0, 601, 37), (1, 450, 50), (2, 330, 64)]:
+                       (0, 601, 37), (1, 450, 50), (2, 330, 64), (0, 3, 128), (1, 7, 113)]:
         agent = _agents()[kind](seed=69)
         sd, _ = opol.init_state_dicts(kind, 69)
         g = torch.Generator().manual_seed(B * N)
