@@ -59,10 +59,14 @@ void run(int waves_per_simd, int blocks) {
   hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[1024]; hipMemcpy(h, cyc, 8 * blocks, hipMemcpyDeviceToHost);
-  const double per_simd = (double)iters * 8 * NACC * waves_per_simd;  // MFMAs issued per SIMD
-  const double flop = (KIND == 0 ? 2048.0 : 4096.0) * per_simd * 4 * blocks;
-  printf("%s nacc %d waves/SIMD %d blocks %d: %.1f cycles per MFMA per SIMD (s_memtime), %.1f TFLOP/s (events)\n",
-         KIND == 0 ? "16x16x4" : "32x32x2", NACC, waves_per_simd, blocks, (double)h[0] / per_simd,
+  const double per_wave = (double)iters * 8 * NACC;                   // MFMAs issued by one wave
+  const double flop = (KIND == 0 ? 2048.0 : 4096.0) * per_wave * waves_per_simd * 4 * blocks;
+  // wave 0 is the oldest wave of its SIMD: the arbiter serves it first, so its own rate stays
+  // one MFMA per 32 (64) cycles however many waves share the pipe; the chip-wide rate is the
+  // event-timed figure
+  printf("%s nacc %d waves/SIMD %d blocks %d: %.1f cycles per MFMA for the oldest wave (s_memtime), "
+         "%.1f TFLOP/s chip-wide (events)\n",
+         KIND == 0 ? "16x16x4" : "32x32x2", NACC, waves_per_simd, blocks, (double)h[0] / per_wave,
          flop / (ms * 1e-3) / 1e12);
   hipFree(out); hipFree(cyc);
 }
