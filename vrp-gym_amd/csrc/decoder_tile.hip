@@ -130,13 +130,10 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
 #pragma unroll
     for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
     if (!proc[gi]) continue;  // wave-uniform
-    // ---- loads: the tile (512-byte rows), score rows, masks, env row -----------------------
-    {
-      const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
-#pragma unroll
-      for (int n = 0; n < NMAX; ++n)
-        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
-    }
+    // ---- loads.  Order matters (they return in order): the score rows and masks first, then
+    // the first half of the tile; the glimpse weights are computed while the tile streams in,
+    // the second half is requested behind them and the sums below consume rows as they land.
+    constexpr int NH = NMAX / 2;
     const size_t row = (size_t)b * 8 * N;
     const float *srow = p.row0 + row;
     if (p.t > 0) {
@@ -145,19 +142,35 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     }
     const bool add_base = p.base && p.t > 0;
     load0[gi] = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+    float sv[NPL][8], bv_[NPL][8], sl_[NPL][8];
+    int mo[NPL][8];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        sv[i][h] = srow[h * N + ln[i]];
+        bv_[i][h] = add_base ? p.base[row + h * N + ln[i]] : 0.f;
+        sl_[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
+        mo[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
+      }
+    const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
+#pragma unroll
+    for (int n = 0; n < NH; ++n)
+      e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+    __builtin_amdgcn_sched_barrier(0);
     float sc[NPL][8];  // score + additive scrambled mask
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        float v = srow[h * N + ln[i]];
-        if (add_base) v += p.base[row + h * N + ln[i]];
-        if (p.kind == VRP_KIND_IRP) v = fmaf((float)load0[gi], p.SLD[row + h * N + ln[i]], v);
-        sc[i][h] = v + (float)mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
+        float v = sv[i][h];
+        if (add_base) v += bv_[i][h];
+        if (p.kind == VRP_KIND_IRP) v = fmaf((float)load0[gi], sl_[i][h], v);
+        sc[i][h] = v + (float)mo[i][h];
       }
     }
     if (!DEFER) load_env(gi, b);
-    if (p.dbg == 1) { if (e[gi][0].x + e[gi][NMAX - 1].y + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
+    if (p.dbg == 1) { if (e[gi][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
 
     // ---- glimpse attention weights (lane = n), one wave-wide shift for all eight heads -----
     {
@@ -195,6 +208,10 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
           if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
       }
     }
+#pragma unroll
+    for (int n = NH; n < NMAX; ++n)
+      e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+    __builtin_amdgcn_sched_barrier(0);
     // a_s of this graph is written and read by this wave only: LDS ops of one wave are ordered
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
