@@ -589,23 +589,26 @@ static int tile_threshold(int N) {
   static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 0;
   if (v > 0) return v;
   // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
-  // selectable node at B = 2048 against 56 us flat for the raw-tile kernel; N = 40 (large
-  // batches): 2.45 us per node against 87 us
-  return N > 64 ? (46 * N + 50) / 100 : 36;
+  // selectable node at B = 2048 against 54 us flat for the raw-tile kernel; N = 40 (large
+  // batches): 98 / 83 / 74 us for the first three steps, then ~72 for five more, against 72 us
+  return N > 64 ? (46 * N + 50) / 100 : N - 2;
 }
 // N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
 // bytes whatever the mask, and since its weight folds stream their fragments line by line
 // (decoder_tile.hip) the tile kernel wins the first half of an episode: VRP-100 x 2048
 // sampling 63 -> 49 us per step (each graph goes to one kernel by its own count; while the batch
-// straddles the threshold both kernels run, about seven steps of an episode).  N <= 40: off (VRP_TILE_HYBRID=1 turns it on for large
-// batches): 87 us flat against 98 -> 19 us for the table kernel, it would win five steps.
+// straddles the threshold both kernels run, about seven steps of an episode).
 // IRP stays with the table kernel: its capacity overlay leaves few nodes selectable and spreads
 // the graphs over the whole range, so both kernels would run at every step (64 vs 57 us).
 static bool hybrid_shape(int kind, int B, int N) {
   static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
   static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
   if (N > 64) return !off && kind != VRP_KIND_IRP && vrp_tile_mfma_supported(N);
-  return on && B > 2048 && N <= 40 && N > tile_threshold(N);
+  // N <= 40, large batches: only with VRP_TILE_HYBRID=1.  The tile kernel (72 us flat at
+  // 8192 x 40) beats the table kernel on the first two steps of a TSP episode (98 and 83 us), but
+  // measured end to end that is 43.7 against 44.0 us per step: not worth a second code path on
+  // the north-star shape.
+  return on && B > 2048 && N > 32 && N <= 40;
 }
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
