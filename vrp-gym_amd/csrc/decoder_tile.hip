@@ -414,18 +414,6 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
       }
       continue;
     }
-    // latency mode of the table kernel reads next step's row from `curs`: keep it current
-    if (B <= 2048 && !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
-      const size_t row = (size_t)b * 8 * N;
-      const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i)
-#pragma unroll
-        for (int h = 0; h < 8; ++h)
-          if (inN[i])
-            p.curs[row + h * N + lane + 64 * i] =
-                arow[h * N + lane + 64 * i] + (p.base ? p.base[row + h * N + lane + 64 * i] : 0.f);
-    }
     // ---- env.step on registers (same operation order as env_device.h) -------------------
     auto node_f64 = [&](const double (&v)[NPL], int n) {
       return (NPL > 1 && n >= 64) ? readlane_f64(v[NPL - 1], n - 64) : readlane_f64(v[0], n);
@@ -463,6 +451,7 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
 #pragma unroll
       for (int i = 0; i < NPL; ++i) if (lane + 64 * i == de) vs[i] = 0;
     }
+    int nsel_next = 0;   // selectable nodes of the next step
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       int mk = vs[i];
@@ -471,6 +460,7 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
         p.env.visited[(size_t)b * N + lane + 64 * i] = (uint8_t)vs[i];
         mask_out[(size_t)b * N + lane + 64 * i] = (uint8_t)mk;
       }
+      nsel_next += __popcll(__ballot(inN[i] && !mk));
     }
     if (lane == 0) {
       p.env.cur[b] = idx;
@@ -482,6 +472,24 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
       if (!done) p.io.notdone[p.t] = 1;
       if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
       if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
+    }
+    // (last: a register reload from scratch behind these stores would wait for them to land)
+    // latency mode of the table kernel reads next step's row from `curs`: keep it current
+    // -- only when the graph's next step can be the table kernel's: under per-graph routing
+    // (sel_lo > 0) a graph that keeps at least sel_lo selectable nodes comes back to this
+    // kernel, which reads SL and base itself (the update costs 7 us per step at 2048 x 100:
+    // 3.2 KB of table row per graph from HBM, at the very end of the workgroup)
+    if (B <= 2048 && (p.sel_lo <= 0 || nsel_next < p.sel_lo) &&
+        !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
+      const size_t row = (size_t)b * 8 * N;
+      const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+          if (inN[i])
+            p.curs[row + h * N + lane + 64 * i] =
+                arow[h * N + lane + 64 * i] + (p.base ? p.base[row + h * N + lane + 64 * i] : 0.f);
     }
   }
 }
