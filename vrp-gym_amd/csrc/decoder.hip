@@ -589,14 +589,15 @@ static int tile_threshold(int N) {
   static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 0;
   if (v > 0) return v;
   // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
-  // selectable node at B = 2048 against 54 us flat for the raw-tile kernel; N = 40 (large
-  // batches): 98 / 83 / 74 us for the first three steps, then ~72 for five more, against 72 us
-  return N > 64 ? (46 * N + 50) / 100 : N - 2;
+  // selectable node at B = 2048 against 45-53 us flat for the raw-tile kernel (the mean step
+  // of an episode is within 1 % for thresholds of 34..42 nodes); N = 40 (large batches):
+  // 98 / 83 / 74 us for the first three steps, then ~72 for five more, against 72 us
+  return N > 64 ? (40 * N + 50) / 100 : N - 2;
 }
 // N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
 // bytes whatever the mask, and since its weight folds stream their fragments line by line
 // (decoder_tile.hip) the tile kernel wins the first half of an episode: VRP-100 x 2048
-// sampling 63 -> 49 us per step (each graph goes to one kernel by its own count; while the batch
+// sampling 63 -> 42 us per step (each graph goes to one kernel by its own count; while the batch
 // straddles the threshold both kernels run, about seven steps of an episode).
 // IRP stays with the table kernel: its capacity overlay leaves few nodes selectable and spreads
 // the graphs over the whole range, so both kernels would run at every step (64 vs 57 us).
