@@ -158,6 +158,9 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
 #define VRP_STEP_NO_FIRST_ROW 8 /* t == 0: the caller runs vrp_decode_first_row itself */
 #define VRP_STEP_THROUGHPUT_KERNEL 16 /* B <= 2048: use the large-batch variant (4 graphs per
                                          workgroup, score row read by pointer chase) anyway */
+#define VRP_STEP_TABLE_KERNEL 64 /* table-driven kernel for every graph, also where the dispatch
+                                    would route graphs with many selectable nodes to the raw-tile
+                                    kernel (64 < N <= 104) */
 #define VRP_STEP_NO_PERSISTENT 32 /* vrp_rollout / vrp_rollout_steps[_range]: one launch per step
                                      even where the persistent multi-step kernel applies (B <= 2048,
                                      3 <= N <= 63, no logits trace, no teacher forcing) */
@@ -184,7 +187,7 @@ int vrp_decode_first_row(int kind, const void *derived, int B, int N, const floa
  * encoder, prologue and max_steps decode+env steps, all on `stream`.
  * emb (B,N,128) receives the node embeddings.  max_steps >= 2(N-1) (N-1 for TSP).
  * `sample` carries the step flags VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL |
- * VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_NO_PERSISTENT. */
+ * VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_TABLE_KERNEL | VRP_STEP_NO_PERSISTENT. */
 int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
                 void *derived, const vrp_env *env, int train, int sample,
                 float *emb, void *enc_workspace, void *dec_workspace,

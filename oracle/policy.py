@@ -272,7 +272,11 @@ def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
     done, T = False, 0
     while not done:
         u = ep.logits(mask, load)
-        noise = noise_fn(T, u) if (noise_fn is not None and not greedy) else None
+        noise = None
+        if not greedy:
+            # same draw (shape, dtype, stream position) as Categorical.sample's
+            # multinomial, graph_decoder.py:105-106; kept in the trace for the tests
+            noise = noise_fn(T, u) if noise_fn is not None else torch.empty_like(u).exponential_(1)
         idx, logp = ep.choose(u, greedy, noise)
         if forced is not None:
             idx = torch.as_tensor(forced[T], dtype=torch.long)
@@ -281,7 +285,8 @@ def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
         ep.advance(idx)
         if trace is not None:
             trace.append({"u": u.detach().clone(), "idx": idx.clone(),
-                          "logp": logp.detach().clone(), "mask": mask.clone()})
+                          "logp": logp.detach().clone(), "mask": mask.clone(),
+                          "noise": noise})
         _, reward, done, _ = env.step(idx[:, None].numpy())
         acc_loss = acc_loss + torch.tensor(reward, dtype=torch.float)
         acc_logp = acc_logp + logp

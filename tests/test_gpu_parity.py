@@ -229,15 +229,19 @@ def test_gemm_mfma_against_torch():
 
 
 # ------------------------------------------------------------------ D1-D6: decoder
+@pytest.mark.parametrize("step_flags", [0, 16, 4], ids=["table", "table_wide", "tile"])
 @pytest.mark.parametrize("name,path", _load("decoder_*.npz"))
-def test_decoder_teacher_forced(name, path):
+def test_decoder_teacher_forced(name, path, step_flags):
     """GraphDecoder.forward (decode-only kernel) on the reference's inputs: same
     action, log-prob within 1e-5, for greedy and (host-noise) sampled steps, with B
-    not a multiple of 8 and B < 8 (the scrambled-mask indexing)."""
+    not a multiple of 8 and B < 8 (the scrambled-mask indexing).  Every step kernel:
+    decode_step_rt_kernel<NPL,1>, <NPL,4> and the raw-tile kernel; the N = 100 file runs
+    their two-nodes-per-lane instances."""
     z = np.load(path)
     kind = int(z["kind"])
     agent = _agents()[kind](seed=69)
     dec = agent.model.decoder
+    dec.step_flags = step_flags
     dec.reset()
     emb = torch.tensor(z["emb"])
     for t in range(z["mask"].shape[0]):
@@ -253,11 +257,28 @@ def test_decoder_teacher_forced(name, path):
 
 
 # ------------------------------------------------------------------ R1: rollouts
+def _log_roots(*row):
+    """Survey aid: with VRPGYM_PARITY_LOG=<file> every comparison appends its tie statistics
+    (the bound asserted in _compare_rollout rests on these)."""
+    path = os.environ.get("VRPGYM_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(",".join(str(v) for v in row) + "\n")
+
+
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
                      ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
-                     throughput_kernel=False, agent=None):
+                     throughput_kernel=False, table_kernel=False, agent=None):
     """HIP rollout vs oracle (and vs reference outputs when given).  `agent`: use this
-    (e.g. trained) agent's weights on both sides instead of the seed's initial ones."""
+    (e.g. trained) agent's weights on both sides instead of the seed's initial ones.
+
+    Actions are compared for greedy AND sampled rollouts.  Along the HIP action path (the
+    oracle teacher-forced on it, same host noise) every HIP choice must be the oracle's
+    choice up to a near tie: greedy = top-2 logit gap < TIE_GAP; sampled = the chosen node's
+    softmax(u)/q within a relative TIE_GAP of the maximum (Categorical.sample is
+    argmax(p/q), graph_decoder.py:104-107; p ~ exp(u), so a relative gap in p/q is an
+    absolute gap in u).  The number of graphs that took a near-tie runner-up is bounded, and
+    without one the free-running action sequences must be identical."""
     from oracle import envs as oenv
     from oracle import policy as opol
     from agents import runtime
@@ -279,7 +300,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     with torch.no_grad():
         res = runtime.rollout(model, deepcopy(env), greedy, train=train, trace=True,
                               noise_mode="host", tile_kernel=tile_kernel,
-                              throughput_kernel=throughput_kernel)
+                              throughput_kernel=throughput_kernel, table_kernel=table_kernel)
     T = res.T
     acts = res.actions[:T].cpu().numpy()
 
@@ -296,28 +317,41 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     forced_trace = trace
     if div_oracle or T != oT:
         # the oracle follows the HIP actions; every divergence must sit on a near tie of the
-        # oracle's own logits at that step
+        # oracle's own logits (greedy) / ratios p/q (sampled) at that step
         forced_trace = []
-        torch.manual_seed(torch_seed)
+        torch.manual_seed(torch_seed)   # same noise stream: one (B,N) draw per step
         with torch.no_grad():
             ol, olp, oT2 = opol.rollout(sd, deepcopy(oe), greedy, train=train,
                                         trace=forced_trace, forced=acts)
         assert oT2 == T
     div_ref = diverged(ref_actions) if ref_actions is not None else {}
+    # Along the HIP action path the oracle must agree with every HIP choice up to a near
+    # tie.  (A graph may also leave the free-running oracle's path WITHOUT a tie of its own:
+    # the scrambled glimpse mask couples it to graphs that flipped earlier.)
+    U = torch.stack([st["u"] for st in forced_trace])                   # (T,B,N)
+    A = torch.as_tensor(acts)[:, :, None]
     if greedy:
-        # Along the HIP action path the oracle must agree with every HIP choice up to a
-        # near tie.  (A graph may also leave the free-running oracle's path WITHOUT a tie of
-        # its own: the scrambled glimpse mask couples it to graphs that flipped earlier.)
-        U = torch.stack([st["u"] for st in forced_trace])               # (T,B,N)
-        chosen = U.gather(2, torch.as_tensor(acts)[:, :, None])[..., 0]
-        slack = U.max(dim=2).values - chosen
-        assert slack.max().item() < TIE_GAP, slack.max().item()
-        roots = int((slack > 0).any(dim=0).sum())                       # graphs with a tie flip
-        assert roots <= max(2, B // 20), f"{roots} of {B} graphs chose a near-tie runner-up"
-        if not roots:
-            assert not div_oracle, "diverged from the oracle without any near tie"
+        slack = U.max(dim=2).values - U.gather(2, A)[..., 0]
+    else:
+        Q = torch.stack([st["noise"] for st in forced_trace])
+        ratio = torch.softmax(U - U.logsumexp(-1, keepdim=True), dim=-1) / Q
+        best = ratio.max(dim=2).values
+        slack = (best - ratio.gather(2, A)[..., 0]) / best              # relative
+    # train-mode BatchNorm noise on the logits reaches 7.4e-5 (see below): twice the gap
+    gap = TIE_GAP * (2 if train else 1)
+    assert slack.max().item() < gap, slack.max().item()
+    roots = int((slack > 0).any(dim=0).sum())                           # graphs with a tie flip
+    _log_roots(kind, B, N, greedy, train, tile_kernel, throughput_kernel, table_kernel, roots,
+               slack.max().item(), len(div_oracle), len(div_ref))
+    assert roots <= max(1, B // 100), f"{roots} of {B} graphs chose a near-tie runner-up"
+    if not roots:
+        assert not div_oracle, "diverged from the oracle without any near tie"
+        assert T == oT
     if ref_T is not None and not div_ref:
         assert T == ref_T
+    if ref_actions is not None:
+        # the reference's own actions: only graphs coupled to a tie flip may differ
+        assert len(div_ref) == 0 or roots > 0, f"{len(div_ref)} graphs left the reference's path"
     exempt = np.zeros(B, bool)
     exempt[list(div_ref)] = True
     loss, logp = res.acc_loss.cpu(), res.acc_logp.cpu()
@@ -328,43 +362,42 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         ok = ~exempt
         assert np.max(np.abs(loss.numpy() - ref_loss)[ok]) < TOL
         assert np.max(np.abs(logp.numpy() - ref_logp)[ok]) < TOL * (1 if greedy else max(1, T / 4))
-    trace = forced_trace
-    exempt[:] = False
     # per-step logits along the same action path
-    if not exempt.any():
-        for t in range(T):
-            u = res.logits[t].cpu()
-            ou = trace[t]["u"]
-            fin = torch.isfinite(ou)
-            assert torch.equal(fin, torch.isfinite(u)), t
-            # logits live in [-10, 10]; train-mode BatchNorm (batch statistics of rounded
-            # activations) amplifies fp32 re-association noise: up to 7.4e-5 seen in a 480-case sweep (tools/parity_sweep.py), 2e-5 in eval mode
-            assert (u[fin] - ou[fin]).abs().max().item() < (1e-4 if train else 2e-5), \
-                (t, (u[fin] - ou[fin]).abs().max())
-        if not greedy:
-            # north_star: log-prob within 1e-5 -- held PER STEP (log p(a_t) of every sampled
-            # action, eval mode); the accumulated sum of T such terms is therefore bounded by
-            # T x 1e-5 and checked above at the tighter 1e-5 x max(1, T/4).  Train mode: the
-            # batch-statistics BatchNorm noise on the logits (see above) carries over.
-            slp = res.step_logp[:T].cpu()
-            olp_t = torch.stack([st["logp"] for st in trace])
-            worst = (slp - olp_t).abs().max().item()
-            assert worst < (5e-5 if train else TOL), worst
+    for t in range(T):
+        u = res.logits[t].cpu()
+        ou = forced_trace[t]["u"]
+        fin = torch.isfinite(ou)
+        assert torch.equal(fin, torch.isfinite(u)), t
+        # logits live in [-10, 10]; train-mode BatchNorm (batch statistics of rounded
+        # activations) amplifies fp32 re-association noise: up to 7.4e-5 seen in a 480-case sweep (tools/parity_sweep.py), 2e-5 in eval mode
+        assert (u[fin] - ou[fin]).abs().max().item() < (1e-4 if train else 2e-5), \
+            (t, (u[fin] - ou[fin]).abs().max())
+    if not greedy:
+        # north_star: log-prob within 1e-5 -- held PER STEP (log p(a_t) of every sampled
+        # action, eval mode); the accumulated sum of T such terms is therefore bounded by
+        # T x 1e-5 and checked above at the tighter 1e-5 x max(1, T/4).  Train mode: the
+        # batch-statistics BatchNorm noise on the logits (see above) carries over.
+        slp = res.step_logp[:T].cpu()
+        olp_t = torch.stack([st["logp"] for st in forced_trace])
+        worst = (slp - olp_t).abs().max().item()
+        assert worst < (5e-5 if train else TOL), worst
     return res, exempt
 
 
-@pytest.mark.parametrize("tile_kernel", [False, True, "wide"], ids=["table", "tile", "table_wide"])
+@pytest.mark.parametrize("mode", ["default", "table", "table_wide", "tile"])
 @pytest.mark.parametrize("name,path", _load("rollout_*.npz"))
-def test_rollout_against_reference(name, path, tile_kernel):
-    """All step kernels: table-driven in its latency mode (default up to B = 2048) and in
-    its large-batch mode (forced here), and the raw-tile formulation."""
-    wide = tile_kernel == "wide"
-    tile_kernel = tile_kernel is True
+def test_rollout_against_reference(name, path, mode):
+    """Every step kernel against the reference's recorded rollouts, greedy and sampled: the
+    default dispatch (persistent kernel at N <= 63; at 64 < N <= 104 each graph goes to the
+    raw-tile or the table kernel by its number of selectable nodes), the table-driven kernel
+    for every graph in its latency mode (`table`: decode_step_rt_kernel<NPL,1>) and in its
+    large-batch mode (`table_wide`: <NPL,4>), and the raw-tile formulation for every graph."""
     z = np.load(path)
     _compare_rollout(int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"]), 69, 69,
                      int(z["torch_seed"]), ref_actions=z["actions"], ref_loss=z["acc_loss"],
-                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=tile_kernel,
-                     throughput_kernel=wide)
+                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=mode == "tile",
+                     throughput_kernel=mode == "table_wide",
+                     table_kernel=mode in ("table", "table_wide"))
 
 
 @pytest.mark.parametrize("kind,B,N,greedy,train", [
@@ -379,7 +412,9 @@ def test_rollout_against_reference(name, path, tile_kernel):
 ])
 def test_rollout_against_oracle(kind, B, N, greedy, train):
     _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train)
-    _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, throughput_kernel=True)
+    _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, table_kernel=True)
+    _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, throughput_kernel=True,
+                     table_kernel=True)
     if N <= 104:  # the raw-tile kernel (opt-in flag) stays covered at every size it supports
         _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
 

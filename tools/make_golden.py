@@ -210,7 +210,7 @@ def gen_encoder():
 def gen_decoder():
     print("[decoder]")
     gen = torch.Generator().manual_seed(4242)
-    for kind, B, N in [(0, 13, 7), (0, 5, 20), (2, 13, 7), (1, 64, 20)]:
+    for kind, B, N in [(0, 13, 7), (0, 5, 20), (2, 13, 7), (1, 64, 20), (1, 13, 100)]:
         ag = REF_AGENT[kind](seed=69)
         dec = ag.model.decoder
         dec.reset()
@@ -255,12 +255,18 @@ def gen_decoder():
 
 
 # ---------------------------------------------------------------- (vi) rollouts
+STATS = []   # oracle-vs-reference deviations seen while generating (written to
+             # tests/golden/oracle_vs_reference.json by the `rollouts` target)
+
+
 def gen_rollouts():
     print("[rollouts]")
     for kind, B, N, greedy in [(0, 2, 4, True), (1, 2, 4, True), (2, 2, 4, True),
                                (0, 64, 20, True), (1, 64, 20, True), (2, 64, 20, True),
                                (0, 32, 10, False), (1, 32, 10, False), (2, 32, 10, False),
-                               (1, 13, 7, True)]:
+                               (1, 13, 7, True),
+                               # sampled episodes on the two-nodes-per-lane kernels (N > 64)
+                               (1, 24, 100, False), (0, 16, 70, False)]:
         ag = REF_AGENT[kind](seed=69)
         env = REF_ENV[kind](N, B, 1, 69)
         ag.model.eval()
@@ -272,6 +278,16 @@ def gen_rollouts():
             return _o(a)
 
         env.step = rec_step
+        # per-step log-probs of the reference (for the oracle-vs-reference statistics)
+        step_lp = []
+        dec_fwd = ag.model.decoder.forward
+
+        def rec_fwd(*a, _f=dec_fwd, _lp=step_lp, **k):
+            idx, lp = _f(*a, **k)
+            _lp.append(lp.detach().reshape(-1).clone())
+            return idx, lp
+
+        ag.model.decoder.forward = rec_fwd
         torch.manual_seed(77)
         with torch.no_grad():
             loss, logp = ag.model(env, greedy)
@@ -300,18 +316,31 @@ def gen_rollouts():
             # teacher-forced replay must then agree everywhere
             oe = oenv.OracleEnv(kind, N, B, 1, 69)
             torch.manual_seed(77)
+            trace = []
             with torch.no_grad():
-                ol, olp, T = opol.rollout(sd, oe, greedy, forced=racts)
+                ol, olp, T = opol.rollout(sd, oe, greedy, forced=racts, trace=trace)
             assert T == len(racts)
         el = (ol - loss).abs().max().item()
         ep = (olp - logp).abs().max().item()
+        # per-step |dlogp| (sampled episodes): the tests' per-step 1e-5 and accumulated
+        # 1e-5 * max(1, T/4) tolerances rest on these numbers
+        eps = max(((trace[t]["logp"] - step_lp[t]).abs().max().item() for t in range(len(acts))),
+                  default=0.0) if not greedy else 0.0
         print(f"   kind={kind} B={B} N={N} greedy={greedy}: T={len(acts)} "
               f"actions_equal={same} near_tie_graphs={ntie} |dloss|={el:.2e} "
-              f"|dlogp|={ep:.2e} mean={loss.mean().item()!r}")
-        assert el < 1e-5 and ep < 1e-5
+              f"|dlogp|={ep:.2e} per-step |dlogp|={eps:.2e} max|logp|={logp.abs().max().item():.1f} "
+              f"mean={loss.mean().item()!r}")
+        STATS.append({"case": f"rollout_k{kind}_B{B}_N{N}_{'greedy' if greedy else 'sample'}",
+                      "T": len(acts), "actions_equal": bool(same), "near_tie_graphs": ntie,
+                      "dloss": el, "dlogp_accumulated": ep, "dlogp_per_step": eps,
+                      "max_abs_logp": logp.abs().max().item()})
+        assert el < 1e-5 and eps < 1e-5 and ep < 1e-5 * max(1, len(acts) / 4)
         save(f"rollout_k{kind}_B{B}_N{N}_{'greedy' if greedy else 'sample'}",
              kind=kind, B=B, N=N, greedy=greedy, torch_seed=77, T=len(acts),
              actions=np.array(acts), acc_loss=loss.numpy(), acc_logp=logp.numpy())
+    import json
+    with open(os.path.join(OUT, "oracle_vs_reference.json"), "w") as f:
+        json.dump(STATS, f, indent=1)
 
 
 # ---------------------------------------------------------------- KATs of the reference's tests

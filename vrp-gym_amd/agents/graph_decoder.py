@@ -18,6 +18,7 @@ class GraphDecoder(nn.Module):
         self._context_proj = nn.Linear(emb_dim * 2 + 1, emb_dim * 3, bias=False)
         self.num_heads = num_heads
         self._episode = None
+        self.step_flags = 0   # VRP_STEP_* kernel-selection bits for forward() (tests, A/B)
         # other sizes can be constructed (state_dict compatibility) but the HIP kernels are
         # specialised for the reference's architecture: running them raises in runtime.py
         self.hip_supported = runtime.check_supported_dims(emb_dim, num_heads, None, decoder=True)

@@ -230,7 +230,9 @@ def decoder_step(dec, node_embs, mask, load, greedy):
     actions = torch.empty((1, B), dtype=torch.int64, device=dev)
     logp = torch.zeros((1, B), dtype=torch.float32, device=dev)
     io = hip.RolloutIO()
-    flags = 2  # VRP_STEP_DECODE_ONLY
+    # VRP_STEP_DECODE_ONLY | kernel selection bits (tests: dec.step_flags = 4 raw-tile kernel,
+    # 16 large-batch table kernel; default 0 = the dispatch's own choice)
+    flags = 2 | (int(getattr(dec, "step_flags", 0)) & (4 | 16 | 64))
     noise = None
     if not greedy:
         noise = torch.empty((B, N)).exponential_(1).to(dev)  # default CPU generator, like
@@ -394,16 +396,18 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
 
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
             noise_mode="device", tile_kernel=False, use_graph=None, record=False,
-            throughput_kernel=False, persistent=True, step_trace=False):
+            throughput_kernel=False, persistent=True, step_trace=False, table_kernel=False):
     """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU.
     trace: keep actions, per-step logits and log-probs (the logits trace needs one launch per
     step); step_trace: actions and per-step log-probs only; persistent=False: one launch per
-    step even where the persistent multi-step kernel applies (A/B and tests)."""
+    step even where the persistent multi-step kernel applies (A/B and tests); table_kernel:
+    the table-driven step kernel for every graph (no per-graph routing to the raw-tile one)."""
     dev = _require_cuda(model)
     if use_graph is None:
         use_graph = USE_GRAPHS
     if (use_graph and forced is None and noise is None and not trace and not record
-            and not throughput_kernel and (greedy or noise_mode == "device")):
+            and not throughput_kernel and not table_kernel
+            and (greedy or noise_mode == "device")):
         if str(env._device) != str(dev):
             raise RuntimeError(f"env is on {env._device} but the model on {dev}")
         env._sync_positions()
@@ -478,7 +482,7 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._parity = 0
     cenv = env._cenv()
     flags = (int(not greedy) | (4 if tile_kernel else 0) | (16 if throughput_kernel else 0) |
-             (0 if persistent else 32))
+             (0 if persistent else 32) | (64 if table_kernel else 0))
     tape = x3 = dmask = None
     if record and train:
         # the pieces of vrp_rollout with the taped encoder: the backward pass reuses the

@@ -118,6 +118,6 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
                                      stream)) return r;
   // `sample` doubles as the step flags
   return rollout_step_loop(kind, derived, dw, env, emb, dec_workspace, io, max_steps,
-                           sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL |
+                           sample & (VRP_STEP_SAMPLE | VRP_STEP_TILE_KERNEL | VRP_STEP_TABLE_KERNEL |
                                      VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_NO_PERSISTENT), stream);
 }

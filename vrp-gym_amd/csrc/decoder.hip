@@ -620,7 +620,7 @@ extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
-  if (hybrid_shape(kind, B, N))
+  if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
     return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
                    : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
                           ? "decode_step_tile_mfma_kernel<104, 1> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
@@ -652,7 +652,7 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     static const bool on = getenv("VRP_TILE_LARGE_N") != nullptr;  // A/B aid (67 vs 62 us at 2048 x 100)
     if (on) return vrp_launch_tile_mfma_step(p, st);
   }
-  if (hybrid_shape(p.kind, B, N) && !p.decode_only) {
+  if (hybrid_shape(p.kind, B, N) && !p.decode_only && !(flags & VRP_STEP_TABLE_KERNEL)) {
     const int th = tile_threshold(N);
     // most selectable nodes any graph can have at step t (TSP: exactly N-1-t; VRP/IRP: a customer
     // is served at least every other step, the depot may be open), and fewest (VRP: the mask is
