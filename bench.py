@@ -90,7 +90,7 @@ def spawn_ranks(a, argv):
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None if absent."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return json.load(fh)["workloads"][workload]["hbm_bytes_per_launch"]
@@ -132,9 +132,12 @@ def sync_barrier(dist):
     torch.cuda.synchronize()
 
 
-def timed_rollouts(env, agent, greedy, steps, warmup, dist, reset=None):
-    """K rollouts between barrier + synchronize brackets.  reset=None: instances stay
-    resident (the headline); "env": env.reset() (new instances) before every rollout."""
+def timed_rollouts(env, agent, greedy, steps, warmup, dist, reset=None, blocks=1):
+    """`blocks` blocks of EXACTLY K rollouts, each between barrier + synchronize brackets (a
+    block of 20 TSP-20 rollouts is 6 ms: one clock ramp moves it by 8 %, so the headline is the
+    median block and the spread is reported).  reset=None: instances stay resident (the
+    headline); "env": env.reset() (new instances) before every rollout.
+    Returns (list of block seconds, T, mean tour cost)."""
     from agents import runtime
 
     def one():
@@ -144,17 +147,18 @@ def timed_rollouts(env, agent, greedy, steps, warmup, dist, reset=None):
             rewind(env)
         return runtime.rollout(agent.model, env, greedy)
 
-    res = None
+    res, dts = None, []
     with torch.no_grad():
         for _ in range(max(warmup, 1)):
             res = one()
-        sync_barrier(dist)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            res = one()
-        sync_barrier(dist)
-        dt = time.perf_counter() - t0
-    return dt, res.T, float(-res.acc_loss.mean().item())
+        for _ in range(blocks):
+            sync_barrier(dist)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = one()
+            sync_barrier(dist)
+            dts.append(time.perf_counter() - t0)
+    return dts, res.T, float(-res.acc_loss.mean().item())
 
 
 def timed_training(env, agent, steps, warmup, dist):
@@ -320,6 +324,66 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
     return out
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md; = vector peak)
+
+
+def encoder_roofline(kind, N, B, device, reps=20):
+    """The encoder phase of the rollout (vrp_rollout_encode: set-up + all layers; ONE launch,
+    encoder_stack_kernel<3>, for small eval-mode batches) against the fp32 MFMA peak.
+    Flops = B*N*(1 180 160 + 1 536 N) (projections, attention, feed-forward of
+    three layers); time = HIP events around the launches on the library's stream."""
+    import ctypes as C
+    import vrpgym_hip as hip
+    from agents import runtime
+    env, agent = make(kind, N, B, 69, device)
+    lib = hip.lib()
+    model = agent.model
+    with torch.no_grad():
+        res = runtime.rollout(model, env, True)
+    ew = runtime.encoder_struct(model.encoder)
+    derived = runtime.decoder_derived(model.decoder, kind)
+    enc_ws, dec_ws = runtime.workspaces(model, env)
+    io = hip.RolloutIO()
+    io.acc_loss, io.acc_logp = res.acc_loss.data_ptr(), res.acc_logp.data_ptr()
+    io.notdone = res.notdone.data_ptr()
+    stream = hip.current_stream(device)
+    ts = []
+    for i in range(reps + 3):
+        rewind(env)
+        cenv = env._cenv()
+        e0, e1 = _event(), _event()
+        e0.record()
+        hip.check(lib.vrp_rollout_encode(kind, C.byref(ew), derived.data_ptr(), C.byref(cenv), 0,
+                                         res.emb.data_ptr(), enc_ws.data_ptr(), dec_ws.data_ptr(),
+                                         C.byref(io), res.max_steps, stream))
+        e1.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+    avg = float(np.mean(ts))
+    flops = B * N * (1180160 + 1536 * N)
+    name = lib.vrp_encoder_kernel_name(C.byref(ew), 0, B, N)
+    return {"bound": "mfma", "kernel": name.decode() if name else "?",
+            "workload": f"kind{kind}_N{N}_B{B}", "achieved": round(flops / avg / 1e12, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / avg / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(avg * 1e6, 2),
+            "timer": "HIP events around vrp_rollout_encode (one launch for small eval-mode "
+                     "batches; the per-layer kernels otherwise)",
+            "launches_timed": reps}
+
+
+def device_identity(device):
+    """What tells two GPUs apart: uuid / PCI bus id where torch exposes them."""
+    p = torch.cuda.get_device_properties(device)
+    ident = {"index": device.index, "name": p.name}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(p, key, None)
+        if v is not None:
+            ident[key] = str(v)
+    return ident
+
+
 def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
     """The CPU oracle (a port of the reference's algorithm: vectorised numpy env +
     torch-CPU fp32 policy) on this host's cores, same workload, bounded sample.  The ops of a
@@ -359,8 +423,9 @@ def cpu_baseline(kind, N, B, greedy, budget_s=15.0):
                       f"BASELINE.md section 3)"}
 
 
-def run_workload(name, steps, warmup, device, dist, rank, world):
-    """One workload on this rank -> dict of whole-job figures (rank-reduced)."""
+def run_workload(name, steps, warmup, device, dist, rank, world, blocks=1):
+    """One workload on this rank -> dict of whole-job figures (rank-reduced).  Per block the
+    time is the MAX over ranks; `seconds` is the median block."""
     kind, N, B, mode = WORKLOADS[name]
     shard = (rank, world) if world > 1 else None
     train = mode == "train"
@@ -372,6 +437,7 @@ def run_workload(name, steps, warmup, device, dist, rank, world):
         distributed.broadcast_model(agent.model)
         distributed.broadcast_model(agent.target_model)
         dt, sum_T, rollouts, cost, ar_ms = timed_training(env, agent, steps, warmup, dist)
+        dts = [dt]
         graph_steps = sum_T * B
         node_steps = graph_steps * N
         T = round(sum_T / max(steps * rollouts, 1), 2)
@@ -379,21 +445,37 @@ def run_workload(name, steps, warmup, device, dist, rank, world):
                  "grad_bucket_bytes": 4 * sum(p.numel() for p in agent.model.parameters()
                                               if p.grad is not None)}
     else:
-        dt, T, cost = timed_rollouts(env, agent, mode == "greedy", steps, warmup, dist)
+        dts, T, cost = timed_rollouts(env, agent, mode == "greedy", steps, warmup, dist,
+                                      blocks=blocks)
         graph_steps = steps * B * T
         node_steps = graph_steps * N
-    red = torch.tensor([dt, cost, float(node_steps), float(graph_steps)], device=device,
+    red = torch.tensor([cost, float(node_steps), float(graph_steps)], device=device,
                        dtype=torch.float64)
-    tmax = red[:1].clone()
+    mine = torch.tensor(dts, device=device, dtype=torch.float64)
+    tmax, tmin = mine.clone(), mine.clone()
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
-    tmax = float(tmax.item())
+    per_block = sorted(tmax.tolist())
+    med = per_block[len(per_block) // 2] if len(per_block) % 2 else \
+        0.5 * (per_block[len(per_block) // 2 - 1] + per_block[len(per_block) // 2])
+    ms = lambda sec: round(sec / steps * 1e3, 4)  # noqa: E731
     out = {"name": name, "kind": kind, "N": N, "B": B, "mode": mode, "T": T,
-           "seconds": tmax, "ms_per_step": round(tmax / steps * 1e3, 4),
-           "node_steps_per_s": round(float(red[2].item()) / tmax, 1),
-           "graph_steps_per_s": round(float(red[3].item()) / tmax, 1),
-           "mean_tour_cost": round(float(red[1].item()) / world, 6)}
+           "seconds": med, "ms_per_step": ms(med),
+           "node_steps_per_s": round(float(red[1].item()) / med, 1),
+           "graph_steps_per_s": round(float(red[2].item()) / med, 1),
+           "mean_tour_cost": round(float(red[0].item()) / world, 6)}
+    if len(per_block) > 1 or world > 1:
+        # blocks: max-over-ranks time of every block; ranks: fastest / slowest rank's own time
+        # of its median block (ms per step) -- the spread the aggregate hides
+        mid = int(torch.argsort(tmax)[len(per_block) // 2].item())
+        out["dispersion"] = {"blocks": len(per_block), "steps_per_block": steps,
+                             "ms_per_step_min": ms(per_block[0]),
+                             "ms_per_step_median": ms(med),
+                             "ms_per_step_max": ms(per_block[-1]),
+                             "rank_ms_per_step_min": ms(float(tmin[mid].item())),
+                             "rank_ms_per_step_max": ms(float(tmax[mid].item()))}
     out.update(extra)
     return out, env, agent
 
@@ -412,6 +494,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="tsp20_b512", choices=sorted(WORKLOADS))
+    ap.add_argument("--blocks", type=int, default=5,
+                    help="timed blocks of --steps rollouts each; ms_per_step is the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -441,8 +525,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
 
+    # every rank on its own GPU: gather what identifies the device and insist on N distinct ones
+    backend, idents = None, [device_identity(device)]
+    if dist is not None:
+        backend = dist.get_backend()
+        idents = [None] * world
+        dist.all_gather_object(idents, device_identity(device))
+        keys = {json.dumps({k: v for k, v in i.items() if k != "index"}, sort_keys=True) + (
+            "" if any(k in i for k in ("uuid", "pci_bus_id")) else str(i["index"])) for i in idents}
+        if not one_gpu:
+            assert len(keys) == world, f"{world} ranks but {len(keys)} distinct GPUs: {idents}"
+
     kind, N, B, mode = WORKLOADS[a.workload]
-    r, env, agent = run_workload(a.workload, a.steps, a.warmup, device, dist, rank, world)
+    r, env, agent = run_workload(a.workload, a.steps, a.warmup, device, dist, rank, world,
+                                 blocks=max(a.blocks, 1))
     T = r["T"]
     out = {
         "metric": "env-steps/sec (batch x nodes), " + ("REINFORCE training" if mode == "train"
@@ -464,6 +560,12 @@ def main():
         "graph_steps_per_s": r["graph_steps_per_s"],
         "mean_tour_cost": r["mean_tour_cost"],
     }
+    if "dispersion" in r:
+        out["dispersion"] = r["dispersion"]
+    if world > 1:
+        out["backend"] = backend + (" (RCCL)" if backend == "nccl" else "")
+        out["rccl_ranks"] = world if backend == "nccl" else 0
+        out["devices"] = idents
     if one_gpu and world > 1:
         out["one_gpu_test_mode"] = True  # all ranks share cuda:0: not a scaling measurement
     if mode == "train":
@@ -484,7 +586,16 @@ def main():
         out["other_configs"] = extras
 
     if rank == 0 and mode != "train":
-        out["roofline"] = step_kernel_roofline(kind, N, B, mode == "greedy", device)
+        # `roofline` = the DOMINANT kernel of the benched rollout: whichever of the encoder
+        # phase (fp32 MFMA-bound) and the decode/env step loop (HBM-bound) takes longer; both
+        # are reported (roofline_encoder, roofline_step)
+        step_r = step_kernel_roofline(kind, N, B, mode == "greedy", device)
+        enc_r = encoder_roofline(kind, N, B, device)
+        steps_us = step_r["avg_launch_us"] * step_r["steps_per_episode"]
+        out["roofline"] = dict(enc_r if enc_r["avg_launch_us"] >= steps_us else step_r)
+        out["roofline"]["share_of_rollout"] = round(
+            max(enc_r["avg_launch_us"], steps_us) / step_r["rollout_us"], 3)
+        out["roofline_encoder"], out["roofline_step"] = enc_r, step_r
         if not a.no_north_star and world == 1 and a.workload != "tsp40_b8192":
             out["roofline_north_star"] = step_kernel_roofline(0, 40, 8192, True, device)
             out["roofline_north_star_vrp"] = step_kernel_roofline(1, 40, 8192, True, device)
@@ -493,13 +604,14 @@ def main():
     if rank == 0 and world == 1 and mode != "train":
         # the same rollouts with env.reset() (new instances: host numpy stream + upload, or
         # the device generator) inside the timed region
-        dt, T2, _ = timed_rollouts(env, agent, mode == "greedy", max(a.steps // 2, 1), 1, None,
-                                   reset="env")
+        (dt,), T2, _ = timed_rollouts(env, agent, mode == "greedy", max(a.steps // 2, 1), 1, None,
+                                      reset="env")
         out["incl_env_reset"] = {"generator": "numpy (host MT19937 replay + upload)",
                                  "ms_per_step": round(dt / max(a.steps // 2, 1) * 1e3, 4),
                                  "value": round(max(a.steps // 2, 1) * B * N * T2 / dt, 1)}
         env_d, _ = make(kind, N, B, 69, device, generator="device")
-        dt, T2, _ = timed_rollouts(env_d, agent, mode == "greedy", a.steps, 1, None, reset="env")
+        (dt,), T2, _ = timed_rollouts(env_d, agent, mode == "greedy", a.steps, 1, None,
+                                      reset="env")
         out["incl_env_reset_device_generator"] = {
             "ms_per_step": round(dt / a.steps * 1e3, 4),
             "value": round(a.steps * B * N * T2 / dt, 1)}

@@ -169,6 +169,14 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     const vrp_rollout_io *io, int t, int max_steps, int flags,
                     void *stream);
 
+/* Single-wave workgroups of the persistent multi-step kernel the current device keeps resident
+ * at once: occupancy of that kernel (minus one workgroup per CU of margin) x the compute units a
+ * census kernel finds usable -- a CU mask or a partition mode shrinks it.  vrp_rollout* use the
+ * persistent kernel only for B <= this, decided before the episode starts (otherwise one launch
+ * per step).  The first call on a device synchronises a private stream (call it once outside
+ * any stream capture; vrp-gym_amd does when it loads the library). */
+int vrp_persistent_capacity(void);
+
 /* Name of the kernel vrp_decode_step launches for this shape and these flags (what a
  * rocprofv3 kernel trace will show). */
 const char *vrp_step_kernel_name(int kind, int B, int N, int flags);
@@ -192,6 +200,16 @@ int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weigh
                 void *derived, const vrp_env *env, int train, int sample,
                 float *emb, void *enc_workspace, void *dec_workspace,
                 const vrp_rollout_io *io, int max_steps, void *stream);
+
+/* Only the encoder phase of vrp_rollout: mask init, features, embedding + encoder layers (for
+ * small eval-mode batches also the decoder's per-graph constants), zeroed accumulators --
+ * exported so a benchmark can bracket exactly these launches with one event pair. */
+int vrp_rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived,
+                       const vrp_env *env, int train, float *emb, void *enc_workspace,
+                       void *dec_workspace, const vrp_rollout_io *io, int max_steps, void *stream);
+
+/* Name of the kernel(s) the encoder phase launches for this shape (profiles, bench line). */
+const char *vrp_encoder_kernel_name(const vrp_encoder_weights *w, int train, int B, int N);
 
 /* Only the T-step decode+env loop of vrp_rollout (emb and prologue already done). */
 int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,

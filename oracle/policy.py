@@ -288,6 +288,8 @@ def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
                           "logp": logp.detach().clone(), "mask": mask.clone(),
                           "noise": noise})
         _, reward, done, _ = env.step(idx[:, None].numpy())
+        if trace is not None:
+            trace[-1]["visited_after"] = np.array(env.visited, dtype=np.float64)
         acc_loss = acc_loss + torch.tensor(reward, dtype=torch.float)
         acc_logp = acc_logp + logp
         _, _, mask, load = split_state(kind, env.get_state())

@@ -46,6 +46,10 @@ def test_bench_spawns_two_ranks_rollout():
     assert p.returncode == 0, p.stderr[-3000:]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["one_gpu_test_mode"] is True
+    assert out["backend"] == "gloo" and out["rccl_ranks"] == 0 and len(out["devices"]) == 2
+    d = out["dispersion"]
+    assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
+    assert d["rank_ms_per_step_min"] <= d["rank_ms_per_step_max"]
     assert out["config"]["global_batch"] == 1024 and out["config"]["steps_per_rollout"] == 19
     assert out["value"] > 0 and out["scaling"] == "weak"
     # rank 0 + rank 1 are the two halves of ONE seed-69 stream of 1024 graphs: their mean cost
@@ -70,6 +74,32 @@ def test_bench_sharded_training_two_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["tsp20_b512", "irp40_b1024_train"])
+def test_bench_two_ranks_over_rccl(workload):
+    """The real backend path, whenever the box has two GPUs: one process per GPU,
+    dist.init_process_group("nccl") (= RCCL), distinct devices asserted inside bench.py, the
+    rollout workload without a collective and the sharded training workload with the flat
+    gradient all-reduce (ReduceOp.AVG, in place on the persistent bucket)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's 8-GPU node runs it)")
+    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+            "--no-north-star", "--no-extras", "--workload", workload]
+    env = {k: v for k, v in os.environ.items() if k != "VRPGYM_BENCH_ONE_GPU"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"].startswith("nccl")
+    assert "one_gpu_test_mode" not in out
+    ids = {json.dumps({k: v for k, v in d.items() if k != "index"}, sort_keys=True) + str(d["index"])
+           for d in out["devices"]}
+    assert len(ids) == 2
+    assert out["value"] > 0
+    if workload.endswith("_train"):
+        assert out["training"]["allreduce_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
 def test_bench_single_rank_line_has_contract_keys():
     p = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-north-star"])
     assert p.returncode == 0, p.stderr[-3000:]
@@ -77,13 +107,23 @@ def test_bench_single_rank_line_has_contract_keys():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out, k
+    # `roofline` names the dominant kernel of the benched rollout: at TSP-20 x 512 the
+    # one-launch encoder (fp32 MFMA-bound); the HBM-bound step kernel is roofline_step
     r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["kernel"] == "encoder_stack_kernel<3>" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r == {**out["roofline_encoder"], "share_of_rollout": r["share_of_rollout"]}
+    r = out["roofline_step"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
               "loop_us_per_step", "loop_frac", "rollout_frac", "kernel"):
         assert k in r, k
-    assert r["kernel"] == "decode_persistent_kernel"
+    assert r["kernel"] == "decode_persistent_kernel" and r["bound"] == "hbm"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["loop_frac"] <= r["frac"] + 1e-6 and r["rollout_frac"] <= r["loop_frac"] + 1e-6
+    d = out["dispersion"]
+    assert d["blocks"] == 5 and d["ms_per_step_min"] <= out["ms_per_step"] <= d["ms_per_step_max"]
     for name in ("vrp40_b2048_train", "irp40_b1024_train", "vrp100_b2048"):
         assert "error" not in out["other_configs"][name], out["other_configs"][name]
         assert out["other_configs"][name]["ms_per_step"] > 0

@@ -745,7 +745,7 @@ def test_video_frames_and_edges_under_fused_rollout(monkeypatch):
     rollout replays exactly that on the host.  Also: render() on a watched env."""
     import sys
     import types
-    frames = []
+    frames, locs = [], []
 
     class CountingRecorder:
         def __init__(self, env=None, path=None, **kw):
@@ -753,6 +753,10 @@ def test_video_frames_and_edges_under_fused_rollout(monkeypatch):
 
         def capture_frame(self):
             frames.append(set(self.env.sampler.graphs[0].visited_edges))
+            # the reference captures INSIDE env.step (tsp.py:92-93): a recorder that looks at
+            # the env sees that step's location and visited flags
+            locs.append((int(self.env.current_location[0, 0]), int(self.env.visited[0].sum()),
+                         int(self.env.step_count)))
 
         def close(self):
             pass
@@ -770,7 +774,7 @@ def test_video_frames_and_edges_under_fused_rollout(monkeypatch):
     from oracle import envs as oenv
     from oracle import policy as opol
     for kind, Env, Agent in ((0, TSPEnv, agents.TSPAgent), (2, IRPEnv, agents.IRPAgent)):
-        del frames[:]
+        del frames[:], locs[:]
         env = Env(num_nodes=9, batch_size=6, num_draw=2, seed=11)
         agent = Agent(seed=69)
         env.enable_video_capturing("unused.mp4")
@@ -791,6 +795,9 @@ def test_video_frames_and_edges_under_fused_rollout(monkeypatch):
             want = {(min(a, b), max(a, b)) for a, b in zip(tour0[: t + 1], tour0[1: t + 2])
                     if a != b}
             assert frames[t] == want, (t, frames[t], want)
+            assert locs[t][0] == tour0[t + 1] and locs[t][2] == t + 1, (t, locs[t])
+        assert [l[1] for l in locs] == [int(s_["visited_after"][0].sum()) for s_ in tr]
+        assert env.step_count == T
         img = env.render()
         assert img.ndim == 3 and img.shape[2] == 3 and img.shape[0] > 0
     # an env nobody watches records nothing and keeps the fused path free of host work

@@ -1,0 +1,93 @@
+"""The persistent multi-step kernel needs its whole grid resident (its waves wait for each
+other's mask words).  These tests run the product in child processes whose HIP runtime is
+restricted to 32 compute units (ROC_GLOBAL_CU_MASK): eligibility must follow the usable CUs
+(fall back to one launch per step BEFORE the episode, same results, no exception), and a grid
+that is forced through anyway must fail loudly -- NaN accumulators for every consumer and an
+exception when the step count is read -- instead of hanging or returning wrong costs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+sys.path[:0] = [os.path.join(%(root)r, "vrp-gym_amd"), %(root)r]
+import torch
+import agents, vrpgym_hip as hip
+from copy import deepcopy
+from agents import runtime
+from gym_vrp.envs import VRPEnv
+cap = hip.lib().vrp_persistent_capacity()
+B, N = 2048, 20
+env = VRPEnv(N, B, 1, 13)
+agent = agents.VRPAgent(seed=69)
+agent.model.eval()
+steps = runtime.max_steps_for(1, N)
+noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
+out = {"capacity": cap, "kernel": hip.lib().vrp_step_kernel_name(1, B, N, 0).decode()}
+res = []
+for persistent in (False, True):
+    with torch.no_grad():
+        r = runtime.rollout(agent.model, deepcopy(env), False, noise=noise, step_trace=True,
+                            persistent=persistent)
+    torch.cuda.synchronize()
+    res.append(r)
+out["nan"] = bool(torch.isnan(res[1].acc_loss).any())
+try:
+    out["T"] = [res[0].T, res[1].T]
+    out["raised"] = False
+except RuntimeError as e:
+    out["raised"] = "timed out" in str(e)
+out["equal"] = bool(torch.equal(res[0].acc_loss, res[1].acc_loss)
+                    and torch.equal(res[0].acc_logp, res[1].acc_logp)
+                    and torch.equal(res[0].actions, res[1].actions))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _child(extra_env, timeout=600):
+    env = dict(os.environ)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, timeout=timeout,
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_capacity_on_the_whole_device():
+    import vrpgym_hip as hip
+    cap = hip.lib().vrp_persistent_capacity()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    # occupancy (<= 8 counted, minus one workgroup per CU of margin) x usable CUs
+    assert cus <= cap <= 7 * cus, (cap, cus)
+    full = _child({})
+    assert full["capacity"] == cap and full["kernel"] == "decode_persistent_kernel"
+    assert full["equal"] and not full["nan"] and not full["raised"]
+
+
+def test_cu_mask_falls_back_before_the_episode():
+    full_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    r = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff"})
+    if r["capacity"] >= 7 * full_cus // 2:
+        pytest.skip(f"this runtime ignores ROC_GLOBAL_CU_MASK (capacity {r['capacity']})")
+    assert r["capacity"] < 2048, r
+    # B = 2048 no longer fits: one launch per step, decided up front -- same results
+    assert r["kernel"] != "decode_persistent_kernel", r
+    assert r["equal"] and not r["nan"] and not r["raised"], r
+
+
+def test_forced_non_resident_grid_fails_loudly():
+    full_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    probe = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff"})
+    if probe["capacity"] >= 7 * full_cus // 2:
+        pytest.skip("this runtime ignores ROC_GLOBAL_CU_MASK")
+    r = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff", "VRP_PERSISTENT_FORCE": "1"}, timeout=900)
+    # either the grid happened to drain (then it must be correct) or it failed loudly
+    assert (r["equal"] and not r["nan"]) or (r["nan"] and r["raised"]), r

@@ -111,7 +111,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert lib.vrp_abi_version() == 3
+    assert lib.vrp_abi_version() == 4
     assert lib.vrp_decoder_derived_bytes() > 0
     assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
     assert lib.vrp_decoder_workspace_bytes(0, 512, 20) > 2 * 512 * 20 * 8 * 20 * 4

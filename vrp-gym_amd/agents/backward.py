@@ -23,11 +23,23 @@ class _TourLogProb(torch.autograd.Function):
         model, kind, res = ctx.model, ctx.kind, ctx.res
         T = res.T
         loads = None if res.load_trace is None else res.load_trace[:T]
+        # Fresh gradients (every .grad None, i.e. right after opt.zero_grad()): the kernels
+        # write into the model's persistent flat bucket and each .grad becomes its view of it,
+        # so the data-parallel all-reduce needs neither a cat nor a copy-back.  Otherwise
+        # (somebody accumulates over several backward calls) autograd gets ordinary tensors.
+        flat, views, _ = runtime.grad_bucket(model, kind)
+        by_param = {id(p): p for p in model.parameters()}
+        direct = all(by_param[i].grad is None for i in views)
+        out = views if direct else None
         dparams, dgrads, d_emb = runtime.decoder_backward(
             model.decoder, kind, res.emb, res.actions[:T], res.mask_trace[:T], loads,
-            d_logp, T)
+            d_logp, T, out=out)
         eparams, egrads = runtime.encoder_backward(model.encoder, res.x3, res.depot_mask,
-                                                   res.tape, d_emb)
+                                                   res.tape, d_emb, out=out)
+        if direct:
+            for i, v in views.items():
+                by_param[i].grad = v
+            return (None, None, None) + (None,) * len(ctx.param_ids)
         by_id = {id(p): g for p, g in zip(dparams + eparams, dgrads + egrads) if p is not None}
         return (None, None, None) + tuple(by_id.get(i) for i in ctx.param_ids)
 

@@ -53,24 +53,50 @@ def unflatten_grads(flat, params):
         off += n
 
 
+def _bucket_in_place(model):
+    """The model's persistent flat gradient buffer if every .grad is its view of it (what the
+    HIP backward leaves behind, agents/backward.py), else None."""
+    hit = getattr(model, "_grad_bucket", None)
+    if hit is None:
+        return None
+    flat, views, _ = hit
+    by_param = {id(p): p for p in model.parameters()}
+    for i, v in views.items():
+        g = by_param[i].grad
+        if g is None or g.data_ptr() != v.data_ptr() or g.numel() != v.numel():
+            return None
+    if any(p.grad is not None and id(p) not in views for p in model.parameters()):
+        return None
+    return flat
+
+
 def allreduce_gradients(model):
-    """mean over ranks of the flat gradient: one bucket, one collective (4.6 MB)."""
+    """mean over ranks of the flat gradient: one bucket, one collective (4.6 MB).  In place on
+    the persistent bucket the backward pass wrote into (RCCL: ReduceOp.AVG, nothing else
+    touches the gradient); a gradient that arrived some other way is packed and unpacked."""
     if not is_distributed():
         return
-    params = grad_parameters(model)
-    if not params:
-        return
-    flat = flatten_grads(params)
+    flat = _bucket_in_place(model)
+    params = None
+    if flat is None:
+        params = grad_parameters(model)
+        if not params:
+            return
+        flat = flatten_grads(params)
     ev = None
     if ALLREDUCE_EVENTS is not None and flat.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
     if ev is not None:
         ev[1].record()
         ALLREDUCE_EVENTS.append(ev)
-    flat.div_(dist.get_world_size())
-    unflatten_grads(flat, params)
+    if params is not None:
+        unflatten_grads(flat, params)
 
 
 def gather_costs(cur, base):

@@ -56,12 +56,13 @@ class TSPModel(nn.Module):
         # rollout keeps the chosen nodes and replays that bookkeeping on the host afterwards.
         watched = env.video_save_path is not None or env.sampler._graphs is not None
         start = env.current_location if watched else None
+        before = env.snapshot_state() if env.video_save_path is not None else None
         res = runtime.rollout(self, env, greedy=bool(rollout), train=self.training,
                               noise_mode=self.sampling_noise, record=grad, trace=watched)
         self.last_rollout = res
         self.decoder.reset()
         if watched:
-            env.replay_tour(start, res.actions[: res.T].cpu().numpy())
+            env.replay_tour(start, res.actions[: res.T].cpu().numpy(), before)
         logp = res.acc_logp
         if grad:
             logp = runtime.attach_grad(self, env, res)

@@ -562,14 +562,40 @@ def encoder_forward_tape(enc, x3, depot_mask_u8, update_running):
     return emb, tape
 
 
-def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb):
-    """Gradients of every encoder parameter given d_emb; list aligned with encoder_param_list."""
+def grad_bucket(model, kind):
+    """ONE persistent flat fp32 buffer per model holding the gradient of every parameter the
+    HIP backward writes (model.parameters() order; decoder._context_proj for TSP/VRP and
+    decoder._first_node for IRP never get one and are left out), plus the per-parameter views
+    into it.  The backward kernels write straight into the views, `.grad` IS the view, and the
+    data-parallel all-reduce runs on the flat buffer in place: no cat, no copy-back
+    (one collective on one bucket)."""
+    hit = getattr(model, "_grad_bucket", None)
+    dev = _dev(model)
+    if hit is not None and hit[0].device == dev and hit[2] == kind:
+        return hit
+    irp = kind == hip.KIND_IRP
+    skip = {id(model.decoder._first_node)} if irp else {id(model.decoder._context_proj.weight)}
+    params = [p for p in model.parameters() if p.requires_grad and id(p) not in skip]
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+    views, off = {}, 0
+    for p in params:
+        views[id(p)] = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    hit = (flat, views, kind)
+    model._grad_bucket = hit
+    return hit
+
+
+def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb, out=None):
+    """Gradients of every encoder parameter given d_emb; list aligned with encoder_param_list.
+    out: {id(param): preallocated gradient tensor} (grad_bucket views) or None."""
     dev = _require_cuda(enc)
     lib = hip.lib()
     w = encoder_struct(enc)
     B, N, _ = x3.shape
     params = encoder_param_list(enc)
-    grads = [None if p is None else torch.empty_like(p) for p in params]
+    grads = [None if p is None else (out[id(p)] if out is not None else torch.empty_like(p))
+             for p in params]
     g = hip.EncoderGrads()
     ptrs = [hip.ptr(t) for t in grads]
     g.node_embed_weight, g.node_embed_bias, g.depot_embed_weight, g.depot_embed_bias = ptrs[:4]
@@ -596,15 +622,16 @@ def decoder_param_list(dec, kind):
             dec._kp.weight, dec._att_output.weight, dec._context_proj.weight if irp else None]
 
 
-def decoder_backward(dec, kind, emb, actions, masks, loads, d_logp, T, want_logp=False):
+def decoder_backward(dec, kind, emb, actions, masks, loads, d_logp, T, want_logp=False, out=None):
     """vrp_decoder_backward over the first T recorded steps.  Returns (params, grads, d_emb
-    [, step_logp]); grads aligned with decoder_param_list."""
+    [, step_logp]); grads aligned with decoder_param_list.  out: as for encoder_backward."""
     dev = _require_cuda(dec)
     lib = hip.lib()
     w = decoder_struct(dec)
     B, N, _ = emb.shape
     params = decoder_param_list(dec, kind)
-    grads = [None if p is None else torch.empty_like(p) for p in params]
+    grads = [None if p is None else (out[id(p)] if out is not None else torch.empty_like(p))
+             for p in params]
     g = hip.DecoderGrads()
     for (name, _), t in zip(hip.DecoderGrads._fields_, grads):
         setattr(g, name, hip.ptr(t))

@@ -12,7 +12,7 @@ void vrp_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *vrp_last_error(void) { return g_err; }
-extern "C" int vrp_abi_version(void) { return 3; }
+extern "C" int vrp_abi_version(void) { return 4; }
 
 // Episode accumulators := 0.  A kernel rather than hipMemsetAsync: memset nodes inside a
 // captured hipGraph were observed to race with the kernels that follow them (ROCm 7.0
@@ -33,7 +33,7 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
               "rollout_steps_range: [%d,%d) outside [0,%d]", t_begin, t_end, max_steps);
   VRP_REQUIRE(derived && env && emb && dec_workspace && io, "rollout_steps_range: NULL argument");
   if (t_end == max_steps && t_end - t_begin >= 2 &&
-      vrp_persistent_eligible(kind, env->B, env->N, max_steps, flags, io)) {
+      vrp_persistent_eligible(kind, env->B, env->N, max_steps, flags, io, (hipStream_t)stream)) {
     // latency-bound regime: step 0 as its own launch (the first-node fold follows it), every
     // later step inside ONE persistent launch (decoder_persistent.hip)
     if (t_begin == 0) {
@@ -85,11 +85,16 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
 int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
                            void *workspace, int constants_done, void *stream);
 
-extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
-                           void *derived, const vrp_env *env, int train, int sample, float *emb,
-                           void *enc_workspace, void *dec_workspace, const vrp_rollout_io *io,
-                           int max_steps, void *stream) {
-  VRP_REQUIRE(ew && dw && derived && env && emb && enc_workspace && dec_workspace && io,
+// The encoder phase of vrp_rollout: state = env.get_state() (mask with the depot fix-ups,
+// tsp.py:106-129), the network inputs, the embedding and the zeroed accumulators; depot_mask: TSP
+// none, VRP = the state's mask column (QUIRK graph_vrp_agent.py:67), IRP = is_depot
+// (graph_irp_agent.py:77-79).  Small eval-mode batches: ONE launch (encoder_stack_kernel) that
+// also leaves the decoder's per-graph constants (*constants_done = 1).
+static int rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived,
+                          const vrp_env *env, int train, float *emb, void *enc_workspace,
+                          void *dec_workspace, const vrp_rollout_io *io, int max_steps,
+                          int *constants_done, void *stream) {
+  VRP_REQUIRE(ew && derived && env && emb && enc_workspace && dec_workspace && io,
               "rollout: NULL argument");
   VRP_REQUIRE(io->acc_loss && io->acc_logp && io->notdone, "rollout: io accumulators NULL");
   VRP_REQUIRE(env->kind == kind, "rollout: env.kind=%d but kind=%d", env->kind, kind);
@@ -99,21 +104,32 @@ extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_de
   const int B = env->B, N = env->N;
   const int need = (kind == VRP_KIND_TSP) ? N - 1 : 2 * (N - 1);
   VRP_REQUIRE(max_steps >= need, "rollout: max_steps=%d < %d", max_steps, need);
-  // state = env.get_state() (mask with the depot fix-ups, tsp.py:106-129), the network inputs,
-  // the embedding and the zeroed accumulators come from one set-up launch; depot_mask: TSP
-  // none, VRP = the state's mask column (QUIRK graph_vrp_agent.py:67), IRP = is_depot
-  // (graph_irp_agent.py:77-79)
+  Derived d = carve_derived(derived);
+  DecWs w = carve_decws(dec_workspace, B, N);
+  return vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
+                                      io->acc_logp, io->notdone, max_steps + 1, d.mb, w.g, w.cvec,
+                                      w.hist, w.err, use_fused_prologue(N) ? d.Wproj : nullptr,
+                                      1536 * 128, constants_done, (hipStream_t)stream);
+}
+
+extern "C" int vrp_rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived,
+                                  const vrp_env *env, int train, float *emb, void *enc_workspace,
+                                  void *dec_workspace, const vrp_rollout_io *io, int max_steps,
+                                  void *stream) {
   int constants_done = 0;
-  {
-    Derived d = carve_derived(derived);
-    DecWs w = carve_decws(dec_workspace, B, N);
-    if (int r = vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
-                                             io->acc_logp, io->notdone, max_steps + 1, d.mb, w.g,
-                                             w.cvec, w.hist, w.err,
-                                             use_fused_prologue(N) ? d.Wproj : nullptr, 1536 * 128,
-                                             &constants_done,
-                                             (hipStream_t)stream)) return r;
-  }
+  return rollout_encode(kind, ew, derived, env, train, emb, enc_workspace, dec_workspace, io,
+                        max_steps, &constants_done, stream);
+}
+
+extern "C" int vrp_rollout(int kind, const vrp_encoder_weights *ew, const vrp_decoder_weights *dw,
+                           void *derived, const vrp_env *env, int train, int sample, float *emb,
+                           void *enc_workspace, void *dec_workspace, const vrp_rollout_io *io,
+                           int max_steps, void *stream) {
+  VRP_REQUIRE(dw, "rollout: NULL argument");
+  int constants_done = 0;
+  if (int r = rollout_encode(kind, ew, derived, env, train, emb, enc_workspace, dec_workspace, io,
+                             max_steps, &constants_done, stream)) return r;
+  const int B = env->B, N = env->N;
   if (int r = vrp_decode_prologue_ex(kind, derived, B, N, emb, dec_workspace, constants_done,
                                      stream)) return r;
   // `sample` doubles as the step flags

@@ -438,14 +438,14 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
 int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
                              hipStream_t st) {
   const size_t lds = (size_t)4 * ((N * 67 + 3) & ~3) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_bwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       vrp_set_error("attention_bwd: cannot raise dynamic LDS");
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(encoder_attention_bwd_kernel, dim3(B, 2), dim3(256), lds, st, qkv, dO, dqkv, N);
   VRP_CHECK_LAUNCH("encoder_attention_bwd");

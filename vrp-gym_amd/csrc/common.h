@@ -28,12 +28,29 @@ void vrp_set_error(const char *fmt, ...);
     }                                 \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: a launcher
+// remembers per device (not per process) that it has raised its kernel's limit.
+#include <atomic>
+struct VrpAttrOnce {
+  std::atomic<unsigned long long> devices{0};
+  static unsigned long long bit() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return 1ull << (dev & 63);
+  }
+  bool done() const { return (devices.load(std::memory_order_acquire) & bit()) != 0; }
+  void mark() { devices.fetch_or(bit(), std::memory_order_release); }
+};
+
 static inline size_t vrp_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
-// exp(x) for x <= 0 (softmax numerators): exp2 of x*log2(e) with the product's rounding
-// error carried into a first-order correction; ~1 ulp, no range handling needed
+// exp(x) for FINITE x <= 0 (softmax numerators: scores minus their finite maximum): exp2 of
+// x*log2(e) with the product's rounding error carried into a first-order correction; ~1 ulp.
+// The argument is clamped at -200 (exp = 0 in fp32 well before): -inf or an overflowing
+// product would otherwise turn the correction term into 0 * NaN.
 __device__ __forceinline__ float exp_nonpos(float x) {
   const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
+  x = fmaxf(x, -200.f);
   const float t = x * l2e_hi;
   float r = fmaf(x, l2e_hi, -t);
   r = fmaf(x, l2e_lo, r);

@@ -21,8 +21,13 @@
 //     aside: vrp_persistent_finalize adds it iff the batch ran on (T - 1 > ta_b).  Later steps
 //     of a finished graph are self-loops on the depot with reward 0 and log-prob 0: nothing to
 //     compute; it publishes its (constant) mask for all remaining steps at once.
-// Requires every workgroup of the grid to be resident (B single-wave workgroups, <= 8 per
-// CU); spins are bounded and report through `err`.
+// Requires every workgroup of the grid to be resident: vrp_persistent_eligible admits only
+// B <= vrp_persistent_capacity() (occupancy of THIS kernel x the compute units a census kernel
+// finds usable, i.e. a CU mask or a partition shrinks it), and persistent launches of one
+// device are serialised across streams.  Spins are bounded all the same: a wave that gives up
+// sets `err`, publishes valid words for its remaining steps (so nobody else waits for it) and
+// leaves; persistent_finalize_kernel then turns the accumulators into NaN, so every consumer
+// sees the failure without a host synchronisation.
 #include "decoder_step.h"
 
 struct PersistParams {
@@ -36,7 +41,7 @@ struct PersistParams {
 };
 
 #define PERSIST_VALID (1ull << 63)
-#define PERSIST_SPIN_LIMIT (1 << 24)
+#define PERSIST_SPIN_LIMIT (1 << 20)  // ~1 s of polling; a legitimate wait is microseconds
 
 __global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams pp) {
   const StepParams &p = pp.s;
@@ -123,9 +128,19 @@ __global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams 
         w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (!(w & PERSIST_VALID)) {
           __builtin_amdgcn_s_sleep(1);
-          if (++spins > PERSIST_SPIN_LIMIT) { *pp.err = 1; break; }
+          if (++spins > PERSIST_SPIN_LIMIT) break;
           w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      }
+      if (__any(!(w & PERSIST_VALID))) {
+        // gave up (the grid is not fully resident, or a graph it depends on gave up): flag the
+        // episode as failed, let everybody who waits for THIS graph go on, and leave the loop
+        if (lane == 0) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long word = (__ballot(inN && own_mask) & ~PERSIST_VALID) | PERSIST_VALID;
+        for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
+          __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        break;
       }
       const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
 #pragma unroll
@@ -302,14 +317,21 @@ __global__ __launch_bounds__(256) void persistent_finalize_kernel(int B, int t0,
                                                                   const int32_t *__restrict__ wb_cur,
                                                                   const double *__restrict__ wb_load,
                                                                   float *__restrict__ acc_loss,
+                                                                  float *__restrict__ acc_logp,
                                                                   int32_t *__restrict__ env_cur,
                                                                   double *__restrict__ env_load,
                                                                   int32_t *__restrict__ notdone,
                                                                   const int32_t *__restrict__ err) {
   __shared__ int smax[4];
   // a wave gave up waiting for another graph's mask (the grid was not fully resident): the
-  // host sees notdone[max_steps] == -1 when it reads the step count
-  if (threadIdx.x == 0 && *err) notdone[max_steps] = -1;
+  // host sees notdone[max_steps] == -1 when it reads the step count, and every consumer of the
+  // accumulators sees NaN (greedy / baseline rollouts never read the step count)
+  if (*err) {
+    if (threadIdx.x == 0) notdone[max_steps] = -1;
+    const float nan = __builtin_nanf("");
+    for (int b = threadIdx.x; b < B; b += 256) { acc_loss[b] = nan; acc_logp[b] = nan; }
+    return;
+  }
   if (notdone[t0 - 1] == 0) return;
   int m = 0;
   for (int b = threadIdx.x; b < B; b += 256) m = max(m, ta[b]);
@@ -328,13 +350,92 @@ __global__ __launch_bounds__(256) void persistent_finalize_kernel(int B, int t0,
   for (int t = t0 + threadIdx.x; t < max_steps; t += 256) notdone[t] = t < last_step ? 1 : 0;
 }
 
+// ---- residency: how many single-wave workgroups of decode_persistent_kernel run at once ----
+// Compute units a launch can actually use (a CU mask -- ROC_GLOBAL_CU_MASK, HSA_CU_MASK -- or
+// a partition mode leaves fewer than hipDeviceProp_t.multiProcessorCount): a census kernel
+// marks the (XCC, shader engine, CU) id every workgroup ran on.
+__device__ unsigned g_census_bits[64];   // 2048 ids: XCC (4 bits) | SE (3 bits) | CU (4 bits)
+__global__ __launch_bounds__(64) void cu_census_kernel() {
+  if (threadIdx.x == 0) {
+    const unsigned id = __smid() & 2047u;
+    atomicOr(&g_census_bits[id >> 5], 1u << (id & 31));
+  }
+  __builtin_amdgcn_s_sleep(64);  // stay a moment: the dispatcher moves on to the other CUs
+}
+
+#define VRP_MAX_DEVICES 64
+struct PersistDevice {
+  int capacity = -1;             // resident single-wave workgroups, -1 = not measured yet
+  int cus = 0;
+  hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
+  hipStream_t last_stream = nullptr;
+};
+static PersistDevice g_pdev[VRP_MAX_DEVICES];
+
+static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
+  if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
+  PersistDevice &pd = g_pdev[dev];
+  if (pd.capacity >= 0) return pd.capacity;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_persistent_kernel, 64, 0) !=
+      hipSuccess) { (void)hipGetLastError(); return 0; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  cus = prop.multiProcessorCount;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
+  if (cs == hipStreamCaptureStatusNone) {
+    // the census synchronises: never inside a stream capture (the figure of the device
+    // properties serves until an eager call gets here)
+    unsigned zero[64] = {0}, bits[64];
+    hipStream_t st = nullptr;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMemcpyToSymbolAsync(HIP_SYMBOL(g_census_bits), zero, sizeof(zero), 0,
+                                      hipMemcpyHostToDevice, st) == hipSuccess;
+    if (ok) {
+      hipLaunchKernelGGL(cu_census_kernel, dim3(16 * cus), dim3(64), 0, st);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpyFromSymbolAsync(bits, HIP_SYMBOL(g_census_bits), sizeof(bits), 0,
+                                        hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if (st) (void)hipStreamDestroy(st);
+    if (!ok) { (void)hipGetLastError(); return 0; }
+    int seen = 0;
+    for (int i = 0; i < 64; ++i) seen += __builtin_popcount(bits[i]);
+    if (seen > 0 && seen < cus) cus = seen;
+    // the occupancy query can be one block per CU high (MI355X_MICROARCH.md, residency) and
+    // other grids may hold slots: one workgroup per CU of margin, at most 8 counted
+    per_cu = per_cu > 8 ? 8 : per_cu;
+    pd.cus = cus;
+    pd.capacity = cus * (per_cu > 1 ? per_cu - 1 : 0);
+    return pd.capacity;
+  }
+  per_cu = per_cu > 8 ? 8 : per_cu;
+  return cus * (per_cu > 1 ? per_cu - 1 : 0);
+}
+
+extern "C" int vrp_persistent_capacity(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return persistent_capacity_of(dev, nullptr);
+}
+
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
-                             const vrp_rollout_io *io) {
+                             const vrp_rollout_io *io, hipStream_t st) {
   (void)kind;
   static const bool off = getenv("VRP_NO_PERSISTENT") != nullptr;  // A/B aid
-  return !off && B <= 2048 && N >= 3 && N <= 63 && max_steps >= 2 && !io->logits && !io->forced &&
-         !(flags & (VRP_STEP_TILE_KERNEL | VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_DECODE_ONLY |
-                    VRP_STEP_NO_PERSISTENT));
+  if (off || N < 3 || N > 63 || max_steps < 2 || io->logits || io->forced ||
+      (flags & (VRP_STEP_TILE_KERNEL | VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_DECODE_ONLY |
+                VRP_STEP_TABLE_KERNEL | VRP_STEP_NO_PERSISTENT)))
+    return false;
+  if (B > 2048) return false;  // beyond this the one-launch-per-step kernel is the faster one
+  static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;  // tests: skip the
+  if (force) return true;                                               // residency check
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  // decided BEFORE the episode starts: a grid that might not be resident takes the per-step path
+  return B <= persistent_capacity_of(dev, st);
 }
 
 // steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
@@ -349,11 +450,31 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   pp.wb_load = ws.wb_load;
   pp.err = ws.err;
   // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
+  // Two persistent grids of one device must not overlap (each is sized against the whole
+  // device: together they might not be resident, and the resident waves of both would wait
+  // for words of workgroups that were never scheduled): a launch on another stream than the
+  // device's previous one waits for that one's end.  (Captured streams are left alone: a
+  // hipGraph replays on one stream; do not replay persistent rollouts of one device on two
+  // streams at once.)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
+                          ? &g_pdev[dev] : nullptr;
+  if (pd && pd->last && pd->last_stream != st) (void)hipStreamWaitEvent(st, pd->last, 0);
   hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
   hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, sp.B, sp.t, sp.max_steps,
-                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.env.cur,
+                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.io.acc_logp, sp.env.cur,
                      sp.kind == VRP_KIND_IRP ? sp.env.load : nullptr, sp.io.notdone, ws.err);
   VRP_CHECK_LAUNCH("persistent_finalize");
+  if (pd) {
+    if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
+      pd->last = nullptr;
+      (void)hipGetLastError();
+    }
+    if (pd->last) { (void)hipEventRecord(pd->last, st); pd->last_stream = st; }
+  }
   return 0;
 }

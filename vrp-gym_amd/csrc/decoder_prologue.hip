@@ -327,14 +327,14 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
 template <int RT_, bool VEC>
 static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * (4 * 48 * PT_LD + 4 * 48) + sizeof(int) * PT_MAXROWS;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("prologue_tables: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   // one workgroup per CU (100 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
   // batch has fewer packs than wave slots

@@ -67,7 +67,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
                                 void *workspace, const vrp_rollout_io *io, int t, int max_steps,
                                 int flags);
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
-                             const vrp_rollout_io *io);
+                             const vrp_rollout_io *io, hipStream_t st);
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st);
 bool vrp_tile_mfma_supported(int N);
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st);

@@ -498,14 +498,14 @@ template <int NMAX, int GPW>
 static int launch_tile(const StepParams &p, hipStream_t st) {
   constexpr int GPB = 8 * GPW;
   const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + 16 * TL_ZG + 16 * TL_OS + 16 * TL_WS);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_mfma_kernel<NMAX, GPW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("decode_step_tile: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL((decode_step_tile_mfma_kernel<NMAX, GPW>), dim3((p.B + GPB - 1) / GPB), dim3(512),
                      lds, st, p);

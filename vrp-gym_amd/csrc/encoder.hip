@@ -269,14 +269,14 @@ template <int NTMAX>
 static int launch_qkv_attention(const float *x, const float *Win, const float *bin, float *att,
                                 int B, int N, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)NTMAX * 16 * (QA_XLD + QA_QLD);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_qkv_attention_kernel<NTMAX>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("qkv_attention: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(encoder_qkv_attention_kernel<NTMAX>, dim3(B), dim3(256), lds, st, x, Win, bin,
                      att, N);
@@ -560,14 +560,14 @@ static int launch_encoder_block(const float *att, const float *x, const vrp_enco
                                 const float *norm1, const float *norm2, float *y, int rows,
                                 int hidden, hipStream_t st) {
   const size_t lds = (size_t)2 * RTW * EB_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block_kernel<RTW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("encoder_block: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(encoder_block_kernel<RTW>, dim3((rows + RTW - 1) / RTW), dim3(256), lds, st,
                      att, x, L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
@@ -739,14 +739,14 @@ static int launch_encoder_block16(const float *att, const float *x, const vrp_en
                                   int hidden, hipStream_t st) {
   constexpr int RTW = 16 * RT16;
   const size_t lds = (size_t)2 * RTW * EB_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block16_kernel<RT16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("encoder_block16: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(encoder_block16_kernel<RT16>, dim3((rows + RTW - 1) / RTW), dim3(256), lds, st,
                      att, x, L.out_proj_weight, L.out_proj_bias, norm1, L.ff0_weight, L.ff0_bias,
@@ -1346,14 +1346,14 @@ static int launch_encoder_block8(const float *att, const float *x, const vrp_enc
                                  int hidden, hipStream_t st) {
   constexpr int RTW = 16 * RT16;
   const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block8_kernel<RT16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("encoder_block8: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   const int ntiles = (rows + RTW - 1) / RTW;
   hipLaunchKernelGGL(encoder_block8_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, att, x,
@@ -1513,14 +1513,14 @@ int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const
                          int ldc, int M, int N, int K, int relu, hipStream_t st) {
   constexpr int RT16 = 5, RTW = 80;
   const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_rows_kernel<RT16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("gemm_rows: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   const int ntiles = (M + RTW - 1) / RTW;
   hipLaunchKernelGGL(gemm_rows_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, A, lda, W,
@@ -1681,14 +1681,14 @@ static int launch_qkv_attn8(const float *x, const float *Win, const float *bin, 
                             int N, hipStream_t st) {
   constexpr int RT16 = 5, RTW = 80;
   const size_t lds = (size_t)RTW * QA_QLD * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_qkv_attn8_kernel<RT16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("qkv_attn8: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   const int G = RTW / N, ntiles = (B + G - 1) / G;
   hipLaunchKernelGGL(encoder_qkv_attn8_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512),
@@ -1861,14 +1861,14 @@ static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, co
                                 hipStream_t st) {
   constexpr int RTW = 16 * RT16;
   const size_t lds = ((size_t)RTW * (2 * EB_LD + QA_QLD) + 16 * 384) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_stack_kernel<RT16>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("encoder_stack: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
-    attr_set = true;
+    attr_set.mark();
   }
   const int G = RTW / N;
   hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
@@ -2047,6 +2047,17 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
                      env_blocks);
   VRP_CHECK_LAUNCH("rollout_setup");
   return encoder_layers(w, train, B, N, cur, emb, ws, st);
+}
+
+// What the encoder phase of vrp_rollout launches for this shape (profiles, bench line).
+extern "C" const char *vrp_encoder_kernel_name(const vrp_encoder_weights *w, int train, int B, int N) {
+  if (!w) return "?";
+  if (encoder_stack_applies(w, train, B, N)) return "encoder_stack_kernel<3>";
+  const int R = B * N;
+  if (train) return "gemm_nt / gemm_rows + encoder_attention_mfma + bn_* per layer (train mode)";
+  if (N <= 64 && (80 / N) * N * 4 >= 3 * 80 && R >= 256 * 80)
+    return "encoder_qkv_attn8_kernel<5> + encoder_block8_kernel<5> per layer";
+  return "qkv/attention + encoder_block* per layer";
 }
 
 static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N, float *cur,

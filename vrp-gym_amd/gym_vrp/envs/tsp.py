@@ -217,13 +217,31 @@ class TSPEnv(GymEnv):
         done = int(self._notdone.item()) == 0
         return self.get_state(), self._reward.cpu().numpy(), done, None
 
-    def replay_tour(self, start, actions):
+    def snapshot_state(self):
+        """Device-side episode state (what `step` mutates), for replay_tour."""
+        return (self._visited.clone(), self._cur.clone(), self._load.clone(), self._mask.clone(),
+                self._parity, self._mask_fresh, self._step_count)
+
+    def replay_tour(self, start, actions, before=None):
         """Host-side part of T env.steps that ran fused on the device: the rendering flags of
         the traversed edges (vrp_network.py:143-152 via tsp.py:88-89) and one video frame per
         step (tsp.py:92-93).  start (B,1) = current_location before the first step, actions
-        (T,B) the chosen nodes."""
+        (T,B) the chosen nodes.  With a video recorder attached and `before` (the
+        snapshot_state() taken before the rollout) the episode is re-stepped through `step`, so
+        every frame is captured with that step's current_location / visited / load in place,
+        like the reference's (the env step is bit-exact: the end state equals the fused one)."""
+        actions = np.asarray(actions)
+        if self.video_save_path is not None and before is not None:
+            last, count = self._last_rollout, self._step_count
+            vis, cur, load, mask, self._parity, self._mask_fresh, _ = before
+            self._visited.copy_(vis); self._cur.copy_(cur); self._load.copy_(load)
+            self._mask.copy_(mask)
+            for a in actions:
+                self.step(a.reshape(-1, 1))   # visit_edges + capture_frame inside
+            self._step_count, self._last_rollout = count, last   # counted once, by the rollout
+            return
         cur = np.asarray(start).reshape(-1, 1)
-        for a in np.asarray(actions):
+        for a in actions:
             nxt = a.reshape(-1, 1)
             self.sampler.visit_edges(np.hstack([cur, nxt]).astype(int))
             if self.video_save_path is not None:

@@ -99,6 +99,8 @@ def _declare(lib):
         "vrp_decode_first_row": (i32, [i32, vp, i32, i32, vp, vp, vp]),
         "vrp_rollout": (i32, [i32, P(EncoderWeights), P(DecoderWeights), vp, P(Env), i32, i32,
                               vp, vp, vp, P(RolloutIO), i32, vp]),
+        "vrp_rollout_encode": (i32, [i32, P(EncoderWeights), vp, P(Env), i32, vp, vp, vp,
+                                     P(RolloutIO), i32, vp]),
         "vrp_rollout_steps": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
                                     i32, i32, vp]),
         "vrp_rollout_steps_range": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp,
@@ -124,6 +126,8 @@ def _declare(lib):
         "vrp_gemm_nt_gated": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "vrp_step_kernel_name": (C.c_char_p, [i32, i32, i32, i32]),
+        "vrp_persistent_capacity": (i32, []),
+        "vrp_encoder_kernel_name": (C.c_char_p, [P(EncoderWeights), i32, i32, i32]),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
     }
