@@ -349,9 +349,19 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         assert T == oT
     if ref_T is not None and not div_ref:
         assert T == ref_T
-    if ref_actions is not None:
-        # the reference's own actions: only graphs coupled to a tie flip may differ
-        assert len(div_ref) == 0 or roots > 0, f"{len(div_ref)} graphs left the reference's path"
+    if div_ref:
+        # The reference's own actions (torch's fused CPU attention) may differ from ours only
+        # through a near tie as well: up to the EARLIEST divergence both sides are in the same
+        # state, so there the reference's choice must be within the gap of the best node on our
+        # logits / ratios; later divergences can be coupled to it through the scrambled mask.
+        t0 = min(div_ref.values())
+        first = [b for b, t in div_ref.items() if t == t0]
+        assert len(first) <= max(1, B // 100), (t0, first)
+        score = U[t0] if greedy else ratio[t0]
+        for b in first:
+            top, theirs = score[b].max().item(), score[b, int(ref_actions[t0, b])].item()
+            miss = top - theirs if greedy else (top - theirs) / top
+            assert miss < gap, (b, t0, miss)
     exempt = np.zeros(B, bool)
     exempt[list(div_ref)] = True
     loss, logp = res.acc_loss.cpu(), res.acc_logp.cpu()

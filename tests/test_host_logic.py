@@ -207,3 +207,89 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"ok {r}" in o
+
+
+_SAN_CHILD = r"""
+import ctypes as C, os, re, sys
+import numpy as np
+sys.path[:0] = [os.path.join(%(root)r, "vrp-gym_amd"), %(root)r]
+import vrpgym_hip
+lib = vrpgym_hip.lib()
+assert vrpgym_hip.library_path().endswith("_asan.so")
+# (1) every declared symbol, the size functions, the ABI version
+header = open(os.path.join(%(root)r, "include", "vrpgym_hip.h")).read()
+for n in sorted(set(re.findall(r"\b(vrp_[a-z_0-9]+)\s*\(", header))):
+    assert hasattr(lib, n), n
+assert lib.vrp_abi_version() == 4 and lib.vrp_decoder_derived_bytes() > 0
+for B, N in ((1, 2), (512, 20), (8192, 40), (2048, 100), (5, 128)):
+    assert lib.vrp_encoder_workspace_bytes(B, N, 512) > 0
+    for kind in (0, 1, 2):
+        assert lib.vrp_decoder_workspace_bytes(kind, B, N) > 0
+    assert lib.vrp_encoder_tape_bytes(B, N, 512, 3) > 0
+    assert lib.vrp_decoder_backward_workspace_bytes(1, B, N, 2 * N) > 0
+# (2) the native MT19937 instance sampler against numpy's legacy stream, ragged sizes
+for seed, B, N in ((69, 7, 9), (5, 33, 2), (123, 64, 100), (1, 1, 128)):
+    np.random.seed(seed)
+    st = np.random.get_state()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = C.c_int32(int(st[2]))
+    xy = np.empty((B, N, 2)); dep = np.empty((B,), np.int64); dem = np.empty((B, N))
+    rc = lib.vrp_draw_instances_host(key.ctypes.data, C.addressof(pos), B, N, xy.ctypes.data,
+                                     dep.ctypes.data, dem.ctypes.data)
+    assert rc == 0, lib.vrp_last_error()
+    for b in range(B):
+        want = np.random.rand(N, 2)
+        d = np.random.choice(N, size=1, replace=False)
+        w = np.random.uniform(1, 10, size=(N, 1)) / (0.2449 * N + 26.12)
+        w[d] = 0
+        assert np.array_equal(xy[b], want) and dep[b] == d[0] and np.array_equal(dem[b], w[:, 0])
+    st2 = np.random.get_state()
+    assert np.array_equal(key, st2[1]) and pos.value == st2[2]
+# (3) argument checking returns errors (never touches the pointers)
+rc = lib.vrp_gemm_nt(None, 128, None, 128, None, None, 0, None, 100, 4, 100, 128, 0, None)
+assert rc != 0 and b"multiple" in lib.vrp_last_error()
+env = vrpgym_hip.Env(); env.kind, env.B, env.N = 1, 4, 5
+io = vrpgym_hip.RolloutIO()
+dw = vrpgym_hip.DecoderWeights()
+assert lib.vrp_decode_step(0, None, C.byref(dw), C.byref(env), None, None, C.byref(io), 0, 4, 0, None) != 0
+assert lib.vrp_rollout_steps_range(1, None, C.byref(dw), C.byref(env), None, None, C.byref(io), 3, 2, 8, 0, None) != 0
+assert b"outside" in lib.vrp_last_error()
+assert lib.vrp_draw_instances_host(None, None, 1, 1, None, None, None) != 0
+# (4) the fold task tables of vrp_decoder_prepare are built on the host before the two
+# launches; without a GPU the launch itself fails (and reports), nothing is dereferenced
+import torch
+if not torch.cuda.is_available():
+    fake = 0x10000000
+    for name, _ in vrpgym_hip.DecoderWeights._fields_:
+        setattr(dw, name, fake)
+    for kind in (0, 1, 2):
+        rc = lib.vrp_decoder_prepare(kind, C.byref(dw), fake, None)
+        assert rc != 0 and b"launch failed" in lib.vrp_last_error(), lib.vrp_last_error()
+    assert lib.vrp_decoder_prepare(5, C.byref(dw), fake, None) != 0
+print("SANITIZED-OK")
+"""
+
+
+def test_host_side_under_sanitizers():
+    """`make asan` builds the host side of every translation unit with
+    -fsanitize=address,undefined (CPU build; GPU sanitizers are unavailable on the pool): the
+    instrumented library is driven through its host-only entry points -- symbol table, size
+    functions, the MT19937 replay, argument checking, the fold task tables -- in a child
+    process running under the ASan runtime.  Any report aborts the child."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "vrp-gym_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rt = subprocess.run(["hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"],
+                        capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=rt, VRPGYM_HIP_LIB=os.path.join(ROOT, "vrp-gym_amd", "vrpgym_hip",
+                                                         "libvrpgym_hip_asan.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    p = subprocess.run([sys.executable, "-c", _SAN_CHILD % {"root": ROOT}], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "SANITIZED-OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr

@@ -507,7 +507,9 @@ static size_t db_slab_bytes(int R, int RB) {
 }
 
 static DecBwdWs carve_dec_bwd(int kind, void *ws, int B, int N, int T, size_t *total) {
-  char *p = (char *)ws;
+  // (offsets are computed on integers: the size query carves from a null base, and pointer
+  // arithmetic on a null pointer is undefined behaviour)
+  uintptr_t p = (uintptr_t)ws;
   DecBwdWs w;
   const size_t R = (size_t)T * B, RB = (size_t)B * N;
   auto take = [&](size_t floats) { float *q = (float *)p; p += vrp_align_up(floats * 4); return q; };
@@ -525,11 +527,11 @@ static DecBwdWs carve_dec_bwd(int kind, void *ws, int B, int N, int T, size_t *t
   w.Wcp = take((size_t)VRP_D * VRP_D);
   w.dWcp = take((size_t)VRP_D * VRP_D);
   w.tmp = take(512);
-  w.slab = p;
+  w.slab = (void *)p;
   p += vrp_align_up(db_slab_bytes((int)R, (int)RB));
-  w.csws = p;
+  w.csws = (void *)p;
   p += vrp_align_up((size_t)vrp_colsum_workspace_bytes((int)(R > RB ? R : RB), VRP_D));
-  if (total) *total = (size_t)(p - (char *)ws);
+  if (total) *total = (size_t)(p - (uintptr_t)ws);
   return w;
 }
 
