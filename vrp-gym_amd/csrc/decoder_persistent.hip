@@ -405,13 +405,14 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
     for (int i = 0; i < 64; ++i) seen += __builtin_popcount(bits[i]);
     if (seen > 0 && seen < cus) cus = seen;
     // the occupancy query can be one block per CU high (MI355X_MICROARCH.md, residency) and
-    // other grids may hold slots: one workgroup per CU of margin, at most 8 counted
-    per_cu = per_cu > 8 ? 8 : per_cu;
+    // other grids may hold slots: one workgroup per CU of margin (single-wave workgroups: the
+    // wave slots, 32 per CU, are the only other limit)
+    per_cu = per_cu > 32 ? 32 : per_cu;
     pd.cus = cus;
     pd.capacity = cus * (per_cu > 1 ? per_cu - 1 : 0);
     return pd.capacity;
   }
-  per_cu = per_cu > 8 ? 8 : per_cu;
+  per_cu = per_cu > 32 ? 32 : per_cu;
   return cus * (per_cu > 1 ? per_cu - 1 : 0);
 }
 

@@ -42,17 +42,23 @@ __device__ __forceinline__ float reduce_scatter64(float (&v)[LEN], int lane) {
   }
 }
 
-template <int NMAX, int GPW>
-__global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p) {
+// NW = waves per workgroup.  8: one 16-graph (GPW = 2) or 8-graph workgroup fills a CU, every
+// phase of its graphs runs in lockstep.  4: half the graphs per workgroup (the MFMA tiles run with
+// 8 or 4 of their 16 rows in use) and TWO workgroups per CU that drift apart, so the tile loads of
+// one run under the folds and logits of the other.
+template <int NMAX, int GPW, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepParams p) {
   constexpr int NPL = (NMAX + 63) / 64;
-  constexpr int GPB = 8 * GPW;  // graphs per workgroup (<= 16 = rows of one MFMA tile)
+  constexpr int GPB = NW * GPW;  // graphs per workgroup (<= 16 = rows of one MFMA tile)
+  constexpr int ROWS = NW == 8 ? 16 : GPB;   // rows of the LDS operand images (power of two)
+  constexpr int HPW = 8 / NW;                // heads (fold 1) / 16-column tiles (fold 2) per wave
   if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *a_s = smem;                      // [GPB][NMAX*8]  a[g][n][h]
-  float *zs = a_s + GPB * NMAX * 8;       // [16][TL_ZG]    z[g][h][128]
-  float *os = zs + 16 * TL_ZG;            // [16][TL_OS]    o[g][384]
-  float *ws = os + 16 * TL_OS;            // [16][TL_WS]    w[g][128]
+  float *zs = a_s + GPB * NMAX * 8;       // [ROWS][TL_ZG]  z[g][h][128]
+  float *os = zs + ROWS * TL_ZG;          // [ROWS][TL_OS]  o[g][384]
+  float *ws = os + ROWS * TL_OS;          // [ROWS][TL_WS]  w[g][128]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,11 +263,13 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
   // of 64 (the vector memory pipe looks lines up one by one, and eight waves stream 384 KB of
   // weights through it in this phase).  Same permutation on the LDS operand.
   const int koff2 = 4 * q;
-  const float *mrow = p.M + (size_t)(wave * 16 + i16) * VRP_D + koff2;
+  const int arow_g = i16 & (ROWS - 1);  // MFMA row -> graph (rows beyond the workgroup's graphs
+                                        // repeat them; their results are dropped)
   float4 mw[PF];
-  {
+#pragma unroll 1
+  for (int hh = 0; hh < HPW; ++hh) {
     const int koff = 4 * q;
-    const int h = wave;
+    const int h = wave * HPW + hh;
     const float *wbase = p.Wv + (size_t)(h * VRP_HD + i16) * VRP_EMB + koff;  // + 16c rows, + 4k4
     float4 wq[PF][3];
 #pragma unroll
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
       const float bb = p.bv[h * VRP_HD + 16 * c + i16];  // D column = lane & 15
       acc[c] = f32x4{bb, bb, bb, bb};
     }
-    const float *arow = zs + i16 * TL_ZG + h * 128 + koff;   // A row = graph i16
+    const float *arow = zs + arow_g * TL_ZG + h * 128 + koff;   // A row = graph
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -287,8 +295,6 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
         if (k4 + PF < 8)
           wq[k4 % PF][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 16 * (k4 + PF));
       }
-      if (k4 + PF >= 8 && k4 + PF < 8 + PF)  // tail: start the second product's fragments
-        mw[k4 + PF - 8] = *reinterpret_cast<const float4 *>(mrow + 16 * (k4 + PF - 8));
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w[c].x, acc[c], 0, 0, 0);
@@ -301,13 +307,18 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)  // D: row = graph 4q + r4, column = lane & 15
-        os[(4 * q + r4) * TL_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
+        if (4 * q + r4 < ROWS) os[(4 * q + r4) * TL_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
   }
   __syncthreads();
-  {
-    const float mbv = p.mb[wave * 16 + i16];
+#pragma unroll 1
+  for (int cc = 0; cc < HPW; ++cc) {
+    const int ct = wave * HPW + cc;
+    const float *mrow = p.M + (size_t)(ct * 16 + i16) * VRP_D + koff2;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) mw[j] = *reinterpret_cast<const float4 *>(mrow + 16 * j);
+    const float mbv = p.mb[ct * 16 + i16];
     f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
-    const float *arow = os + i16 * TL_OS + koff2;
+    const float *arow = os + arow_g * TL_OS + koff2;
 #pragma unroll
     for (int k4 = 0; k4 < 24; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -320,7 +331,8 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) ws[(4 * q + r4) * TL_WS + wave * 16 + i16] = acc0[r4] + acc1[r4];
+    for (int r4 = 0; r4 < 4; ++r4)
+      if (4 * q + r4 < ROWS) ws[(4 * q + r4) * TL_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
   }
   __syncthreads();
 
@@ -494,28 +506,36 @@ __global__ __launch_bounds__(512) void decode_step_tile_mfma_kernel(StepParams p
   }
 }
 
-template <int NMAX, int GPW>
+template <int NMAX, int GPW, int NW>
 static int launch_tile(const StepParams &p, hipStream_t st) {
-  constexpr int GPB = 8 * GPW;
-  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + 16 * TL_ZG + 16 * TL_OS + 16 * TL_WS);
+  constexpr int GPB = NW * GPW;
+  constexpr int ROWS = NW == 8 ? 16 : GPB;
+  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + ROWS * (TL_ZG + TL_OS + TL_WS));
   static VrpAttrOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_mfma_kernel<NMAX, GPW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_mfma_kernel<NMAX, GPW, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("decode_step_tile: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
     attr_set.mark();
   }
-  hipLaunchKernelGGL((decode_step_tile_mfma_kernel<NMAX, GPW>), dim3((p.B + GPB - 1) / GPB), dim3(512),
-                     lds, st, p);
+  hipLaunchKernelGGL((decode_step_tile_mfma_kernel<NMAX, GPW, NW>), dim3((p.B + GPB - 1) / GPB),
+                     dim3(64 * NW), lds, st, p);
   VRP_CHECK_LAUNCH("decode_step_tile_mfma");
   return 0;
 }
 
 bool vrp_tile_mfma_supported(int N) { return N <= 104; }
 
+// VRP_TILE_WAVES=8: the one-workgroup-per-CU variants (A/B aid)
+static int tile_waves() {
+  static const int v = getenv("VRP_TILE_WAVES") ? atoi(getenv("VRP_TILE_WAVES")) : 4;
+  return v;
+}
+
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st) {
-  if (p.N <= 40) return launch_tile<40, 2>(p, st);
-  return launch_tile<104, 1>(p, st);
+  if (tile_waves() == 8)
+    return p.N <= 40 ? launch_tile<40, 2, 8>(p, st) : launch_tile<104, 1, 8>(p, st);
+  return p.N <= 40 ? launch_tile<40, 2, 4>(p, st) : launch_tile<104, 1, 4>(p, st);
 }

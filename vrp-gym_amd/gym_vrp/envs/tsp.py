@@ -233,7 +233,8 @@ class TSPEnv(GymEnv):
         actions = np.asarray(actions)
         if self.video_save_path is not None and before is not None:
             last, count = self._last_rollout, self._step_count
-            vis, cur, load, mask, self._parity, self._mask_fresh, _ = before
+            vis, cur, load, mask, self._parity, self._mask_fresh, self._step_count = before
+            self._last_rollout = None     # step_count reads t + 1 inside the t-th step's frame
             self._visited.copy_(vis); self._cur.copy_(cur); self._load.copy_(load)
             self._mask.copy_(mask)
             for a in actions:
