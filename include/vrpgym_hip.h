@@ -127,11 +127,15 @@ typedef struct vrp_rollout_io {
                           /*   notdone[t]==0 <=> env.step t returned done (tsp.py:95)    */
   int64_t *actions;       /* (max_steps,B) chosen nodes, or NULL                         */
   const int64_t *forced;  /* (max_steps,B) teacher-forced actions, or NULL               */
-  const float *noise;     /* (max_steps,B,N) Exp(1) noise for sampling, or NULL=greedy   */
+  const float *noise;     /* (max_steps,B,N) Exp(1) noise for sampling (parity runs: drawn   */
+                          /*   on the host like the reference), or NULL                      */
   float *logits;          /* (max_steps,B,N) masked logits u, or NULL (debug/tests)      */
   float *step_logp;       /* (max_steps,B) per-step log-prob, or NULL                    */
   uint8_t *mask_trace;    /* (max_steps,B,N) the mask column step t decoded with, or NULL */
   float *load_trace;      /* (max_steps,B) IRP vehicle load fed to step t, or NULL        */
+  uint64_t noise_seed;    /* sampling with noise == NULL: the Exp(1) noise is drawn inside    */
+                          /*   the step kernels from a Philox stream keyed by this seed       */
+                          /*   (counter = graph, node, step): throughput mode, no parity      */
 } vrp_rollout_io;
 
 /* D2  Per-episode constants of GraphDecoder.forward (agents/graph_decoder.py:75-83):
@@ -144,7 +148,8 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
  * followed by env.step on its actions (tsp.py:60-101 / irp.py:49-99), i.e. one
  * iteration of the loop in TSPModel.forward agents/graph_tsp_agent.py:78-88.
  * `t` is the step index; the kernel is a no-op once notdone[t-1]==0.
- * flags: VRP_STEP_SAMPLE = sample with io->noise instead of argmax;
+ * flags: VRP_STEP_SAMPLE = sample (io->noise, or in-kernel noise from io->noise_seed when
+ *        io->noise is NULL) instead of argmax;
  *        VRP_STEP_DECODE_ONLY = GraphDecoder.forward alone: no env.step, no
  *        accumulation (only env->{B,N,mask,load} are read; results go to
  *        io->actions / io->step_logp / io->logits);

@@ -464,19 +464,21 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
         io.forced = f.data_ptr()
     gen_state = None
     if not greedy:
-        if noise is None:
-            if noise_mode == "host":
+        if noise is None and noise_mode != "host":
+            # throughput mode: the step kernels draw their Exp(1) noise themselves (Philox,
+            # counter = graph / node / step); one seed per rollout from the CPU generator, so
+            # torch.manual_seed still makes a run reproducible.  No (max_steps, B, N) tensor.
+            io.noise_seed = int(torch.empty((), dtype=torch.int64).random_().item()) | 1
+        else:
+            if noise is None:
                 gen_state = torch.get_rng_state()
                 noise = host_noise(max_steps, B, N)
-            else:
-                noise = torch.empty((max_steps, B, N), dtype=torch.float32,
-                                    device=dev).exponential_(1)
-        noise = torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous()
-        if noise.shape[0] < max_steps:
-            pad = torch.ones((max_steps - noise.shape[0], B, N), device=dev)
-            noise = torch.cat([noise, pad]).contiguous()
-        keep.append(noise)
-        io.noise = noise.data_ptr()
+            noise = torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous()
+            if noise.shape[0] < max_steps:
+                pad = torch.ones((max_steps - noise.shape[0], B, N), device=dev)
+                noise = torch.cat([noise, pad]).contiguous()
+            keep.append(noise)
+            io.noise = noise.data_ptr()
 
     env._sync_positions()
     env._parity = 0

@@ -43,7 +43,8 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
     }
     VRP_REQUIRE(env->kind == kind && io->acc_loss && io->acc_logp && io->notdone,
                 "rollout_steps_range: bad env/io");
-    VRP_REQUIRE(!(flags & VRP_STEP_SAMPLE) || io->noise, "rollout_steps_range: sampling needs io.noise");
+    VRP_REQUIRE(!(flags & VRP_STEP_SAMPLE) || io->noise || io->noise_seed,
+                "rollout_steps_range: sampling needs io.noise or io.noise_seed");
     const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
                                                 max_steps, flags);
     return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream);

@@ -58,6 +58,33 @@ __device__ __forceinline__ float exp_nonpos(float x) {
   return fmaf(e, r * 0.693147180559945f, e);
 }
 
+// ---- counter-based random numbers (Philox4x32-10): instance generator, device RandomAgent and
+// the in-kernel sampling noise of the throughput mode
+__device__ __forceinline__ void vrp_philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+// Exp(1) noise q of Categorical.sample's argmax(p / q) (agents/graph_decoder.py:104-107) for
+// step t, graph b, node n, drawn in the kernel: counter = (b, n, t, tag), key = seed.  NOT the
+// reference's CPU generator stream (parity runs ship host-drawn noise through io.noise).
+__device__ __forceinline__ float vrp_exp1_noise(uint64_t seed, int t, int b, int n) {
+  uint32_t c[4] = {(uint32_t)b, (uint32_t)n, (uint32_t)t, 0x45585031u};
+  vrp_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float u = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
+  return -__logf(u);
+}
+
 // ---- wave-level reductions (all 64 lanes participate) -----------------------
 // DPP row shifts + row broadcasts (no LDS crossbar): after the six steps lane 63 holds
 // the reduction of the whole wave; readlane(63) hands it back as a wave-uniform value.

@@ -253,7 +253,12 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
       if (inN[i]) vis[i] = p.env.visited[(size_t)b * N + ln[i]];
       if (p.kind == VRP_KIND_IRP) dem[i] = p.env.demand[(size_t)b * N + ln[i]];
     }
-    q_noise[i] = p.sample ? p.io.noise[((size_t)p.t * B + b) * N + ln[i]] : 1.f;
+    q_noise[i] = !p.sample ? 1.f
+                 : p.io.noise ? p.io.noise[((size_t)p.t * B + b) * N + ln[i]]
+                              : vrp_exp1_noise(p.io.noise_seed, p.t, b, ln[i]);
+#ifdef VRP_MUTATION_NOISE_SHIFT  // test-the-tests build: off-by-one noise index (NPL = 2 kernels)
+    if (NPL > 1 && p.sample) q_noise[i] = p.io.noise[((size_t)p.t * B + b) * N + (ln[i] + 1) % N];
+#endif
   }
   const int cur = p.decode_only ? 0 : p.env.cur[b];
   const int dep = p.decode_only ? 0 : p.env.depot[b];
@@ -568,7 +573,8 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
   VRP_REQUIRE(decode_only || (io->acc_loss && io->acc_logp && io->notdone),
               "decode_step: io accumulators NULL");
   VRP_REQUIRE(env->mask && (kind != VRP_KIND_IRP || env->load), "decode_step: env.mask/load NULL");
-  VRP_REQUIRE(!sample || io->noise, "decode_step: sampling needs io.noise");
+  VRP_REQUIRE(!sample || io->noise || io->noise_seed,
+              "decode_step: sampling needs io.noise or io.noise_seed");
   VRP_REQUIRE(t >= 0 && t < max_steps, "decode_step: t=%d outside [0,%d)", t, max_steps);
   const int B = env->B, N = env->N;
   VRP_REQUIRE(N >= 2 && N <= VRP_MAX_NODES, "decode_step: N=%d unsupported (2..%d)", N, VRP_MAX_NODES);

@@ -98,7 +98,9 @@ __global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams 
 
   for (; t < p.max_steps; ++t) {
     // ---- loads that do not depend on other graphs: noise, first rows of the logit table
-    const float q_noise = p.sample ? p.io.noise[((size_t)t * B + b) * N + ln] : 1.f;
+    const float q_noise = !p.sample ? 1.f
+                          : p.io.noise ? p.io.noise[((size_t)t * B + b) * N + ln]
+                                       : vrp_exp1_noise(p.io.noise_seed, t, b, ln);
     const bool s_i = inN && !own_mask;
     const unsigned long long sel = __ballot(s_i);
     const int nsel = __popcll(sel);

@@ -98,21 +98,6 @@ extern "C" int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, in
 // episode, draw).  No state, no host work, no upload; a sharded run (first_graph = the
 // rank's offset) draws exactly the instances of the unsharded one.
 namespace {
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (uint32_t)p1;
-    c[3] = (uint32_t)p0;
-    c[0] = n0;
-    c[2] = n2;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
-}
 // 53 random bits -> [0,1), like numpy's random_sample
 __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
   return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
@@ -131,12 +116,12 @@ __global__ __launch_bounds__(256) void draw_instances_kernel(uint64_t seed, uint
   const uint32_t g = (uint32_t)(first_graph + b), e0 = (uint32_t)episode;
   const uint32_t e1 = (uint32_t)(episode >> 32) << 2;  // low two bits of word 3 = draw id
   uint32_t c[4] = {g, (uint32_t)n, e0, e1 | 0u};
-  philox4x32_10(c, k0, k1);
+  vrp_philox4x32_10(c, k0, k1);
   reinterpret_cast<double2 *>(pos)[i] = make_double2(u53(c[0], c[1]), u53(c[2], c[3]));
   uint32_t d[4] = {g, (uint32_t)n, e0, e1 | 1u};
-  philox4x32_10(d, k0, k1);
+  vrp_philox4x32_10(d, k0, k1);
   uint32_t q[4] = {g, 0xFFFFFFFFu, e0, e1 | 2u};
-  philox4x32_10(q, k0, k1);
+  vrp_philox4x32_10(q, k0, k1);
   int dep = (int)(u53(q[0], q[1]) * (double)N);
   if (dep >= N) dep = N - 1;
   demand[i] = (n == dep) ? 0.0 : (1.0 + 9.0 * u53(d[0], d[1])) / (0.2449 * (double)N + 26.12);
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(256) void random_step_kernel(vrp_env e, uint64_t se
   const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);  // >= 1: a feasible action always exists
   uint32_t c[4] = {(uint32_t)(first_graph + b), (uint32_t)t, (uint32_t)episode,
                    ((uint32_t)(episode >> 32) << 2) | 3u};
-  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  vrp_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   int k = (int)(u53(c[0], c[1]) * (double)cnt);
   if (k >= cnt) k = cnt - 1;
   unsigned long long bits = k < c0 ? m0 : m1;

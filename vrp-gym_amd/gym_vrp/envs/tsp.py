@@ -237,6 +237,7 @@ class TSPEnv(GymEnv):
             self._last_rollout = None     # step_count reads t + 1 inside the t-th step's frame
             self._visited.copy_(vis); self._cur.copy_(cur); self._load.copy_(load)
             self._mask.copy_(mask)
+            self._apply_mask()            # the model's initial env.get_state() (depot fix-up)
             for a in actions:
                 self.step(a.reshape(-1, 1))   # visit_edges + capture_frame inside
             self._step_count, self._last_rollout = count, last   # counted once, by the rollout
