@@ -270,7 +270,7 @@ def _log_roots(*row):
 
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
                      ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
-                     throughput_kernel=False, table_kernel=False, agent=None):
+                     throughput_kernel=False, table_kernel=False, agent=None, fused=False):
     """HIP rollout vs oracle (and vs reference outputs when given).  `agent`: use this
     (e.g. trained) agent's weights on both sides instead of the seed's initial ones.
 
@@ -280,7 +280,12 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     softmax(u)/q within a relative TIE_GAP of the maximum (Categorical.sample is
     argmax(p/q), graph_decoder.py:104-107; p ~ exp(u), so a relative gap in p/q is an
     absolute gap in u).  The number of graphs that took a near-tie runner-up is bounded, and
-    without one the free-running action sequences must be identical."""
+    without one the free-running action sequences must be identical.
+
+    fused=True: no per-step logits trace (which forces one launch per step), so the episode
+    kernels that run steps 1..T-1 in ONE launch are the ones compared (decode_persistent_kernel
+    at N <= 63, decode_resident_kernel at 64 < N <= 104): actions, per-step log-probs,
+    accumulators and T are checked, the logits only through them."""
     from oracle import envs as oenv
     from oracle import policy as opol
     from agents import runtime
@@ -300,8 +305,8 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     oacts = np.array([t["idx"].numpy() for t in trace])
     torch.manual_seed(torch_seed)
     with torch.no_grad():
-        res = runtime.rollout(model, deepcopy(env), greedy, train=train, trace=True,
-                              noise_mode="host", tile_kernel=tile_kernel,
+        res = runtime.rollout(model, deepcopy(env), greedy, train=train, trace=not fused,
+                              step_trace=fused, noise_mode="host", tile_kernel=tile_kernel,
                               throughput_kernel=throughput_kernel, table_kernel=table_kernel)
     T = res.T
     acts = res.actions[:T].cpu().numpy()
@@ -376,7 +381,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         assert np.max(np.abs(loss.numpy() - ref_loss)[ok]) < TOL
         assert np.max(np.abs(logp.numpy() - ref_logp)[ok]) < TOL * (1 if greedy else max(1, T / 4))
     # per-step logits along the same action path
-    for t in range(T):
+    for t in range(0 if fused else T):
         u = res.logits[t].cpu()
         ou = forced_trace[t]["u"]
         fin = torch.isfinite(ou)
@@ -430,6 +435,34 @@ def test_rollout_against_oracle(kind, B, N, greedy, train):
                      table_kernel=True)
     if N <= 104:  # the raw-tile kernel (opt-in flag) stays covered at every size it supports
         _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, tile_kernel=True)
+
+
+@pytest.mark.parametrize("kind,B,N,greedy,train", [
+    (1, 24, 100, False, False),   # config 5 shape, three workgroups of the resident kernel
+    (0, 77, 65, False, False),    # N = 65: node 63 / 64 sit on the word boundary of the hand-off
+    (1, 130, 64, True, False),    # N = 64
+    (0, 16, 70, True, False),     # two full workgroups
+    (1, 13, 104, False, True),    # largest N, train-mode BatchNorm, ragged last workgroup
+    (1, 300, 100, True, False),   # more graphs than one XCD's CUs
+    (1, 200, 40, False, False),   # the persistent table kernel (N <= 63) through the same check
+    (2, 64, 21, False, False),
+])
+def test_fused_episode_kernels_against_oracle(kind, B, N, greedy, train):
+    """Steps 1..T-1 in one launch: decode_resident_kernel (64 <= N <= 104, embeddings resident
+    in registers, TSP/VRP) and decode_persistent_kernel (N <= 63) against the oracle."""
+    import vrpgym_hip as hip
+    name = hip.lib().vrp_step_kernel_name(kind, B, N, 0 if greedy else 1).decode()
+    assert name.startswith("decode_resident_kernel" if N > 63 else "decode_persistent_kernel"), name
+    _compare_rollout(kind, B, N, greedy, 11, 69, 5, train=train, fused=True)
+
+
+@pytest.mark.parametrize("name,path", _load("rollout_*_N[17]*0_sample.npz"))
+def test_resident_kernel_against_reference(name, path):
+    """The reference's recorded sampled episodes at N = 70 / 100 through the resident kernel."""
+    z = np.load(path)
+    _compare_rollout(int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"]), 69, 69,
+                     int(z["torch_seed"]), ref_actions=z["actions"], ref_loss=z["acc_loss"],
+                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), fused=True)
 
 
 @pytest.mark.parametrize("kind,B,N,greedy", [

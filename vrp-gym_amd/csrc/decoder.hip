@@ -92,6 +92,27 @@ struct FoldBuilder {
   }
 };
 
+// v_proj and M once more, in the order the fold MFMAs consume them: a wave's fragment load is
+// then 64 consecutive float4 (1 KB, eight whole cache lines) instead of sixteen 64-byte pieces
+// of sixteen rows.  Runs after the fold tasks (it reads M).
+__global__ __launch_bounds__(256) void pack_fold_weights_kernel(const float *__restrict__ Wv,
+                                                                const float *__restrict__ M,
+                                                                float *__restrict__ WvP,
+                                                                float *__restrict__ MP) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // float4 index, 2 x 12288
+  if (i < 12288) {            // WvP[head][k4][tile][lane]
+    const int lane = i & 63, f = i >> 6, c = f % 3, k4 = (f / 3) & 7, h = f / 24;
+    const int i16 = lane & 15, q = lane >> 4;
+    reinterpret_cast<float4 *>(WvP)[i] = *reinterpret_cast<const float4 *>(
+        Wv + (size_t)(h * VRP_HD + 16 * c + i16) * VRP_EMB + 16 * k4 + 4 * q);
+  } else if (i < 24576) {     // MP[tile][k4][lane]
+    const int j = i - 12288, lane = j & 63, f = j >> 6, k4 = f % 24, ct = f / 24;
+    const int i16 = lane & 15, q = lane >> 4;
+    reinterpret_cast<float4 *>(MP)[j] = *reinterpret_cast<const float4 *>(
+        M + (size_t)(16 * ct + i16) * VRP_D + 16 * k4 + 4 * q);
+  }
+}
+
 extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
                                    void *stream) {
   VRP_REQUIRE(w && derived, "decoder_prepare: NULL argument");
@@ -150,7 +171,11 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   b.mm(d.M, 384, 1, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
   b.mm(d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s);
   if (int r = a.launch(st)) return r;
-  return b.launch(st);
+  if (int r = b.launch(st)) return r;
+  hipLaunchKernelGGL(pack_fold_weights_kernel, dim3(96), dim3(256), 0, st,
+                     d.Wproj + (size_t)1152 * 128, d.M, d.WvP, d.MP);
+  VRP_CHECK_LAUNCH("pack_fold_weights");
+  return 0;
 }
 
 // Batch-wide "somebody is not done" flag.  Only zero / non-zero matters, the readers are
@@ -553,6 +578,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.last = ws.last; p.first = ws.first;
   p.WvT = d.WvT; p.bv = d.bv; p.MT = d.MT; p.mb = d.mb;
   p.Wv = d.Wproj + (size_t)1152 * 128; p.M = d.M;
+  p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
   p.sel_lo = 0; p.sel_hi = 1 << 30;
   static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
@@ -622,15 +648,17 @@ static bool hybrid_shape(int kind, int B, int N) {
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
-  const char *tile = N <= 40 ? "decode_step_tile_mfma_kernel<40, 2>" : "decode_step_tile_mfma_kernel<104, 1>";
+  if (vrp_resident_eligible(kind, B, N, 2, flags, &none, nullptr))
+    return N <= 100 ? "decode_resident_kernel<50>" : "decode_resident_kernel<52>";
+  const char *tile = N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8>" : "decode_step_tile_mfma_kernel<104, 1, 8>";
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
   if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
-    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
+    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
                    : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
-                          ? "decode_step_tile_mfma_kernel<104, 1> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
-                          : "decode_step_tile_mfma_kernel<104, 1> | decode_step_rt_kernel<2, 4> (by selectable nodes)");
+                          ? "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
+                          : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)");
   const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
   if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
   return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";

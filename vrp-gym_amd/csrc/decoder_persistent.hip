@@ -441,6 +441,53 @@ bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
   return B <= persistent_capacity_of(dev, st);
 }
 
+// Usable compute units of the current device (the census above; the device's figure while a
+// stream capture forbids the census).
+int vrp_usable_cus(hipStream_t capturing_guard) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  (void)persistent_capacity_of(dev, capturing_guard);
+  if (dev >= 0 && dev < VRP_MAX_DEVICES && g_pdev[dev].capacity >= 0) return g_pdev[dev].cus;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return prop.multiProcessorCount;
+}
+
+// Two persistent grids of one device must not overlap (each is sized against the whole
+// device: together they might not be resident, and the resident waves of both would wait
+// for words of workgroups that were never scheduled): a launch on another stream than the
+// device's previous one waits for that one's end.  (Captured streams are left alone: a
+// hipGraph replays on one stream; do not replay persistent rollouts of one device on two
+// streams at once.)
+void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
+                          ? &g_pdev[dev] : nullptr;
+  if (pd && pd->last && pd->last_stream != st) (void)hipStreamWaitEvent(st, pd->last, 0);
+  *token = pd;
+}
+void vrp_persistent_serialize_end(hipStream_t st, void *token) {
+  PersistDevice *pd = (PersistDevice *)token;
+  if (!pd) return;
+  if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
+    pd->last = nullptr;
+    (void)hipGetLastError();
+  }
+  if (pd->last) { (void)hipEventRecord(pd->last, st); pd->last_stream = st; }
+}
+
+int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st) {
+  DecWs ws = carve_decws(workspace, sp.B, sp.N);
+  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, sp.B, sp.t, sp.max_steps,
+                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.io.acc_logp, sp.env.cur,
+                     sp.kind == VRP_KIND_IRP ? sp.env.load : nullptr, sp.io.notdone, ws.err);
+  VRP_CHECK_LAUNCH("persistent_finalize");
+  return 0;
+}
+
 // steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st) {
   DecWs ws = carve_decws(workspace, sp.B, sp.N);
@@ -453,31 +500,11 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   pp.wb_load = ws.wb_load;
   pp.err = ws.err;
   // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
-  // Two persistent grids of one device must not overlap (each is sized against the whole
-  // device: together they might not be resident, and the resident waves of both would wait
-  // for words of workgroups that were never scheduled): a launch on another stream than the
-  // device's previous one waits for that one's end.  (Captured streams are left alone: a
-  // hipGraph replays on one stream; do not replay persistent rollouts of one device on two
-  // streams at once.)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  (void)hipStreamIsCapturing(st, &cs);
-  PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
-                          ? &g_pdev[dev] : nullptr;
-  if (pd && pd->last && pd->last_stream != st) (void)hipStreamWaitEvent(st, pd->last, 0);
+  void *token = nullptr;
+  vrp_persistent_serialize_begin(st, &token);
   hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
-  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, sp.B, sp.t, sp.max_steps,
-                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.io.acc_logp, sp.env.cur,
-                     sp.kind == VRP_KIND_IRP ? sp.env.load : nullptr, sp.io.notdone, ws.err);
-  VRP_CHECK_LAUNCH("persistent_finalize");
-  if (pd) {
-    if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
-      pd->last = nullptr;
-      (void)hipGetLastError();
-    }
-    if (pd->last) { (void)hipEventRecord(pd->last, st); pd->last_stream = st; }
-  }
+  if (int r = vrp_launch_persistent_finalize(sp, workspace, st)) return r;
+  vrp_persistent_serialize_end(st, token);
   return 0;
 }

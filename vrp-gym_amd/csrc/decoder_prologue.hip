@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
                                                               unsigned long long *__restrict__ hist,
                                                               int32_t *__restrict__ err) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 2 * N) hist[(size_t)tid * gridDim.x + b] = 0ull;
+  for (int r = tid; r < hist_rows(N); r += 256) hist[(size_t)r * gridDim.x + b] = 0ull;
   if (b == 0 && tid == 0) *err = 0;
   const float *eb = emb + (size_t)b * N * VRP_EMB;
   if (tid < VRP_EMB) {

@@ -12,6 +12,7 @@ struct StepParams {
   int32_t *last, *first;
   const float *WvT, *bv, *MT, *mb;
   const float *Wv, *M;          // (384,128) v_proj rows; (128,384) M = Wkp^T Watt Wo / sqrt(128)
+  const float *WvP, *MP;        // the same two in MFMA fragment order (decoder_ws.h)
   const float *RT, *cvec;
   int dbg;                      // tuning aid (VRP_TILE_DBG): stop the tile kernel after phase dbg
   int sel_lo, sel_hi;           // a kernel handles the graphs with sel_lo <= selectable nodes < sel_hi
@@ -69,5 +70,13 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
                              const vrp_rollout_io *io, hipStream_t st);
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st);
+// resident-tile episode kernel (decoder_resident.hip): 64 <= N <= 104, TSP/VRP, B <= 8 x usable CUs
+bool vrp_resident_eligible(int kind, int B, int N, int max_steps, int flags,
+                           const vrp_rollout_io *io, hipStream_t st);
+int vrp_launch_resident_steps(const StepParams &sp, void *workspace, hipStream_t st);
+int vrp_usable_cus(hipStream_t capturing_guard);  // census of decoder_persistent.hip
+int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st);
+void vrp_persistent_serialize_begin(hipStream_t st, void **token);
+void vrp_persistent_serialize_end(hipStream_t st, void *token);
 bool vrp_tile_mfma_supported(int N);
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st);

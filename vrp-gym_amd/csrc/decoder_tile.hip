@@ -533,9 +533,11 @@ static int launch_tile(const StepParams &p, hipStream_t st) {
 
 bool vrp_tile_mfma_supported(int N) { return N <= 104; }
 
-// VRP_TILE_WAVES=8: the one-workgroup-per-CU variants (A/B aid)
+// VRP_TILE_WAVES=4: two 4-wave workgroups per CU instead of one of eight (A/B aid; measured
+// SLOWER -- 132 vs 72 us at 8192 x 40, 87 vs 55 us at 2048 x 100: with half the MFMA rows in
+// use the weight folds, which stream 384 KB of weights per workgroup from L2, cost twice as much)
 static int tile_waves() {
-  static const int v = getenv("VRP_TILE_WAVES") ? atoi(getenv("VRP_TILE_WAVES")) : 4;
+  static const int v = getenv("VRP_TILE_WAVES") ? atoi(getenv("VRP_TILE_WAVES")) : 8;
   return v;
 }
 

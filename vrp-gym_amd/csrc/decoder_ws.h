@@ -23,6 +23,9 @@ struct Derived {
   float *M;      // (128,384)  M itself (row-major: the tile kernel's B operand)
   float *AfT;    // (1024,128) row h*128+k: sum_d Wk[48h+d][k] Wq_first[48h+d][:] / sqrt(48): the
                  //            first-node query folded through the keys (TSP/VRP)
+  float *WvP;    // (384*128)  v_proj rows in MFMA fragment order: [head][k4][col tile][lane][4],
+                 //            lane (i16, q) = Wv[48 head + 16 tile + i16][16 k4 + 4 q ..+3]
+  float *MP;     // (128*384)  M in fragment order: [col tile][k4][lane][4] = M[16 tile + i16][16 k4 + 4 q ..+3]
 };
 
 static inline Derived carve_derived(void *base) {
@@ -43,12 +46,14 @@ static inline Derived carve_derived(void *base) {
   d.tmpv = p;  p += 128;
   d.M = p;     p += 128 * 384;
   d.AfT = p;   p += 1024 * 128;
+  d.WvP = p;   p += 384 * 128;
+  d.MP = p;    p += 128 * 384;
   return d;
 }
 
 static inline int64_t derived_floats() {
   return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
-         128 * 384 + 128 + 128 * 384 + 1024 * 128;
+         128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384;
 }
 
 // ------------------------------------------------------------------ per-episode workspace
@@ -69,7 +74,8 @@ struct DecWs {
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
   // persistent multi-step kernel (decoder_persistent.hip)
-  unsigned long long *hist;      // (2N, B) published mask words, one row per step
+  unsigned long long *hist;      // (hist_rows(N), B) published mask words: one row per step
+                                 // (N <= 63), two per step above (63 nodes + valid bit per word)
   int32_t *ta;                   // (B) step at which a graph's visited row became all ones
   float *ret;                    // (B) reward of the forced way back after ta
   int32_t *wb_cur;               // (B) location before the way back
@@ -81,6 +87,7 @@ struct DecWs {
 // the fused projection+table prologue packs <= 80 rows (five 16-row tiles) per wave when
 // N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
 #define VRP_FUSED_MAX_N 80
+__host__ __device__ static inline int hist_rows(int N) { return N <= 63 ? 2 * N : 4 * N; }
 static inline int fused_max_rows(int N) { return (N & 3) == 0 ? 80 : 64; }
 static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 // A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
@@ -117,7 +124,7 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
   w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
   w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
-  w.hist = (unsigned long long *)p; p += vrp_align_up((size_t)2 * N * B * 8);
+  w.hist = (unsigned long long *)p; p += vrp_align_up((size_t)hist_rows(N) * B * 8);
   w.ta = (int32_t *)p;    p += vrp_align_up((size_t)B * 4);
   w.ret = (float *)p;     p += vrp_align_up((size_t)B * 4);
   w.wb_cur = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
@@ -134,7 +141,7 @@ static inline int64_t decws_bytes(int B, int N) {
                    vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 5 * vrp_align_up((size_t)B * 4) +
                    vrp_align_up((size_t)B * 8) +
-                   vrp_align_up((size_t)2 * N * B * 8) + vrp_align_up(4));
+                   vrp_align_up((size_t)hist_rows(N) * B * 8) + vrp_align_up(4));
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
