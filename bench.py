@@ -256,6 +256,8 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
     if per_step:  # tuning aid: mean duration of step t over the repetitions
         return [round(float(np.mean(pairs[t::T])) * 1e6, 2) for t in range(T)]
 
+    name = lib.vrp_step_kernel_name(kind, B, N, sflags)
+    fused = name == b"decode_persistent_kernel"
     kern = []
     for _ in range(reps):
         cenv = start_episode()
@@ -267,7 +269,10 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
         hip.check(lib.vrp_decode_first_row(kind, derived.data_ptr(), B, N, res.emb.data_ptr(),
                                            dec_ws.data_ptr(), stream))
         ev[2].record()
-        hip.check(lib.vrp_rollout_steps_range(*args, C.byref(cenv), *tail, 1, T, max_steps,
+        # (a range that ends the episode may run as ONE launch, the persistent kernel: then up
+        # to max_steps; per-step kernels: the T real steps, not the no-op launches after `done`)
+        hip.check(lib.vrp_rollout_steps_range(*args, C.byref(cenv), *tail, 1,
+                                              max_steps if fused else T, max_steps,
                                               sflags | 8, stream))
         ev[3].record()
         torch.cuda.synchronize()
@@ -306,7 +311,6 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
     achieved = byts / avg / 1e9
     wl = f"kind{kind}_N{N}_B{B}"
     traffic = pmc_traffic(wl)
-    name = lib.vrp_step_kernel_name(kind, B, N, sflags)
     out = {"bound": "hbm", "kernel": name.decode() if name else "?", "workload": wl,
            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -175,8 +175,9 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
                     void *stream);
 
 /* Single-wave workgroups of the persistent multi-step kernel the current device keeps resident
- * at once: occupancy of that kernel (minus one workgroup per CU of margin) x the compute units a
- * census kernel finds usable -- a CU mask or a partition mode shrinks it.  vrp_rollout* use the
+ * at once, MEASURED: the compute units a census kernel finds usable (a CU mask or a partition
+ * mode shrinks them) x the largest per-CU count for which a census launch of the kernel itself
+ * had every workgroup see all the others (starting from the occupancy query's answer).  vrp_rollout* use the
  * persistent kernel only for B <= this, decided before the episode starts (otherwise one launch
  * per step).  The first call on a device synchronises a private stream (call it once outside
  * any stream capture; vrp-gym_amd does when it loads the library). */

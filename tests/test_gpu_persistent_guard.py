@@ -65,9 +65,9 @@ def test_capacity_on_the_whole_device():
     import vrpgym_hip as hip
     cap = hip.lib().vrp_persistent_capacity()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    # (occupancy of the kernel - one workgroup per CU of margin) x usable CUs; the B <= 2048
+    # measured residency (a census launch of the kernel itself) x usable CUs; the B <= 2048
     # regime of the persistent kernel must fit a whole MI355X
-    assert 2048 <= cap <= 31 * cus, (cap, cus)
+    assert 2048 <= cap <= 32 * cus and cap % cus == 0, (cap, cus)
     full = _child({})
     assert full["capacity"] == cap and full["kernel"] == "decode_persistent_kernel"
     assert full["equal"] and not full["nan"] and not full["raised"]

@@ -49,23 +49,6 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                                                 max_steps, flags);
     return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream);
   }
-  if (t_end == max_steps && t_end - t_begin >= 2 &&
-      vrp_resident_eligible(kind, env->B, env->N, max_steps, flags, io, (hipStream_t)stream)) {
-    // 64 < N <= 104, B <= 8 x CUs: the embeddings stay in registers for the whole episode
-    // (decoder_resident.hip); step 0 and the first-node fold as their own launches
-    if (t_begin == 0) {
-      if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
-                                  flags | VRP_STEP_TABLE_KERNEL, stream)) return r;
-      t_begin = 1;
-    }
-    VRP_REQUIRE(env->kind == kind && io->acc_loss && io->acc_logp && io->notdone,
-                "rollout_steps_range: bad env/io");
-    VRP_REQUIRE(!(flags & VRP_STEP_SAMPLE) || io->noise || io->noise_seed,
-                "rollout_steps_range: sampling needs io.noise or io.noise_seed");
-    const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
-                                                max_steps, flags);
-    return vrp_launch_resident_steps(sp, dec_workspace, (hipStream_t)stream);
-  }
   for (int t = t_begin; t < t_end; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,
                                 flags, stream))

@@ -648,8 +648,6 @@ static bool hybrid_shape(int kind, int B, int N) {
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
-  if (vrp_resident_eligible(kind, B, N, 2, flags, &none, nullptr))
-    return N <= 100 ? "decode_resident_kernel<50>" : "decode_resident_kernel<52>";
   const char *tile = N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8>" : "decode_step_tile_mfma_kernel<104, 1, 8>";
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&

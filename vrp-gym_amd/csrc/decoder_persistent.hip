@@ -38,6 +38,7 @@ struct PersistParams {
   int32_t *wb_cur;            // (B) node the graph stood on before its way back (-1: none)
   double *wb_load;            // (B) its load there (IRP)
   int32_t *err;
+  int32_t *census;            // residency census mode (vrp_persistent_capacity): {arrived, saw all}
 };
 
 #define PERSIST_VALID (1ull << 63)
@@ -50,6 +51,23 @@ __global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams 
   __shared__ int sel_s[64];  // compacted list of selectable nodes
 
   const int lane = threadIdx.x;
+  if (pp.census) {
+    // Residency census: is a grid of this size, of THIS kernel (same registers, same LDS),
+    // resident all at once?  Every workgroup checks in and waits (bounded) for the others; a grid
+    // that runs in two shifts leaves the first shift without the full count.
+    if (lane == 0) {
+      __hip_atomic_fetch_add(&pp.census[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int seen = 0;
+      for (int spins = 0; spins < 4000; ++spins) {
+        seen = __hip_atomic_load(&pp.census[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= (int)gridDim.x) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (seen >= (int)gridDim.x)
+        __hip_atomic_fetch_add(&pp.census[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   const int N = p.N, B = p.B;
   const int b = blockIdx.x;
   const int t0 = p.t;
@@ -357,6 +375,7 @@ __global__ __launch_bounds__(256) void persistent_finalize_kernel(int B, int t0,
 // a partition mode leaves fewer than hipDeviceProp_t.multiProcessorCount): a census kernel
 // marks the (XCC, shader engine, CU) id every workgroup ran on.
 __device__ unsigned g_census_bits[64];   // 2048 ids: XCC (4 bits) | SE (3 bits) | CU (4 bits)
+__device__ int32_t g_residency[2];       // decode_persistent_kernel's census: {arrived, saw all}
 __global__ __launch_bounds__(64) void cu_census_kernel() {
   if (threadIdx.x == 0) {
     const unsigned id = __smid() & 2047u;
@@ -406,12 +425,36 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
     int seen = 0;
     for (int i = 0; i < 64; ++i) seen += __builtin_popcount(bits[i]);
     if (seen > 0 && seen < cus) cus = seen;
-    // the occupancy query can be one block per CU high (MI355X_MICROARCH.md, residency) and
-    // other grids may hold slots: one workgroup per CU of margin (single-wave workgroups: the
-    // wave slots, 32 per CU, are the only other limit)
+    // The occupancy query can be one block per CU high (MI355X_MICROARCH.md, residency): the
+    // kernel itself is the judge.  A census launch of cus x per_cu workgroups in which every
+    // workgroup saw all the others proves that such a grid is resident at once; otherwise one
+    // workgroup per CU less, and so on.
     per_cu = per_cu > 32 ? 32 : per_cu;
     pd.cus = cus;
-    pd.capacity = cus * (per_cu > 1 ? per_cu - 1 : 0);
+    pd.capacity = 0;
+    int32_t *res = nullptr;
+    hipStream_t st2 = nullptr;
+    if (hipGetSymbolAddress((void **)&res, HIP_SYMBOL(g_residency)) != hipSuccess ||
+        hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      pd.capacity = cus * (per_cu > 1 ? per_cu - 1 : 0);
+      return pd.capacity;
+    }
+    for (int k = per_cu; k >= 1 && pd.capacity == 0; --k) {
+      int32_t zero2[2] = {0, 0}, got[2] = {0, 0};
+      PersistParams cp = {};
+      cp.census = res;
+      bool ok2 = hipMemcpyAsync(res, zero2, sizeof(zero2), hipMemcpyHostToDevice, st2) == hipSuccess;
+      if (ok2) {
+        hipLaunchKernelGGL(decode_persistent_kernel, dim3(cus * k), dim3(64), 0, st2, cp);
+        ok2 = hipGetLastError() == hipSuccess;
+      }
+      ok2 = ok2 && hipMemcpyAsync(got, res, sizeof(got), hipMemcpyDeviceToHost, st2) == hipSuccess;
+      ok2 = ok2 && hipStreamSynchronize(st2) == hipSuccess;
+      if (!ok2) { (void)hipGetLastError(); break; }
+      if (got[1] == cus * k) pd.capacity = cus * k;
+    }
+    (void)hipStreamDestroy(st2);
     return pd.capacity;
   }
   per_cu = per_cu > 32 ? 32 : per_cu;
@@ -499,6 +542,7 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   pp.wb_cur = ws.wb_cur;
   pp.wb_load = ws.wb_load;
   pp.err = ws.err;
+  pp.census = nullptr;
   // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
   void *token = nullptr;
   vrp_persistent_serialize_begin(st, &token);

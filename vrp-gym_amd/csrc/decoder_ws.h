@@ -74,8 +74,7 @@ struct DecWs {
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
   // persistent multi-step kernel (decoder_persistent.hip)
-  unsigned long long *hist;      // (hist_rows(N), B) published mask words: one row per step
-                                 // (N <= 63), two per step above (63 nodes + valid bit per word)
+  unsigned long long *hist;      // (hist_rows(N), B) published mask words, one row per step
   int32_t *ta;                   // (B) step at which a graph's visited row became all ones
   float *ret;                    // (B) reward of the forced way back after ta
   int32_t *wb_cur;               // (B) location before the way back
@@ -87,7 +86,7 @@ struct DecWs {
 // the fused projection+table prologue packs <= 80 rows (five 16-row tiles) per wave when
 // N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
 #define VRP_FUSED_MAX_N 80
-__host__ __device__ static inline int hist_rows(int N) { return N <= 63 ? 2 * N : 4 * N; }
+__host__ __device__ static inline int hist_rows(int N) { return 2 * N; }
 static inline int fused_max_rows(int N) { return (N & 3) == 0 ? 80 : 64; }
 static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 // A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
