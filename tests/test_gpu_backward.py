@@ -201,7 +201,10 @@ def test_decoder_backward_against_oracle_autograd(kind, B, N):
     params, grads, d_emb, step_logp = runtime.decoder_backward(
         model.decoder, kind, res.emb, acts, masks, loads, wgt.cuda(), T, want_logp=True)
     assert (step_logp - res.step_logp[:T]).abs().max().item() < 2e-5
-    assert (step_logp.sum(0) - res.acc_logp).abs().max().item() < 1e-4
+    # (a column sum against the rollout's step-order fp32 accumulation: a few ulp of |sum|,
+    # which reaches ~380 at N = 100)
+    assert (step_logp.sum(0) - res.acc_logp).abs().max().item() < \
+        1e-4 + 1e-6 * res.acc_logp.abs().max().item()
 
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     args = (sd, res.emb.cpu(), acts.cpu(), masks.cpu(), None if loads is None else loads.cpu(), wgt)

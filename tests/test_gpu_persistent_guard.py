@@ -44,9 +44,10 @@ try:
     out["raised"] = False
 except RuntimeError as e:
     out["raised"] = "timed out" in str(e)
+T = min(out.get("T", [1, 1]))
 out["equal"] = bool(torch.equal(res[0].acc_loss, res[1].acc_loss)
                     and torch.equal(res[0].acc_logp, res[1].acc_logp)
-                    and torch.equal(res[0].actions, res[1].actions))
+                    and torch.equal(res[0].actions[:T], res[1].actions[:T]))
 print("RESULT " + json.dumps(out))
 """
 

@@ -275,13 +275,13 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   for (int hh = 0; hh < HPW; ++hh) {
     const int koff = 4 * q;
     const int h = wave * HPW + hh;
-    const float *wbase = p.Wv + (size_t)(h * VRP_HD + i16) * VRP_EMB + koff;  // + 16c rows, + 4k4
+    // fragment (k4, c) of head h, in MFMA operand order (Derived::WvP): 64 consecutive float4
+    const float4 *wbase = reinterpret_cast<const float4 *>(p.WvP) + (size_t)h * 24 * 64 + lane;
     float4 wq[PF][3];
 #pragma unroll
     for (int j = 0; j < PF; ++j)
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        wq[j][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 16 * j);
+      for (int c = 0; c < 3; ++c) wq[j][c] = wbase[(3 * j + c) * 64];
     f32x4 acc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -297,8 +297,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         w[c] = wq[k4 % PF][c];
-        if (k4 + PF < 8)
-          wq[k4 % PF][c] = *reinterpret_cast<const float4 *>(wbase + (size_t)16 * c * VRP_EMB + 16 * (k4 + PF));
+        if (k4 + PF < 8) wq[k4 % PF][c] = wbase[(3 * (k4 + PF) + c) * 64];
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -318,9 +317,9 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
 #pragma unroll 1
   for (int cc = 0; cc < HPW; ++cc) {
     const int ct = wave * HPW + cc;
-    const float *mrow = p.M + (size_t)(ct * 16 + i16) * VRP_D + koff2;
+    const float4 *mrow = reinterpret_cast<const float4 *>(p.MP) + (size_t)ct * 24 * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < PF; ++j) mw[j] = *reinterpret_cast<const float4 *>(mrow + 16 * j);
+    for (int j = 0; j < PF; ++j) mw[j] = mrow[j * 64];
     const float mbv = p.mb[ct * 16 + i16];
     f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
     const float *arow = os + arow_g * TL_OS + koff2;
@@ -328,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     for (int k4 = 0; k4 < 24; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
       const float4 w = mw[k4 % PF];
-      if (k4 + PF < 24) mw[k4 % PF] = *reinterpret_cast<const float4 *>(mrow + 16 * (k4 + PF));
+      if (k4 + PF < 24) mw[k4 % PF] = mrow[(k4 + PF) * 64];
       f32x4 &acc = (k4 & 1) ? acc1 : acc0;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
