@@ -1043,7 +1043,7 @@ def test_training_reaches_the_reference_cost_level(tmp_path):
     """Solution quality, not just throughput: train_models.py's TSP-20 setting (batch 256, seed
     69, Adam 1e-4, rollout baseline with the paired t-test) for 300 of its 851 epochs, then
     reproduction.py's greedy evaluation on fresh seed-1234 instances.  The reference's own log
-    reads 4.81 at epoch 300 and 4.32 at epoch 850 (sampled cost,
+    reads 4.62 at epoch 300 and 4.32 at epoch 850 (sampled cost,
     train_logs/loss_log_tsp_20_69.csv:302,852), its greedy evaluation 4.16
     (reproduction_log/reproduction_results_20_nodes_model_TSP.csv); the full 851-epoch sweep of
     this package is in profiles/r03_train/summary.md (greedy 4.175)."""
@@ -1064,6 +1064,6 @@ def test_training_reaches_the_reference_cost_level(tmp_path):
     rows = list(csv.reader(open(tmp_path / "log.csv")))[1:]
     first, last = -float(rows[0][2]), -float(rows[-1][2])
     assert 8.8 < first < 9.7, first           # the reference's epoch-0 log line: 9.25
-    assert last < 5.1, last                   # the reference at epoch 300: 4.81
+    assert last < 5.1, last                   # the reference at epoch 300: 4.62
     greedy = -agent.evaluate(TSPEnv(num_nodes=20, batch_size=256, num_draw=6, seed=1234)).mean().item()
     assert greedy < 4.5, greedy
