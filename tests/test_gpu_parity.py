@@ -21,7 +21,7 @@ G = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5          # north_star tolerance on cost / log-prob
 TIE_GAP = 5e-5      # near-tie exemption threshold on the oracle's top-2 logit gap: twice the
                     # 2e-5 the logits may differ by; the largest slack seen over the 150-case
-                    # GPU suite is 2.7e-7 (gpurun_out/r03/parity_roots.csv, VRPGYM_PARITY_LOG)
+                    # GPU suite is 2.7e-7 (profiles/r03_parity_tie_statistics.csv, VRPGYM_PARITY_LOG)
 
 
 def _load(pat):
