@@ -623,8 +623,11 @@ static int tile_threshold(int N) {
   // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
   // selectable node at B = 2048 against 45-53 us flat for the raw-tile kernel (the mean step
   // of an episode is within 1 % for thresholds of 34..42 nodes); N = 40 (large batches):
-  // 98 / 83 / 74 us for the first three steps, then ~72 for five more, against 72 us
-  return N > 64 ? (40 * N + 50) / 100 : N - 2;
+  // 102 / 83 / 77 / 77 / 77 / 74 / 71 us for the first seven steps of a TSP episode, 66 us at
+  // the eighth, against 65.7 us flat for the raw-tile kernel (round 3: fold weights in fragment
+  // order): threshold 33 of 39 selectable nodes measured best (42.8 us per step, against 43.9 for
+  // the table kernel alone and 43.1 / 43.2 for thresholds 30 / 36)
+  return N > 64 ? (40 * N + 50) / 100 : (33 * N + 20) / 40;
 }
 // N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
 // bytes whatever the mask, and since its weight folds stream their fragments line by line
@@ -637,11 +640,12 @@ static bool hybrid_shape(int kind, int B, int N) {
   static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
   static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
   if (N > 64) return !off && kind != VRP_KIND_IRP && vrp_tile_mfma_supported(N);
-  // N <= 40, large batches: only with VRP_TILE_HYBRID=1.  The tile kernel (72 us flat at
-  // 8192 x 40) beats the table kernel on the first two steps of a TSP episode (98 and 83 us), but
-  // measured end to end that is 43.7 against 44.0 us per step: not worth a second code path on
-  // the north-star shape.
-  return on && B > 2048 && N > 32 && N <= 40;
+  // 32 < N <= 40, large batches, TSP: the first seven steps of an episode (at least 33 of 39
+  // nodes selectable) go to the raw-tile kernel -- every graph of a TSP batch has the same count,
+  // so exactly one kernel runs per step.  VRP stays with the table kernel (its counts spread
+  // and both kernels would run for a dozen steps: 41.0 - 46.2 us against 39.4); VRP_TILE_HYBRID=1
+  // forces the routing for VRP as well (A/B aid).
+  return !off && B > 2048 && N > 32 && N <= 40 && (kind == VRP_KIND_TSP || on);
 }
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
