@@ -143,9 +143,10 @@ def timed_rollouts(env, agent, greedy, steps, warmup, dist, reset=None, blocks=1
     def one():
         if reset == "env":
             env.reset(return_state=False)
-        else:
-            rewind(env)
-        return runtime.rollout(agent.model, env, greedy)
+            return runtime.rollout(agent.model, env, greedy)
+        # same resident instances, a fresh episode: the state reset (visited, location, load) is
+        # part of the rollout's set-up kernel (VRP_ENV_RESET_ON_ROLLOUT)
+        return runtime.rollout(agent.model, env, greedy, reset_env=True)
 
     res, dts = None, []
     with torch.no_grad():

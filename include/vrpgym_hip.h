@@ -34,8 +34,12 @@ extern "C" {
 #define VRP_MAX_NODES 128
 
 /* ---- environment state (replaces the numpy attributes of TSPEnv/IRPEnv) ------ */
+#define VRP_ENV_RESET_ON_ROLLOUT 1 /* vrp_env.flags: vrp_rollout starts the episode itself --
+                                      visited := 0, current_location := depots, load := 1, the
+                                      state part of TSPEnv.reset (tsp.py:150-160,172-174) -- inside
+                                      its set-up kernel instead of expecting a vrp_env_reset launch */
 typedef struct vrp_env {
-  int32_t kind, B, N, reserved;
+  int32_t kind, B, N, flags;
   const double *pos;     /* (B,N,2) fp64 coordinates   vrp_graph.py:28-31          */
   const double *demand;  /* (B,N)   fp64, IRP only     vrp_graph.py:41-43          */
   const int32_t *depot;  /* (B)                        vrp_graph.py:34             */

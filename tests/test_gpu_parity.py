@@ -1067,3 +1067,25 @@ def test_training_reaches_the_reference_cost_level(tmp_path):
     assert last < 5.1, last                   # the reference at epoch 300: 4.62
     greedy = -agent.evaluate(TSPEnv(num_nodes=20, batch_size=256, num_draw=6, seed=1234)).mean().item()
     assert greedy < 4.5, greedy
+
+
+@pytest.mark.parametrize("kind,B,N", [(0, 512, 20), (1, 300, 40), (2, 64, 21), (1, 24, 100)])
+def test_rollout_with_in_kernel_reset_equals_reset_then_rollout(kind, B, N):
+    """runtime.rollout(reset_env=True) -- VRP_ENV_RESET_ON_ROLLOUT: the state part of env.reset()
+    runs inside the rollout's set-up kernel -- equals _reset_state() followed by a rollout, bit
+    for bit, on an env that has already been played."""
+    from agents import runtime
+    env = _envs()[kind](N, B, 1, 4)
+    agent = _agents()[kind](seed=69)
+    agent.model.eval()
+    with torch.no_grad():
+        first = runtime.rollout(agent.model, env, True, step_trace=True)
+        T = first.T
+        assert env.step_count == T and env._visited.any()
+        again = runtime.rollout(agent.model, env, True, step_trace=True, reset_env=True)
+        assert again.T == T and env.step_count == T
+        env._reset_state()
+        env._step_count, env._last_rollout = 0, None
+        ref = runtime.rollout(agent.model, env, True, step_trace=True)
+    for a, b in ((again, first), (again, ref)):
+        assert torch.equal(a.acc_loss, b.acc_loss) and torch.equal(a.actions[:T], b.actions[:T])

@@ -3,9 +3,9 @@
 #   kernel stats of the default bench command, per-shape kernel stats (TSP / VRP 8192x40,
 #   VRP 2048x100 sampling, TSP 512x20), training epochs of configs 3 and 4, and the PMC passes
 #   (FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only) behind roofline.traffic.
-# usage: bash tools/collect_profiles.sh r02
+# usage: bash tools/collect_profiles.sh r03
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -24,4 +24,5 @@ for shp in 0,20,512 0,40,8192 1,40,8192 1,100,2048,0,1; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc/write_$tag -o p -- python3 tools/step_probe.py $shp > $OUT/pmc_write_$tag.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp40 -o p -- python3 tools/rollout_loop.py 0 40 8192 3 > $OUT/pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp20 -o p -- python3 tools/rollout_loop.py 0 20 512 10 > $OUT/pmc_mfma20.log 2>&1
 ls $OUT

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copies the summaries tools/collect_profiles.sh left under gpurun_out/<round>/ into profiles/
-# (tracked) under their committed names.  usage: bash tools/publish_profiles.sh r02
+# (tracked) under their committed names.  usage: bash tools/publish_profiles.sh r03
 set -eu
-R=${1:-r02}
+R=${1:-r03}
 S=gpurun_out/$R
 D=profiles
 stats() { find "$1" -name '*kernel_stats.csv' | head -1; }
@@ -20,4 +20,8 @@ for t in vrp40_b2048 irp40_b1024 tsp20_b512; do
   cp "$(stats $S/train_$t)" $D/${R}_train_${t}_kernel_stats.csv
 done
 python3 tools/pmc_traffic.py $S/pmc $D/${R}_traffic.json
+# per-kernel summaries of the counter passes themselves (the raw per-dispatch CSVs stay in gpurun_out/)
+for d in $S/pmc/fetch_* $S/pmc/write_* $S/pmc/mfma_*; do
+  [ -d "$d" ] && python3 tools/pmc_summary_csv.py "$d" $D/${R}_pmc_$(basename $d).csv
+done
 ls -la $D | grep ${R}_

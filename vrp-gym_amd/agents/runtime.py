@@ -396,17 +396,20 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
 
 def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=False,
             noise_mode="device", tile_kernel=False, use_graph=None, record=False,
-            throughput_kernel=False, persistent=True, step_trace=False, table_kernel=False):
+            throughput_kernel=False, persistent=True, step_trace=False, table_kernel=False,
+            reset_env=False):
     """TSPModel/VRPModel/IRPModel.forward: encoder + T x (decode, env.step) on the GPU.
     trace: keep actions, per-step logits and log-probs (the logits trace needs one launch per
     step); step_trace: actions and per-step log-probs only; persistent=False: one launch per
     step even where the persistent multi-step kernel applies (A/B and tests); table_kernel:
-    the table-driven step kernel for every graph (no per-graph routing to the raw-tile one)."""
+    the table-driven step kernel for every graph (no per-graph routing to the raw-tile one);
+    reset_env: start a fresh episode on the instances in place (the state part of env.reset():
+    visited, current_location, load, step_count) inside the rollout's own set-up kernel."""
     dev = _require_cuda(model)
     if use_graph is None:
         use_graph = USE_GRAPHS
     if (use_graph and forced is None and noise is None and not trace and not record
-            and not throughput_kernel and not table_kernel
+            and not throughput_kernel and not table_kernel and not reset_env
             and (greedy or noise_mode == "device")):
         if str(env._device) != str(dev):
             raise RuntimeError(f"env is on {env._device} but the model on {dev}")
@@ -483,6 +486,13 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     env._sync_positions()
     env._parity = 0
     cenv = env._cenv()
+    if reset_env:
+        if record and train:
+            env._reset_state()          # the taped path runs vrp_env_mask itself
+        else:
+            cenv.flags = 1              # VRP_ENV_RESET_ON_ROLLOUT
+        env._step_count = 0
+        env._last_rollout = None
     flags = (int(not greedy) | (4 if tile_kernel else 0) | (16 if throughput_kernel else 0) |
              (0 if persistent else 32) | (64 if table_kernel else 0))
     tape = x3 = dmask = None

@@ -770,16 +770,24 @@ __device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_enc
   const int N = e.N;
   if (lane == 0 && part == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
   // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
+  // VRP_ENV_RESET_ON_ROLLOUT: the episode starts here (tsp.py:150-160,172-174; irp.py:47,184):
+  // nothing visited, the vehicle on the depot with a full load
+  const bool fresh = (e.flags & VRP_ENV_RESET_ON_ROLLOUT) != 0;
   const uint8_t *vis = e.visited + (size_t)b * N;
-  int v0 = (lane < N) ? vis[lane] : 1;
-  int v1 = (lane + 64 < N) ? vis[lane + 64] : 1;
-  const double load = (e.kind == VRP_KIND_IRP) ? e.load[b] : 1.0;
+  int v0 = (lane < N) ? (fresh ? 0 : vis[lane]) : 1;
+  int v1 = (lane + 64 < N) ? (fresh ? 0 : vis[lane + 64]) : 1;
+  const double load = (e.kind == VRP_KIND_IRP && !fresh) ? e.load[b] : 1.0;
   const int dep = e.depot[b];
+  const int cur0 = fresh ? dep : e.cur[b];
+  if (fresh && part == 0 && lane == 0) {
+    e.cur[b] = dep;
+    if (e.kind == VRP_KIND_IRP) e.load[b] = 1.0;
+  }
   if (part == 0) {
-    env_fixups_and_mask(e, b, lane, e.cur[b] == dep, v0, v1, load, e.mask);
+    env_fixups_and_mask(e, b, lane, cur0 == dep, v0, v1, load, e.mask);
   } else {  // the same flag fix-ups in registers only (tsp.py:141-146, vrp.py:28-31)
     const int n0 = lane, n1 = lane + 64;
-    if (e.cur[b] == dep) { if (n0 == dep) v0 = 1; if (n1 == dep) v1 = 1; }
+    if (cur0 == dep) { if (n0 == dep) v0 = 1; if (n1 == dep) v1 = 1; }
     else if (e.kind != VRP_KIND_TSP) { if (n0 == dep) v0 = 0; if (n1 == dep) v1 = 0; }
     if (__all((n0 >= N || v0) && (n1 >= N || v1))) { if (n0 == dep) v0 = 0; if (n1 == dep) v1 = 0; }
   }

@@ -13,7 +13,7 @@ c_vp = C.c_void_p
 
 class Env(C.Structure):
     """struct vrp_env"""
-    _fields_ = [("kind", C.c_int32), ("B", C.c_int32), ("N", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("kind", C.c_int32), ("B", C.c_int32), ("N", C.c_int32), ("flags", C.c_int32),
                 ("pos", c_vp), ("demand", c_vp), ("depot", c_vp), ("visited", c_vp),
                 ("mask", c_vp), ("cur", c_vp), ("load", c_vp)]
 
