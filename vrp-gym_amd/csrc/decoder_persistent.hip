@@ -44,7 +44,7 @@ struct PersistParams {
 #define PERSIST_VALID (1ull << 63)
 #define PERSIST_SPIN_LIMIT (1 << 20)  // ~1 s of polling; a legitimate wait is microseconds
 
-__global__ __launch_bounds__(64, 2) void decode_persistent_kernel(PersistParams pp) {
+__global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams pp) {
   const StepParams &p = pp.s;
   __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
   __shared__ __attribute__((aligned(16))) float u_s[64];
