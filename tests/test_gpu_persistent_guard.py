@@ -93,3 +93,36 @@ def test_forced_non_resident_grid_fails_loudly():
     r = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff", "VRP_PERSISTENT_FORCE": "1"}, timeout=900)
     # either the grid happened to drain (then it must be correct) or it failed loudly
     assert (r["equal"] and not r["nan"]) or (r["nan"] and r["raised"]), r
+
+
+def test_persistent_rollouts_from_two_streams():
+    """runtime.workspaces() gives every (model, env) pair private scratch so that two rollouts
+    may be in flight on two streams -- but two persistent grids of one device must not overlap
+    (each is sized against the whole device).  The library serialises them (a one-time host
+    wait when the second stream shows up, events afterwards): interleaved launches from two
+    streams give exactly the results of running them one after the other."""
+    import sys
+    sys.path[:0] = [os.path.join(ROOT, "vrp-gym_amd"), ROOT]
+    from copy import deepcopy
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import VRPEnv
+    B, N = 2048, 20
+    agent = agents.VRPAgent(seed=69)
+    agent.model.eval()
+    envs = [VRPEnv(N, B, 1, 3), VRPEnv(N, B, 1, 4)]
+    with torch.no_grad():
+        want = [runtime.rollout(agent.model, deepcopy(e), True).acc_loss.clone() for e in envs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        got = [[], []]
+        for rep in range(4):
+            for i, (e, s) in enumerate(zip(envs, streams)):
+                with torch.cuda.stream(s):
+                    got[i].append(runtime.rollout(agent.model, e, True, reset_env=True).acc_loss)
+        torch.cuda.synchronize()
+    for i in range(2):
+        for g in got[i]:
+            assert torch.equal(g, want[i])

@@ -652,15 +652,19 @@ static bool hybrid_shape(int kind, int B, int N) {
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
-  const char *tile = N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8>" : "decode_step_tile_mfma_kernel<104, 1, 8>";
+  const char *tile = N <= 40    ? "decode_step_tile_mfma_kernel<40, 2, 8>"
+                     : N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8>"
+                                : "decode_step_tile_mfma_kernel<104, 1, 8>";
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
   if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
     return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
                    : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
-                          ? "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
-                          : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)");
+                          ? (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
+                                      : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)")
+                          : (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)"
+                                      : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)"));
   const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
   if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
   return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";

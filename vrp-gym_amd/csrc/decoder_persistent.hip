@@ -390,6 +390,7 @@ struct PersistDevice {
   int cus = 0;
   hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
   hipStream_t last_stream = nullptr;
+  bool multi_stream = false;     // persistent launches have come from more than one stream
 };
 static PersistDevice g_pdev[VRP_MAX_DEVICES];
 
@@ -498,10 +499,12 @@ int vrp_usable_cus(hipStream_t capturing_guard) {
 
 // Two persistent grids of one device must not overlap (each is sized against the whole
 // device: together they might not be resident, and the resident waves of both would wait
-// for words of workgroups that were never scheduled): a launch on another stream than the
-// device's previous one waits for that one's end.  (Captured streams are left alone: a
-// hipGraph replays on one stream; do not replay persistent rollouts of one device on two
-// streams at once.)
+// for words of workgroups that were never scheduled).  As long as every persistent launch of
+// the device comes from ONE stream, stream order is the guarantee and nothing is added to the
+// queue.  The first launch from a second stream waits on the host for the first stream (once per
+// process); from then on every launch records an event and a launch on another stream than the
+// previous one waits for it.  (Captured streams are left alone: a hipGraph replays on one
+// stream; do not replay persistent rollouts of one device on two streams at once.)
 void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -509,17 +512,26 @@ void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
   (void)hipStreamIsCapturing(st, &cs);
   PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
                           ? &g_pdev[dev] : nullptr;
-  if (pd && pd->last && pd->last_stream != st) (void)hipStreamWaitEvent(st, pd->last, 0);
+  if (pd && pd->last_stream && pd->last_stream != st) {
+    if (!pd->multi_stream) {
+      (void)hipStreamSynchronize(pd->last_stream);
+      pd->multi_stream = true;
+    } else if (pd->last) {
+      (void)hipStreamWaitEvent(st, pd->last, 0);
+    }
+  }
   *token = pd;
 }
 void vrp_persistent_serialize_end(hipStream_t st, void *token) {
   PersistDevice *pd = (PersistDevice *)token;
   if (!pd) return;
+  pd->last_stream = st;
+  if (!pd->multi_stream) return;
   if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
     pd->last = nullptr;
     (void)hipGetLastError();
   }
-  if (pd->last) { (void)hipEventRecord(pd->last, st); pd->last_stream = st; }
+  if (pd->last) (void)hipEventRecord(pd->last, st);
 }
 
 int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st) {

@@ -541,7 +541,9 @@ static int tile_waves() {
 }
 
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st) {
-  if (tile_waves() == 8)
-    return p.N <= 40 ? launch_tile<40, 2, 8>(p, st) : launch_tile<104, 1, 8>(p, st);
+  if (tile_waves() == 8)   // N <= 100 (configs[4]) has its own instance: 8 registers less of tile
+    return p.N <= 40    ? launch_tile<40, 2, 8>(p, st)
+           : p.N <= 100 ? launch_tile<100, 1, 8>(p, st)
+                        : launch_tile<104, 1, 8>(p, st);
   return p.N <= 40 ? launch_tile<40, 2, 4>(p, st) : launch_tile<104, 1, 4>(p, st);
 }
