@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
                  : p.io.noise ? p.io.noise[((size_t)p.t * B + b) * N + ln[i]]
                               : vrp_exp1_noise(p.io.noise_seed, p.t, b, ln[i]);
 #ifdef VRP_MUTATION_NOISE_SHIFT  // test-the-tests build: off-by-one noise index (NPL = 2 kernels)
-    if (NPL > 1 && p.sample) q_noise[i] = p.io.noise[((size_t)p.t * B + b) * N + (ln[i] + 1) % N];
+    if (NPL > 1 && p.sample && p.io.noise) q_noise[i] = p.io.noise[((size_t)p.t * B + b) * N + (ln[i] + 1) % N];
 #endif
   }
   const int cur = p.decode_only ? 0 : p.env.cur[b];

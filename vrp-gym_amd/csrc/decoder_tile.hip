@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
                        : p.io.noise ? p.io.noise[((size_t)p.t * B + b) * N + l]
                                     : vrp_exp1_noise(p.io.noise_seed, p.t, b, l);
 #ifdef VRP_MUTATION_NOISE_SHIFT  // test-the-tests build: off-by-one noise index
-      if (p.sample) q_noise[gi][i] = p.io.noise[((size_t)p.t * B + b) * N + (l + 1) % N];
+      if (p.sample && p.io.noise) q_noise[gi][i] = p.io.noise[((size_t)p.t * B + b) * N + (l + 1) % N];
 #endif
     }
     cur[gi] = p.decode_only ? 0 : p.env.cur[b];
