@@ -1089,3 +1089,45 @@ def test_rollout_with_in_kernel_reset_equals_reset_then_rollout(kind, B, N):
         ref = runtime.rollout(agent.model, env, True, step_trace=True)
     for a, b in ((again, first), (again, ref)):
         assert torch.equal(a.acc_loss, b.acc_loss) and torch.equal(a.actions[:T], b.actions[:T])
+
+
+@pytest.mark.parametrize("kind,B,N", [(0, 2048, 20), (1, 512, 100), (2, 1024, 40), (0, 4096, 40)])
+def test_in_kernel_sampling_noise(kind, B, N):
+    """Throughput mode draws the Exp(1) noise of Categorical.sample inside the step kernels
+    (Philox, counter = graph / node / step, keyed by a per-rollout seed from the CPU generator)
+    instead of shipping a (max_steps, B, N) tensor.  Not the reference's stream, so no
+    action-level parity -- but: reproducible under torch.manual_seed, different across
+    rollouts, the same draw in every step kernel (persistent, table, raw-tile: same counter),
+    log-probs those of the chosen actions, and a cost distribution matching host-noise
+    sampling."""
+    from agents import runtime
+    env = _envs()[kind](N, B, 1, 8)
+    agent = _agents()[kind](seed=69)
+    agent.model.eval()
+
+    def run(seed, **kw):
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            return runtime.rollout(agent.model, deepcopy(env), False, step_trace=True, **kw)
+
+    a, b, c = run(1), run(1), run(2)
+    T = a.T
+    assert b.T == T and torch.equal(a.actions[:T], b.actions[:T]) and torch.equal(a.acc_logp, b.acc_logp)
+    assert not torch.equal(a.actions[:min(T, c.T)], c.actions[:min(T, c.T)])
+    # the same noise whichever kernel consumes it
+    d = run(1, persistent=False)
+    assert d.T == T and torch.equal(a.actions[:T], d.actions[:T])
+    if N <= 104 and kind != 2:
+        e = run(1, persistent=False, tile_kernel=True)
+        flips = (e.actions[:T] != a.actions[:T]).any(dim=0).float().mean().item()
+        assert flips <= 0.01, flips      # other arithmetic for the logits: near ties only
+    assert (a.step_logp[:T] <= 0).all() and torch.isfinite(a.acc_logp).all()
+    acc = torch.zeros(B, device=a.acc_logp.device)
+    for t in range(T):
+        acc += a.step_logp[t]
+    assert torch.equal(acc, a.acc_logp)
+    # distribution: mean sampled cost vs host-noise sampling of the same policy
+    h = run(3, noise_mode="host")
+    ma, mh = -a.acc_loss.mean().item(), -h.acc_loss.mean().item()
+    sd = a.acc_loss.std().item() / (B ** 0.5)
+    assert abs(ma - mh) < 6 * sd + 0.01 * mh, (ma, mh, sd)
