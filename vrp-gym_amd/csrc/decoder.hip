@@ -573,6 +573,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.sample = flags & VRP_STEP_SAMPLE;
   p.decode_only = (flags & VRP_STEP_DECODE_ONLY) ? 1 : 0;
   p.emb = emb;
+  p.embP = (kind != VRP_KIND_IRP && tile_pairs_shape(B, N)) ? ws.embP : nullptr;
   p.row0 = ws.row0; p.SLD = ws.SLD; p.SL = ws.SL; p.curs = ws.curs;
   p.base = (kind == VRP_KIND_IRP) ? nullptr : ws.base;  // IRP: the constant row is inside SL
   p.last = ws.last; p.first = ws.first;

@@ -572,6 +572,26 @@ extern "C" int64_t vrp_decoder_workspace_bytes(int kind, int B, int N) {
   return decws_bytes(B, N);
 }
 
+// The embeddings once more with the rows paired (DecWs::embP): float4 number (pair i, lane l) =
+// {e[2i][2l], e[2i][2l+1], e[2i+1][2l], e[2i+1][2l+1]}, zeros for a row beyond N.  The raw-tile
+// step kernel keeps lane l's two columns of every row in registers; from this copy it fills two
+// rows with ONE 16-byte load per lane (8-byte loads reach 0.5-0.7 of the 16-byte rate).  Written
+// once per episode, read once per tile step.
+__global__ __launch_bounds__(256) void pair_rows_kernel(const float *__restrict__ emb, int N,
+                                                        float *__restrict__ embP, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index
+  if (i >= total) return;
+  const int NP = (N + 1) / 2;
+  const int l = (int)(i & 63);
+  const size_t pr = i >> 6;                 // b * NP + pair
+  const size_t b = pr / NP;
+  const int pi = (int)(pr - b * NP);
+  const float2 *r0 = reinterpret_cast<const float2 *>(emb + (b * N + 2 * pi) * VRP_EMB) + l;
+  const float2 lo = *r0;
+  const float2 hi = (2 * pi + 1 < N) ? r0[64] : make_float2(0.f, 0.f);
+  reinterpret_cast<float4 *>(embP)[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
 int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
                            void *workspace, int constants_done, void *stream);
 extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float *emb,
@@ -596,6 +616,12 @@ int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const fl
   }
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
                                  st)) return r;
+  if (kind != VRP_KIND_IRP && tile_pairs_shape(B, N)) {
+    const size_t total = (size_t)B * ((N + 1) / 2) * 64;
+    hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, emb,
+                       N, w.embP, total);
+    VRP_CHECK_LAUNCH("pair_rows");
+  }
   if (use_fused_prologue(N)) {
     const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
     return (N & 3) == 0 ? launch_prologue_vec<true>(p, st) : launch_prologue_vec<false>(p, st);

@@ -7,6 +7,7 @@
 struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only;
   const float *emb;
+  const float *embP;            // row-paired copy of emb (DecWs::embP) or NULL
   const float *row0, *SLD, *SL, *base;
   float *curs;
   int32_t *last, *first;

@@ -164,10 +164,24 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
         sl_[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
         mo[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
       }
+    // the tile: from the row-paired copy two rows per 16-byte load (prologue: pair_rows_kernel),
+    // else row by row
     const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
+    const float4 *srcP = p.embP ? reinterpret_cast<const float4 *>(p.embP) +
+                                      (size_t)b * ((N + 1) / 2) * 64 + lane : nullptr;
+    static_assert(NH % 2 == 0, "the first half of the tile is a whole number of row pairs");
+    if (srcP) {
 #pragma unroll
-    for (int n = 0; n < NH; ++n)
-      e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+      for (int i = 0; i < NH / 2; ++i) {
+        const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        e[gi][2 * i] = make_float2(v.x, v.y);
+        e[gi][2 * i + 1] = make_float2(v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NH; ++n)
+        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+    }
     __builtin_amdgcn_sched_barrier(0);
     float sc[NPL][8];  // score + additive scrambled mask
 #pragma unroll
@@ -219,9 +233,18 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
           if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
       }
     }
+    if (srcP) {
 #pragma unroll
-    for (int n = NH; n < NMAX; ++n)
-      e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+      for (int i = NH / 2; i < NMAX / 2; ++i) {
+        const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        e[gi][2 * i] = make_float2(v.x, v.y);
+        e[gi][2 * i + 1] = make_float2(v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int n = NH; n < NMAX; ++n)
+        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // a_s of this graph is written and read by this wave only: LDS ops of one wave are ordered
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)

@@ -70,6 +70,10 @@ struct DecWs {
   float *Efirst;                 // (B,128)  first chosen node (general-GEMM fallback)
   float *FK;                     // (B,1024) first-node query folded through the keys (N > 80)
 
+  float *embP;                   // (B, ceil(N/2), 64, 4)  the embeddings once more, rows paired: lane l of
+                                 // pair i holds {e[2i][2l], e[2i][2l+1], e[2i+1][2l], e[2i+1][2l+1]} -- the
+                                 // raw-tile kernel's register layout as ONE 16-byte load per lane and
+                                 // row pair (only for the shapes that kernel serves by default)
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:]
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
@@ -87,6 +91,14 @@ struct DecWs {
 // N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
 #define VRP_FUSED_MAX_N 80
 __host__ __device__ static inline int hist_rows(int N) { return 2 * N; }
+// shapes on which the default dispatch sends steps to the raw-tile kernel (decoder.hip,
+// hybrid_shape; IRP excepted there): they get the row-paired copy of the embeddings
+static inline bool tile_pairs_shape(int B, int N) {
+  return (N > 64 && N <= 104) || (B > 2048 && N > 32 && N <= 40);
+}
+static inline size_t pairs_floats(int B, int N) {
+  return tile_pairs_shape(B, N) ? (size_t)B * ((N + 1) / 2) * 256 : 0;
+}
 static inline int fused_max_rows(int N) { return (N & 3) == 0 ? 80 : 64; }
 static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 // A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
@@ -120,6 +132,7 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.FK = (float *)p;     p += vrp_align_up((size_t)B * 1024 * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
   w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
+  w.embP = (float *)p;  p += vrp_align_up(pairs_floats(B, N) * 4);
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
   w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
   w.first = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
@@ -138,6 +151,7 @@ static inline int64_t decws_bytes(int B, int N) {
                    vrp_align_up(proj_floats(B, N) * 4) + 6 * vrp_align_up(hn) +
                    vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 1024 * 4) +
                    vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
+                   vrp_align_up(pairs_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 5 * vrp_align_up((size_t)B * 4) +
                    vrp_align_up((size_t)B * 8) +
                    vrp_align_up((size_t)hist_rows(N) * B * 8) + vrp_align_up(4));
