@@ -581,7 +581,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.Wv = d.Wproj + (size_t)1152 * 128; p.M = d.M;
   p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
-  p.sel_lo = 0; p.sel_hi = 1 << 30;
+  p.sel_lo = 0; p.sel_hi = 1 << 30; p.tile_lo = 0;
   static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
   p.dbg = dbg;
   p.env = *env;
@@ -704,7 +704,8 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
                       : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - p.t) : 0);
     if (most < th) return launch_rt(p, flags, st);
     StepParams pt = p, pr = p;
-    pt.sel_lo = th;
+    pt.sel_lo = least >= th ? 0 : th;   // every graph above the threshold: no routing check
+    pt.tile_lo = th;
     pr.sel_hi = th;
     if (int r = vrp_launch_tile_mfma_step(pt, st)) return r;
     if (least >= th) return 0;  // every graph was the tile kernel's

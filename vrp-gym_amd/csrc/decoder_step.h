@@ -17,6 +17,8 @@ struct StepParams {
   const float *RT, *cvec;
   int dbg;                      // tuning aid (VRP_TILE_DBG): stop the tile kernel after phase dbg
   int sel_lo, sel_hi;           // a kernel handles the graphs with sel_lo <= selectable nodes < sel_hi
+  int tile_lo;                  // per-graph routing threshold in force (0: none): a graph that keeps
+                                // at least this many selectable nodes meets the raw-tile kernel again
   vrp_env env;
   vrp_rollout_io io;
 };

@@ -112,6 +112,11 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   // selectable nodes decide which kernel handles a graph at this step; a workgroup none of
   // whose graphs is this kernel's leaves at once (hybrid dispatch launches both kernels while
   // the batch straddles the threshold)
+  // (when the host knows that every graph is this kernel's -- no routing, or a step at which even
+  // the graph with the fewest selectable nodes is above the threshold -- nothing waits for the
+  // mask rows: the score rows and the tile are requested in the same round trip)
+  const bool routed = p.sel_lo > 0 || p.sel_hi < (1 << 30);
+  int lastn[GPW];
   {
     int any = 0;
 #pragma unroll
@@ -120,17 +125,22 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       const bool active = braw < B;
       const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
       bg[gi] = b;
-      int nsel = 0;
+      lastn[gi] = p.t > 0 ? p.last[b] : 0;   // requested with the mask rows, not behind them
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         const bool in = lane + 64 * i < N;
         own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
-        nsel += __popcll(__ballot(in && !own_mask[gi][i]));
       }
-      proc[gi] = active && nsel >= p.sel_lo && nsel < p.sel_hi;
+      proc[gi] = active;
+      if (routed) {
+        int nsel = 0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) nsel += __popcll(__ballot(lane + 64 * i < N && !own_mask[gi][i]));
+        proc[gi] = active && nsel >= p.sel_lo && nsel < p.sel_hi;
+      }
       any |= proc[gi] ? 1 : 0;
     }
-    if (!__syncthreads_or(any)) return;
+    if (routed && !__syncthreads_or(any)) return;
   }
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     const size_t row = (size_t)b * 8 * N;
     const float *srow = p.row0 + row;
     if (p.t > 0) {
-      const int last = __builtin_amdgcn_readfirstlane(p.last[b]);
+      const int last = __builtin_amdgcn_readfirstlane(lastn[gi]);
       srow = p.SL + ((size_t)b * N + last) * 8 * N;
     }
     const bool add_base = p.base && p.t > 0;
@@ -515,10 +525,10 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     // (last: a register reload from scratch behind these stores would wait for them to land)
     // latency mode of the table kernel reads next step's row from `curs`: keep it current
     // -- only when the graph's next step can be the table kernel's: under per-graph routing
-    // (sel_lo > 0) a graph that keeps at least sel_lo selectable nodes comes back to this
+    // (tile_lo > 0) a graph that keeps at least tile_lo selectable nodes comes back to this
     // kernel, which reads SL and base itself (the update costs 7 us per step at 2048 x 100:
     // 3.2 KB of table row per graph from HBM, at the very end of the workgroup)
-    if (B <= 2048 && (p.sel_lo <= 0 || nsel_next < p.sel_lo) &&
+    if (B <= 2048 && (p.tile_lo <= 0 || nsel_next < p.tile_lo) &&
         !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
       const size_t row = (size_t)b * 8 * N;
       const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;
