@@ -641,12 +641,13 @@ static bool hybrid_shape(int kind, int B, int N) {
   static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
   static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
   if (N > 64) return !off && kind != VRP_KIND_IRP && vrp_tile_mfma_supported(N);
-  // 32 < N <= 40, large batches, TSP: the first seven steps of an episode (at least 33 of 39
-  // nodes selectable) go to the raw-tile kernel -- every graph of a TSP batch has the same count,
-  // so exactly one kernel runs per step.  VRP stays with the table kernel (its counts spread
-  // and both kernels would run for a dozen steps: 41.0 - 46.2 us against 39.4); VRP_TILE_HYBRID=1
-  // forces the routing for VRP as well (A/B aid).
-  return !off && B > 2048 && N > 32 && N <= 40 && (kind == VRP_KIND_TSP || on);
+  // 32 < N <= 40, large batches, TSP and VRP: the first steps of an episode -- while EVERY graph
+  // still has at least 33 of 39 nodes selectable -- go to the raw-tile kernel, the rest to the table
+  // kernel: exactly one kernel runs per step (launch_step_any never splits a batch at these N; a
+  // VRP batch that straddled the threshold would run both kernels for a dozen steps: 41.0 - 46.2
+  // us against 39.4).  IRP's capacity overlay closes nodes from the first step on: table kernel.
+  (void)on;
+  return !off && B > 2048 && N > 32 && N <= 40 && kind != VRP_KIND_IRP;
 }
 
 // name of the kernel vrp_decode_step dispatches for this shape (profiles, bench line)
@@ -660,7 +661,7 @@ extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
   if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
-    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> | decode_step_rt_kernel<1, 4> (by selectable nodes)"
+    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> (first steps) | decode_step_rt_kernel<1, 4>"
                    : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
                           ? (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
                                       : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)")
@@ -703,6 +704,9 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     const int least = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t
                       : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - p.t) : 0);
     if (most < th) return launch_rt(p, flags, st);
+    // N <= 64: never both kernels for one step -- the tile kernel only while every graph qualifies
+    static const bool split_ok = getenv("VRP_TILE_HYBRID") != nullptr;   // A/B aid
+    if (N <= 64 && least < th && !split_ok) return launch_rt(p, flags, st);
     StepParams pt = p, pr = p;
     pt.sel_lo = least >= th ? 0 : th;   // every graph above the threshold: no routing check
     pt.tile_lo = th;
