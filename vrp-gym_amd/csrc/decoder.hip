@@ -618,7 +618,7 @@ extern "C" int vrp_decode_step(int kind, const void *derived, const vrp_decoder_
 // Which kernel takes which graphs at step t.  The raw-tile kernel costs the same whatever the
 // mask, a table step costs one 32 N-byte row per selectable node: tile for graphs with at least
 // `thresh` selectable nodes (measured crossover, large batches), table below.
-static int tile_threshold(int N) {
+static int tile_threshold(int kind, int N) {
   static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 0;
   if (v > 0) return v;
   // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
@@ -628,7 +628,11 @@ static int tile_threshold(int N) {
   // the eighth, against 65.7 us flat for the raw-tile kernel (round 3: fold weights in fragment
   // order): threshold 33 of 39 selectable nodes measured best (42.8 us per step, against 43.9 for
   // the table kernel alone and 43.1 / 43.2 for thresholds 30 / 36)
-  return N > 64 ? (40 * N + 50) / 100 : (33 * N + 20) / 40;
+  // VRP at N <= 40 (the tile kernel runs only while EVERY graph is above the threshold, see
+  // launch_step_any): 28 of 39 measured best (38.5 us per step; 30 / 33 / 35: 38.7 / 39.3 / 39.5;
+  // table kernel alone 40.0)
+  if (N > 64) return (40 * N + 50) / 100;
+  return kind == VRP_KIND_VRP ? (28 * N + 20) / 40 : (33 * N + 20) / 40;
 }
 // N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
 // bytes whatever the mask, and since its weight folds stream their fragments line by line
@@ -695,7 +699,7 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     if (on) return vrp_launch_tile_mfma_step(p, st);
   }
   if (hybrid_shape(p.kind, B, N) && !p.decode_only && !(flags & VRP_STEP_TABLE_KERNEL)) {
-    const int th = tile_threshold(N);
+    const int th = tile_threshold(p.kind, N);
     // most selectable nodes any graph can have at step t (TSP: exactly N-1-t; VRP/IRP: a customer
     // is served at least every other step, the depot may be open), and fewest (VRP: the mask is
     // the visited row and a step visits at most one customer; IRP: the capacity overlay can
