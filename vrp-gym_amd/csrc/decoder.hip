@@ -584,6 +584,8 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.sel_lo = 0; p.sel_hi = 1 << 30; p.tile_lo = 0;
   static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
   p.dbg = dbg;
+  static const int stagger = getenv("VRP_TILE_STAGGER") ? atoi(getenv("VRP_TILE_STAGGER")) : 0;
+  p.stagger = stagger;
   p.env = *env;
   p.io = *io;
   return p;

@@ -53,6 +53,12 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   constexpr int ROWS = NW == 8 ? 16 : GPB;   // rows of the LDS operand images (power of two)
   constexpr int HPW = 8 / NW;                // heads (fold 1) / 16-column tiles (fold 2) per wave
   if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
+  // Every workgroup alternates between a phase that only loads (the tile) and phases that only
+  // compute; launched together they do so in lockstep and the memory system idles while the
+  // CUs compute.  Odd workgroups (= every other XCD under round-robin dispatch) start late, so
+  // that one half of the chip loads at up to twice its share while the other half computes.
+  if (p.stagger > 0 && (blockIdx.x & 1))
+    for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *a_s = smem;                      // [GPB][NMAX*8]  a[g][n][h]
