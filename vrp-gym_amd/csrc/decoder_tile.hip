@@ -55,9 +55,9 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
   // Every workgroup alternates between a phase that only loads (the tile) and phases that only
   // compute; launched together they do so in lockstep and the memory system idles while the
-  // CUs compute.  Odd workgroups (= every other XCD under round-robin dispatch) start late, so
+  // CUs compute.  Every other workgroup of an XCD (blocks b and b + 8 share one) starts late, so
   // that one half of the chip loads at up to twice its share while the other half computes.
-  if (p.stagger > 0 && (blockIdx.x & 1))
+  if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
     for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
