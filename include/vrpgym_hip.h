@@ -14,6 +14,8 @@
  *     synchronises, and is safe to capture into a hipGraph;
  *   - return value 0 = ok, non-zero = error; vrp_last_error() returns a
  *     thread-local description of the last failure;
+ *   - process-wide state: none that results depend on (the measured residency of the
+ *     persistent kernel per device and the stream of its last launch are cached under a lock);
  *   - kind: 0 = TSP, 1 = VRP, 2 = IRP  (gym_vrp/envs/{tsp,vrp,irp}.py).
  */
 #ifndef VRPGYM_HIP_H

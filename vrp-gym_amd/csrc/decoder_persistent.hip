@@ -393,9 +393,14 @@ struct PersistDevice {
   bool multi_stream = false;     // persistent launches have come from more than one stream
 };
 static PersistDevice g_pdev[VRP_MAX_DEVICES];
+// (process-wide state besides the thread-local error string: the measured capacity per device and
+// the stream of its last persistent launch; launches from several host threads take this lock)
+#include <mutex>
+static std::mutex g_pdev_lock;
 
 static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
   if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
   PersistDevice &pd = g_pdev[dev];
   if (pd.capacity >= 0) return pd.capacity;
   int per_cu = 0, cus = 0;
@@ -485,18 +490,6 @@ bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
   return B <= persistent_capacity_of(dev, st);
 }
 
-// Usable compute units of the current device (the census above; the device's figure while a
-// stream capture forbids the census).
-int vrp_usable_cus(hipStream_t capturing_guard) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  (void)persistent_capacity_of(dev, capturing_guard);
-  if (dev >= 0 && dev < VRP_MAX_DEVICES && g_pdev[dev].capacity >= 0) return g_pdev[dev].cus;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return prop.multiProcessorCount;
-}
-
 // Two persistent grids of one device must not overlap (each is sized against the whole
 // device: together they might not be resident, and the resident waves of both would wait
 // for words of workgroups that were never scheduled).  As long as every persistent launch of
@@ -512,6 +505,7 @@ void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
   (void)hipStreamIsCapturing(st, &cs);
   PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
                           ? &g_pdev[dev] : nullptr;
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
   if (pd && pd->last_stream && pd->last_stream != st) {
     if (!pd->multi_stream) {
       (void)hipStreamSynchronize(pd->last_stream);
@@ -525,6 +519,7 @@ void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
 void vrp_persistent_serialize_end(hipStream_t st, void *token) {
   PersistDevice *pd = (PersistDevice *)token;
   if (!pd) return;
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
   pd->last_stream = st;
   if (!pd->multi_stream) return;
   if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
