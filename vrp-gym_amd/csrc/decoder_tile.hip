@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   // ---- matrix phase: o = Wv z + bv (wave = head), then w = M o + mb (wave = 16 columns) ----
   // The weight fragments come from L2 (~600 cycles): they are requested PF k-steps ahead of
   // their MFMAs, and the first ones of the second product before the barrier in between.
-  constexpr int PF = 3;
+  constexpr int PF = 3;    // first product: a k-step is 12 MFMAs (384 cycles of matrix pipe)
+  constexpr int PF2 = NMAX > 64 ? 5 : 8;   // second product: 4 MFMAs per k-step (128 cycles) against the same ~600-
+                           // cycle fragment latency; the ring reuses the first product's registers
   // Inner dimensions are spread over the four 16-lane groups as k = 16 S + 4 q + e (S = k-step,
   // e = element of the lane's float4): the four lanes that read one weight row in one
   // instruction cover 64 consecutive bytes, so a fragment load touches 16 cache lines instead
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   const int koff2 = 4 * q;
   const int arow_g = i16 & (ROWS - 1);  // MFMA row -> graph (rows beyond the workgroup's graphs
                                         // repeat them; their results are dropped)
-  float4 mw[PF];
+  float4 mw[PF2];
 #pragma unroll 1
   for (int hh = 0; hh < HPW; ++hh) {
     const int koff = 4 * q;
@@ -352,21 +354,28 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       for (int r4 = 0; r4 < 4; ++r4)  // D: row = graph 4q + r4, column = lane & 15
         if (4 * q + r4 < ROWS) os[(4 * q + r4) * TL_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
   }
+  {  // the second product's first fragments travel across the barrier
+    const float4 *mrow0 = reinterpret_cast<const float4 *>(p.MP) + (size_t)(wave * HPW) * 24 * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < PF2; ++j) mw[j] = mrow0[j * 64];
+  }
   __syncthreads();
 #pragma unroll 1
   for (int cc = 0; cc < HPW; ++cc) {
     const int ct = wave * HPW + cc;
     const float4 *mrow = reinterpret_cast<const float4 *>(p.MP) + (size_t)ct * 24 * 64 + lane;
+    if (cc > 0) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) mw[j] = mrow[j * 64];
+      for (int j = 0; j < PF2; ++j) mw[j] = mrow[j * 64];
+    }
     const float mbv = p.mb[ct * 16 + i16];
     f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
     const float *arow = os + arow_g * TL_OS + koff2;
 #pragma unroll
     for (int k4 = 0; k4 < 24; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
-      const float4 w = mw[k4 % PF];
-      if (k4 + PF < 24) mw[k4 % PF] = mrow[(k4 + PF) * 64];
+      const float4 w = mw[k4 % PF2];
+      if (k4 + PF2 < 24) mw[k4 % PF2] = mrow[(k4 + PF2) * 64];
       f32x4 &acc = (k4 & 1) ? acc1 : acc0;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
