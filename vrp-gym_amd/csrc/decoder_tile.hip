@@ -17,7 +17,6 @@
 // 384 KB of folded weights are shared by every workgroup and step).  The partial dot products
 // e_n . w of a lane's two columns are summed over the 64 lanes by a butterfly reduce-scatter
 // that leaves node n's total in lane n -- the layout the action/env code wants.
-#include <type_traits>
 #include "decoder_step.h"
 
 #define TL_ZG 1028  // zs: floats between graphs (8 heads x 128 + 4: conflict-free b128 reads)
@@ -149,29 +148,29 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     }
     if (routed && !__syncthreads_or(any)) return;
   }
-  // ---- loads, then per graph: glimpse weights -> a_s, z = A E -> zs ---------------------------
-  // Loads return in order, so the ISSUE order is the schedule: the first graph's score rows and
-  // masks, its tile, the other graph's tile -- all before anything is consumed; a later graph's
-  // score rows are requested once the previous graph's are dead (same registers) and arrive
-  // under that graph's sums.  (Round 2 requested each graph's loads at its turn and the second
-  // half of a tile behind the glimpse weights: four exposed round trips per wave at GPW = 2.)
-  bool inN[NPL];
-  int ln[NPL];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
-  float sv[NPL][8], bv_[NPL][8], sl_[NPL][8];
-  int mo[NPL][8];
-  const bool add_base = p.base && p.t > 0;
-  auto issue_small = [&](auto GI) {
-    constexpr int gi = decltype(GI)::value;
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int g = wave * GPW + gi;
     const int b = bg[gi];
+    bool inN[NPL];
+    int ln[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
+    if (!proc[gi]) continue;  // wave-uniform
+    // ---- loads.  Order matters (they return in order): the score rows and masks first, then
+    // the first half of the tile; the glimpse weights are computed while the tile streams in,
+    // the second half is requested behind them and the sums below consume rows as they land.
+    constexpr int NH = NMAX / 2;
     const size_t row = (size_t)b * 8 * N;
     const float *srow = p.row0 + row;
     if (p.t > 0) {
       const int last = __builtin_amdgcn_readfirstlane(lastn[gi]);
       srow = p.SL + ((size_t)b * N + last) * 8 * N;
     }
+    const bool add_base = p.base && p.t > 0;
     load0[gi] = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+    float sv[NPL][8], bv_[NPL][8], sl_[NPL][8];
+    int mo[NPL][8];
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
 #pragma unroll
@@ -181,33 +180,25 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
         sl_[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
         mo[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
       }
-  };
-  auto issue_tile = [&](auto GI, auto HALF) {   // HALF: 0 = rows [0, NMAX/2), 1 = the rest, 2 = all
-    constexpr int gi = decltype(GI)::value;
-    constexpr int P0 = decltype(HALF)::value == 1 ? NMAX / 4 : 0;               // row pairs
-    constexpr int P1 = decltype(HALF)::value == 0 ? NMAX / 4 : NMAX / 2;
-    const int b = bg[gi];
-    // from the row-paired copy two rows per 16-byte load (prologue: pair_rows_kernel), else row
-    // by row
-    if (p.embP) {
-      const float4 *srcP = reinterpret_cast<const float4 *>(p.embP) + (size_t)b * ((N + 1) / 2) * 64 + lane;
+    // the tile: from the row-paired copy two rows per 16-byte load (prologue: pair_rows_kernel),
+    // else row by row
+    const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
+    const float4 *srcP = p.embP ? reinterpret_cast<const float4 *>(p.embP) +
+                                      (size_t)b * ((N + 1) / 2) * 64 + lane : nullptr;
+    static_assert(NH % 2 == 0, "the first half of the tile is a whole number of row pairs");
+    if (srcP) {
 #pragma unroll
-      for (int i = P0; i < P1; ++i) {
+      for (int i = 0; i < NH / 2; ++i) {
         const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
         e[gi][2 * i] = make_float2(v.x, v.y);
         e[gi][2 * i + 1] = make_float2(v.z, v.w);
       }
     } else {
-      const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
 #pragma unroll
-      for (int n = 2 * P0; n < 2 * P1; ++n)
+      for (int n = 0; n < NH; ++n)
         e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
     }
-  };
-  static_assert(NMAX % 4 == 0, "each half of the tile is a whole number of row pairs");
-  auto glimpse = [&](auto GI) {
-    constexpr int gi = decltype(GI)::value;
-    const int g = wave * GPW + gi;
+    __builtin_amdgcn_sched_barrier(0);
     float sc[NPL][8];  // score + additive scrambled mask
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
@@ -219,103 +210,89 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
         sc[i][h] = v + (float)mo[i][h];
       }
     }
-    if (!DEFER) load_env(gi, bg[gi]);
-    if (p.dbg == 1) { if (e[gi][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; return; }
-    // glimpse attention weights (lane = n), one wave-wide shift for all eight heads
-    float s[NPL][8], mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const float v = inN[i] ? sc[i][h] : -INFINITY;
-        s[i][h] = v;
-        mx = fmaxf(mx, v);
-      }
-    const float M = wave_max(mx);
-    float *ag = a_s + (size_t)g * NMAX * 8;
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      float ev[NPL], es = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(s[i][h] - M) : 0.f; es += ev[i]; }
-      float sum = wave_sum(es);
-      if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
-        float hm = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) hm = fmaxf(hm, s[i][h]);
-        hm = wave_max(hm);
-        es = 0.f;
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(s[i][h] - hm) : 0.f; es += ev[i]; }
-        sum = wave_sum(es);
-      }
-      float r = __builtin_amdgcn_rcpf(sum);
-      r = fmaf(fmaf(-sum, r, 1.f), r, r);
+    if (!DEFER) load_env(gi, b);
+    if (p.dbg == 1) { if (e[gi][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
+
+    // ---- glimpse attention weights (lane = n), one wave-wide shift for all eight heads -----
+    {
+      float s[NPL][8], mx = -INFINITY;
 #pragma unroll
       for (int i = 0; i < NPL; ++i)
-        if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const float v = inN[i] ? sc[i][h] : -INFINITY;
+          s[i][h] = v;
+          mx = fmaxf(mx, v);
+        }
+      const float M = wave_max(mx);
+      float *ag = a_s + (size_t)g * NMAX * 8;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        float ev[NPL], es = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(s[i][h] - M) : 0.f; es += ev[i]; }
+        float sum = wave_sum(es);
+        if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+          float hm = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) hm = fmaxf(hm, s[i][h]);
+          hm = wave_max(hm);
+          es = 0.f;
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(s[i][h] - hm) : 0.f; es += ev[i]; }
+          sum = wave_sum(es);
+        }
+        float r = __builtin_amdgcn_rcpf(sum);
+        r = fmaf(fmaf(-sum, r, 1.f), r, r);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+          if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
+      }
     }
-  };
-  auto zsum = [&](auto GI) {
-    constexpr int gi = decltype(GI)::value;
-    const int g = wave * GPW + gi;
+    if (srcP) {
+#pragma unroll
+      for (int i = NH / 2; i < NMAX / 2; ++i) {
+        const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        e[gi][2 * i] = make_float2(v.x, v.y);
+        e[gi][2 * i + 1] = make_float2(v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int n = NH; n < NMAX; ++n)
+        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // a_s of this graph is written and read by this wave only: LDS ops of one wave are ordered
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-    // z_h[2l..2l+1] = sum_n a[h][n] * e[n][2l..2l+1]
-    float2 z[8];
+    // ---- z_h[2l..2l+1] = sum_n a[h][n] * e[n][2l..2l+1] -------------------------------------
+    {
+      float2 z[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
-    const float4 *ap = reinterpret_cast<const float4 *>(a_s + (size_t)g * NMAX * 8);
-    // the weights of node n + 1 are read (LDS broadcast) before node n's sixteen FMAs are
-    // issued: left to the compiler, every node started with an LDS round trip
-    float4 a0 = ap[0], a1 = ap[1];
+      for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
+      const float4 *ap = reinterpret_cast<const float4 *>(a_s + (size_t)g * NMAX * 8);
+      // the weights of node n + 1 are read (LDS broadcast) before node n's sixteen FMAs are
+      // issued: left to the compiler, every node started with an LDS round trip
+      float4 a0 = ap[0], a1 = ap[1];
 #pragma unroll
-    for (int n = 0; n < NMAX; ++n) {
-      const float4 c0 = a0, c1 = a1;
-      if (n + 1 < NMAX) { a0 = ap[2 * n + 2]; a1 = ap[2 * n + 3]; }
-      __builtin_amdgcn_sched_barrier(0);
-      if (n < N) {
-        const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      for (int n = 0; n < NMAX; ++n) {
+        const float4 c0 = a0, c1 = a1;
+        if (n + 1 < NMAX) { a0 = ap[2 * n + 2]; a1 = ap[2 * n + 3]; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n < N) {
+          const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          z[h].x = fmaf(av[h], e[gi][n].x, z[h].x);
-          z[h].y = fmaf(av[h], e[gi][n].y, z[h].y);
+          for (int h = 0; h < 8; ++h) {
+            z[h].x = fmaf(av[h], e[gi][n].x, z[h].x);
+            z[h].y = fmaf(av[h], e[gi][n].y, z[h].y);
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
 #pragma unroll
-    for (int h = 0; h < 8; ++h)
-      *reinterpret_cast<float2 *>(zs + g * TL_ZG + h * 128 + 2 * lane) = z[h];
-  };
-  using G0 = std::integral_constant<int, 0>;
-  using G1 = std::integral_constant<int, GPW - 1>;   // == G0 when GPW == 1
-  using H0 = std::integral_constant<int, 0>;
-  using H1 = std::integral_constant<int, 1>;
-  using HA = std::integral_constant<int, 2>;
-  // one graph per wave (N > 64, 200+ tile registers): the second half of the tile is requested
-  // behind the glimpse weights, whose temporaries would not fit beside the whole tile
-  constexpr bool SPLIT = GPW == 1;
-  if (proc[0]) {
-    issue_small(G0{});
-    if (SPLIT) issue_tile(G0{}, H0{}); else issue_tile(G0{}, HA{});
-  }
-  if (GPW > 1 && proc[GPW - 1]) {
-    if (!proc[0]) issue_small(G1{});
-    issue_tile(G1{}, HA{});
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (proc[0]) {
-    glimpse(G0{});
-    if (SPLIT && p.dbg != 1) { issue_tile(G0{}, H1{}); __builtin_amdgcn_sched_barrier(0); }
-    if (GPW > 1 && proc[GPW - 1] && p.dbg != 1) issue_small(G1{});
-    if (p.dbg != 1) zsum(G0{});
-  }
-  if (GPW > 1 && proc[GPW - 1]) {
-    if (proc[0] && p.dbg == 1) issue_small(G1{});
-    glimpse(G1{});
-    if (p.dbg != 1) zsum(G1{});
+      for (int h = 0; h < 8; ++h)
+        *reinterpret_cast<float2 *>(zs + g * TL_ZG + h * 128 + 2 * lane) = z[h];
+    }
   }
   if (p.dbg == 1 || p.dbg == 2) return;
   __syncthreads();
