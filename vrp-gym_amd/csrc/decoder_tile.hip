@@ -1,9 +1,9 @@
 // Decode + env step from the RAW embedding tile (the "streaming formulation" of SURVEY.md
 // 8d): a graph-step reads its (N,128) fp32 tile ONCE -- exactly the algorithmic 512 N bytes --
 // instead of one 32 N-byte row of the pointer-logit table per selectable node.  It wins
-// wherever many nodes are still selectable: the early steps of an episode at any N, and every
-// step at N > 64.  vrp_decode_step launches it for the graphs with at least `sel_lo`
-// selectable nodes and the table kernel (decoder.hip) for the rest.
+// wherever many nodes are still selectable.  At 64 < N <= 104 vrp_decode_step launches it for the
+// graphs with at least `sel_lo` selectable nodes and the table kernel (decoder.hip) for the rest;
+// at N <= 40 (large batches) for the first steps of an episode, while every graph qualifies.
 //
 // Same algebra as the table kernel:
 //   a[h][n]   glimpse weights from the score rows (row0 | SL[last] + base) + scrambled masks
@@ -11,10 +11,12 @@
 //   o_h       = Wv_h z_h + bv_h,  w = M o + mb                matrix cores, 16 graphs per tile
 //   u_n       = 10 tanh(e_n . w + cvec_n)                     VALU + cross-lane reduce-scatter
 // Workgroup = 8 waves = 8*GPW graphs.  A wave keeps its graphs' tiles in registers (lane =
-// two embedding columns: e[n] is a float2, 512-byte coalesced row loads) through both passes
-// over them.  The two weight folds are batched over the workgroup's graphs as the 16 rows of
-// v_mfma_f32_16x16x4_f32 (A = z / o rows from LDS, B = weight fragments streamed from L2: the
-// 384 KB of folded weights are shared by every workgroup and step).  The partial dot products
+// two embedding columns: e[n] is a float2; filled two rows per 16-byte load from the row-paired
+// copy DecWs::embP where the prologue built one, else row by row) through both passes over them.
+// The two weight folds are batched over the workgroup's graphs as the 16 rows of
+// v_mfma_f32_16x16x4_f32 (A = z / o rows from LDS, B = weight fragments streamed from L2 in
+// MFMA fragment order, Derived::WvP/MP: the 384 KB of folded weights are shared by every
+// workgroup and step).  The partial dot products
 // e_n . w of a lane's two columns are summed over the 64 lanes by a butterfly reduce-scatter
 // that leaves node n's total in lane n -- the layout the action/env code wants.
 #include "decoder_step.h"
