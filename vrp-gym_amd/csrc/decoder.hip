@@ -209,6 +209,26 @@ __device__ __forceinline__ void flag_notdone(int32_t *flag) { *flag = 1; }
 // WPG = waves (= graphs) per workgroup: 4 for large batches; 1 for small ones, where the
 // kernel is latency-bound and single-wave workgroups spread over more CUs and never wait
 // for a sibling wave at the two barriers.
+// Barrier between a wave's LDS writes (a_s, u_s) and their reads.  a_s / u_s / sel_s are private
+// to a wave, and the LDS operations of one wave execute in program order: all that is needed is to
+// keep the compiler from reordering them.  Single-wave workgroups therefore skip s_barrier --
+// __syncthreads would also drain every global load in flight (vmcnt(0)); multi-wave workgroups
+// keep it (their waves share nothing either, but the round-1 tuning was done with it in place).
+template <int WPG>
+__device__ __forceinline__ void step_sync() {
+#ifdef VRP_RT_NO_BARRIER   // experiment: no workgroup barrier in the four-wave instances either
+  constexpr bool wave_only = true;
+#else
+  constexpr bool wave_only = WPG == 1;
+#endif
+  if constexpr (wave_only) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 template <int NPL, int WPG>  // nodes per lane: 1 (N <= 64) or 2 (N <= 128); node = lane + 64*i
 __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_step_rt_kernel(StepParams p) {
   constexpr int NMAXL = 64 * NPL;
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
         if (inN[i]) a_s[wave][h * N + lane + 64 * i] = e[i][h] * r;
     }
   }
-  __syncthreads();
+  step_sync<WPG>();
 
   // ---- u_m = sum_{h,n} a[h][n] * RT[m][h][n] + cvec[m]  for selectable m ---------------
   {
@@ -408,7 +428,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
       }
     }
   }
-  __syncthreads();
+  step_sync<WPG>();
 
   float u[NPL];
 #pragma unroll

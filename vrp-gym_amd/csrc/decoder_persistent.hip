@@ -41,6 +41,15 @@ struct PersistParams {
   int32_t *census;            // residency census mode (vrp_persistent_capacity): {arrived, saw all}
 };
 
+// The workgroup is ONE wave: its LDS operations execute in program order, so a barrier between
+// writing and reading a_s / u_s only has to keep the compiler from reordering them -- s_barrier
+// would also drain every global load in flight (__syncthreads waits for vmcnt(0)), among them the
+// prefetched rows of the logit table and the next step's score row.
+#define PERSIST_WAVE_SYNC()                                  \
+  do {                                                       \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */     \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
 #define PERSIST_VALID (1ull << 63)
 #define PERSIST_SPIN_LIMIT (1 << 20)  // ~1 s of polling; a legitimate wait is microseconds
 
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
         if (inN) a_s[h * N + lane] = e[h] * r;
       }
     }
-    __syncthreads();
+    PERSIST_WAVE_SYNC();
     // ---- u_m = sum_{h,n} a[h][n] * RT[m][h][n] + cvec[m]  for selectable m ---------------
     {
       const float4 *aw = reinterpret_cast<const float4 *>(a_s) + part;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
         }
       }
     }
-    __syncthreads();
+    PERSIST_WAVE_SYNC();
     float u = -INFINITY;
     if (inN && !own_mask) u = 10.f * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
     if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)t * B + b) * N + lane] = (uint8_t)own_mask;
