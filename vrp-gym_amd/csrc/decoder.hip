@@ -310,6 +310,11 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   const double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
   float accl = 0.f, accp = 0.f;
   if (!p.decode_only) { accl = p.io.acc_loss[b]; accp = p.io.acc_logp[b]; }
+  // the batch was done before this launch (tsp.py:95): nothing to commit, and a fixed-length
+  // loop of 2(N-1) launches spends its tail here (VRP-100 x 2048: 86 of 198 launches, 10.7 us
+  // each when they decoded first).  Wave-uniform and workgroup-uniform, ahead of any barrier;
+  // the loads issued above are simply dropped.
+  if (prev_notdone == 0) return;
 
   // selectable nodes (own mask == 0); their RT rows are the only ones fetched
   unsigned long long sel[NPL];
@@ -323,6 +328,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   }
   // graphs with many selectable nodes may belong to the raw-tile kernel (decoder_tile.hip)
   const bool mine = nsel >= p.sel_lo && nsel < p.sel_hi;
+  if (WPG == 1 && !mine) return;   // single-wave workgroup: no barrier to keep (the raw-tile kernel's graph)
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
   const int total = mine ? ((nsel + 7) >> 3) * nchunk : 0;  // work items (pass, chunk), wave-uniform
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
                                                                idx & 63));
   }
   idx = __builtin_amdgcn_readfirstlane(idx);
-  if (!active || !mine || prev_notdone == 0) return;  // wave-uniform; no barriers below
+  if (!active || !mine) return;  // wave-uniform; no barriers below
 
   // latency mode: next step's score row = SL[b][idx], copied while the env step runs (after
   // step 0 of TSP/VRP the table does not exist yet: its builder writes the row itself)
@@ -601,7 +607,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.Wv = d.Wproj + (size_t)1152 * 128; p.M = d.M;
   p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
-  p.sel_lo = 0; p.sel_hi = 1 << 30; p.tile_lo = 0;
+  p.sel_lo = 0; p.sel_hi = 1 << 30; p.tile_lo = 0; p.skip_curs = 0;
   static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
   p.dbg = dbg;
   static const int stagger = getenv("VRP_TILE_STAGGER") ? atoi(getenv("VRP_TILE_STAGGER")) : 0;
@@ -644,8 +650,11 @@ static int tile_threshold(int kind, int N) {
   static const int v = getenv("VRP_TILE_MIN_SEL") ? atoi(getenv("VRP_TILE_MIN_SEL")) : 0;
   if (v > 0) return v;
   // measured crossovers (tools/step_probe.py): N = 100: a table step costs 1.21 us per
-  // selectable node at B = 2048 against 45-53 us flat for the raw-tile kernel (the mean step
-  // of an episode is within 1 % for thresholds of 34..42 nodes); N = 40 (large batches):
+  // selectable node at B = 2048 against 38 us flat for the raw-tile kernel; with one kernel per
+  // step (launch_step_any) the mean step of a VRP-100 x 2048 sampling episode is 33.9 / 33.8 /
+  // 33.6 / 33.7 / 33.5 / 34.1 / 34.4 us for thresholds of 25 / 28 / 31 / 34 / 37 / 40 / 44
+  // expected selectable nodes (per-graph routing at 40: 37.0); greedy, untrained (long tours):
+  // 36.0 / 37.1 / 38.3 at 28 / 34 / 40.  N = 40 (large batches):
   // 102 / 83 / 77 / 77 / 77 / 74 / 71 us for the first seven steps of a TSP episode, 66 us at
   // the eighth, against 65.7 us flat for the raw-tile kernel (round 3: fold weights in fragment
   // order): threshold 33 of 39 selectable nodes measured best (42.8 us per step, against 43.9 for
@@ -653,16 +662,15 @@ static int tile_threshold(int kind, int N) {
   // VRP at N <= 40 (the tile kernel runs only while EVERY graph is above the threshold, see
   // launch_step_any): 28 of 39 measured best (38.5 us per step; 30 / 33 / 35: 38.7 / 39.3 / 39.5;
   // table kernel alone 40.0)
-  if (N > 64) return (40 * N + 50) / 100;
+  if (N > 64) return (31 * N + 50) / 100;
   return kind == VRP_KIND_VRP ? (28 * N + 20) / 40 : (33 * N + 20) / 40;
 }
 // N > 64: ON by default -- a table row is 32 N bytes per selectable node, the raw tile 512 N
 // bytes whatever the mask, and since its weight folds stream their fragments line by line
-// (decoder_tile.hip) the tile kernel wins the first half of an episode: VRP-100 x 2048
-// sampling 63 -> 42 us per step (each graph goes to one kernel by its own count; while the batch
-// straddles the threshold both kernels run, about seven steps of an episode).
-// IRP stays with the table kernel: its capacity overlay leaves few nodes selectable and spreads
-// the graphs over the whole range, so both kernels would run at every step (64 vs 57 us).
+// (decoder_tile.hip) the tile kernel wins the first two thirds of an episode: VRP-100 x 2048
+// sampling 63 -> 33.6 us per step.
+// IRP stays with the table kernel: its capacity overlay leaves few nodes selectable from the
+// first step on (64 vs 57 us).
 static bool hybrid_shape(int kind, int B, int N) {
   static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
   static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
@@ -689,10 +697,10 @@ extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
     return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> (first steps) | decode_step_rt_kernel<1, 4>"
                    : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
-                          ? (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)"
-                                      : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 1> (by selectable nodes)")
-                          : (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)"
-                                      : "decode_step_tile_mfma_kernel<104, 1, 8> | decode_step_rt_kernel<2, 4> (by selectable nodes)"));
+                          ? (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> (first steps) | decode_step_rt_kernel<2, 1>"
+                                      : "decode_step_tile_mfma_kernel<104, 1, 8> (first steps) | decode_step_rt_kernel<2, 1>")
+                          : (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> (first steps) | decode_step_rt_kernel<2, 4>"
+                                      : "decode_step_tile_mfma_kernel<104, 1, 8> (first steps) | decode_step_rt_kernel<2, 4>"));
   const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
   if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
   return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";
@@ -726,13 +734,29 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     // is served at least every other step, the depot may be open), and fewest (VRP: the mask is
     // the visited row and a step visits at most one customer; IRP: the capacity overlay can
     // close any number of them)
-    const int most = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t : N - (p.t + 1) / 2;
-    const int least = (p.kind == VRP_KIND_TSP) ? N - 1 - p.t
-                      : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - p.t) : 0);
+    auto most_at = [&](int t) { return (p.kind == VRP_KIND_TSP) ? N - 1 - t : N - (t + 1) / 2; };
+    auto least_at = [&](int t) {
+      return (p.kind == VRP_KIND_TSP) ? N - 1 - t : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - t) : 0);
+    };
+    static const bool split_ok = getenv("VRP_TILE_HYBRID") != nullptr;   // A/B aid: per-graph routing
+    if (!split_ok) {
+      // ONE kernel per step, chosen by the step number alone (the raw-tile kernel is correct for
+      // any mask; the choice is a cost estimate).  N <= 64: the tile kernel while EVERY graph is
+      // above the threshold.  N > 64: while the expected count -- a quarter of the way from the
+      // fewest to the most (depot returns are the minority of a tour's steps) -- is.  Per-graph
+      // routing ran BOTH kernels at full cost while a batch straddled the threshold (VRP-100 x
+      // 2048: six steps of 34 + 44 us) and an empty tile launch (4.7 us) for fifty steps after.
+      auto tile_step = [&](int t) {
+        const int lo = least_at(t), hi = most_at(t);
+        return (N <= 64 ? lo : lo + (hi - lo) / 4) >= th;
+      };
+      if (!tile_step(p.t)) return launch_rt(p, flags, st);
+      StepParams pt = p;
+      pt.skip_curs = (p.t + 1 < p.max_steps && tile_step(p.t + 1)) ? 1 : 0;
+      return vrp_launch_tile_mfma_step(pt, st);
+    }
+    const int most = most_at(p.t), least = least_at(p.t);
     if (most < th) return launch_rt(p, flags, st);
-    // N <= 64: never both kernels for one step -- the tile kernel only while every graph qualifies
-    static const bool split_ok = getenv("VRP_TILE_HYBRID") != nullptr;   // A/B aid
-    if (N <= 64 && least < th && !split_ok) return launch_rt(p, flags, st);
     StepParams pt = p, pr = p;
     pt.sel_lo = least >= th ? 0 : th;   // every graph above the threshold: no routing check
     pt.tile_lo = th;

@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     // (tile_lo > 0) a graph that keeps at least tile_lo selectable nodes comes back to this
     // kernel, which reads SL and base itself (the update costs 7 us per step at 2048 x 100:
     // 3.2 KB of table row per graph from HBM, at the very end of the workgroup)
-    if (B <= 2048 && (p.tile_lo <= 0 || nsel_next < p.tile_lo) &&
+    if (B <= 2048 && !p.skip_curs && (p.tile_lo <= 0 || nsel_next < p.tile_lo) &&
         !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
       const size_t row = (size_t)b * 8 * N;
       const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;

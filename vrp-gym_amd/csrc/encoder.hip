@@ -1430,7 +1430,6 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
     f32x4v acc[RT16];
     for (int st = 0; st < nst; ++st) {
       const int cb = st / nkc, kc = st - cb * nkc;
-      const int col = cb * 128 + wave * 16 + i16;
       if (kc == 0) {
 #pragma unroll
         for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
