@@ -169,9 +169,9 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
 #define VRP_STEP_NO_FIRST_ROW 8 /* t == 0: the caller runs vrp_decode_first_row itself */
 #define VRP_STEP_THROUGHPUT_KERNEL 16 /* B <= 2048: use the large-batch variant (4 graphs per
                                          workgroup, score row read by pointer chase) anyway */
-#define VRP_STEP_TABLE_KERNEL 64 /* table-driven kernel for every graph, also where the dispatch
-                                    would route graphs with many selectable nodes to the raw-tile
-                                    kernel (64 < N <= 104) */
+#define VRP_STEP_TABLE_KERNEL 64 /* table-driven kernel at every step, also where the dispatch
+                                    would give an episode's first steps to the raw-tile kernel
+                                    (64 < N <= 104; 32 < N <= 40 at B > 2048) */
 #define VRP_STEP_NO_PERSISTENT 32 /* vrp_rollout / vrp_rollout_steps[_range]: one launch per step
                                      even where the persistent multi-step kernel applies (B <= 2048,
                                      3 <= N <= 63, no logits trace, no teacher forcing) */

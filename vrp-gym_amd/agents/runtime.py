@@ -402,7 +402,7 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
     trace: keep actions, per-step logits and log-probs (the logits trace needs one launch per
     step); step_trace: actions and per-step log-probs only; persistent=False: one launch per
     step even where the persistent multi-step kernel applies (A/B and tests); table_kernel:
-    the table-driven step kernel for every graph (no per-graph routing to the raw-tile one);
+    the table-driven step kernel at every step (the raw-tile one takes no first steps);
     reset_env: start a fresh episode on the instances in place (the state part of env.reset():
     visited, current_location, load, step_count) inside the rollout's own set-up kernel."""
     dev = _require_cuda(model)

@@ -326,12 +326,9 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     if (s_i) sel_s[wave][nsel + __popcll(sel[i] & ((1ull << lane) - 1ull))] = lane + 64 * i;
     nsel += __popcll(sel[i]);
   }
-  // graphs with many selectable nodes may belong to the raw-tile kernel (decoder_tile.hip)
-  const bool mine = nsel >= p.sel_lo && nsel < p.sel_hi;
-  if (WPG == 1 && !mine) return;   // single-wave workgroup: no barrier to keep (the raw-tile kernel's graph)
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
-  const int total = mine ? ((nsel + 7) >> 3) * nchunk : 0;  // work items (pass, chunk), wave-uniform
+  const int total = ((nsel + 7) >> 3) * nchunk;  // work items (pass, chunk), wave-uniform
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
   // measured (tools/step_probe.py): three items in flight are best at 8192 graphs, two in
   // the latency mode (512..2048 graphs)
@@ -442,12 +439,12 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
     u[i] = -INFINITY;
     if (inN[i] && !own_mask[i])
       u[i] = 10.f * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
-    if (active && mine && p.io.logits && inN[i])
+    if (active && p.io.logits && inN[i])
       p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
-    if (active && mine && p.io.mask_trace && inN[i])
+    if (active && p.io.mask_trace && inN[i])
       p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] = (uint8_t)own_mask[i];
   }
-  if (active && mine && p.io.load_trace && lane == 0)
+  if (active && p.io.load_trace && lane == 0)
     p.io.load_trace[(size_t)p.t * B + b] = (float)load0;
 
   // lowest node index among the maxima (torch CPU argmax): slot 0 holds nodes < 64
@@ -500,7 +497,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
                                                                idx & 63));
   }
   idx = __builtin_amdgcn_readfirstlane(idx);
-  if (!active || !mine) return;  // wave-uniform; no barriers below
+  if (!active) return;  // wave-uniform; no barriers below
 
   // latency mode: next step's score row = SL[b][idx], copied while the env step runs (after
   // step 0 of TSP/VRP the table does not exist yet: its builder writes the row itself)
@@ -607,7 +604,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.Wv = d.Wproj + (size_t)1152 * 128; p.M = d.M;
   p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
-  p.sel_lo = 0; p.sel_hi = 1 << 30; p.tile_lo = 0; p.skip_curs = 0;
+  p.skip_curs = 0;
   static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
   p.dbg = dbg;
   static const int stagger = getenv("VRP_TILE_STAGGER") ? atoi(getenv("VRP_TILE_STAGGER")) : 0;
@@ -672,15 +669,13 @@ static int tile_threshold(int kind, int N) {
 // IRP stays with the table kernel: its capacity overlay leaves few nodes selectable from the
 // first step on (64 vs 57 us).
 static bool hybrid_shape(int kind, int B, int N) {
-  static const bool on = getenv("VRP_TILE_HYBRID") != nullptr;        // A/B aids
-  static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;
+  static const bool off = getenv("VRP_TILE_NO_HYBRID") != nullptr;   // A/B aid
   if (N > 64) return !off && kind != VRP_KIND_IRP && vrp_tile_mfma_supported(N);
   // 32 < N <= 40, large batches, TSP and VRP: the first steps of an episode -- while EVERY graph
   // still has at least 33 of 39 nodes selectable -- go to the raw-tile kernel, the rest to the table
-  // kernel: exactly one kernel runs per step (launch_step_any never splits a batch at these N; a
-  // VRP batch that straddled the threshold would run both kernels for a dozen steps: 41.0 - 46.2
-  // us against 39.4).  IRP's capacity overlay closes nodes from the first step on: table kernel.
-  (void)on;
+  // kernel: exactly one kernel runs per step (a VRP batch split per graph ran both kernels for a
+  // dozen steps: 41.0 - 46.2 us against 39.4).  IRP's capacity overlay closes nodes from the first
+  // step on: table kernel.
   return !off && B > 2048 && N > 32 && N <= 40 && kind != VRP_KIND_IRP;
 }
 
@@ -738,32 +733,21 @@ static int launch_step_any(const StepParams &p, int flags, hipStream_t st) {
     auto least_at = [&](int t) {
       return (p.kind == VRP_KIND_TSP) ? N - 1 - t : (p.kind == VRP_KIND_VRP ? max(0, N - 2 - t) : 0);
     };
-    static const bool split_ok = getenv("VRP_TILE_HYBRID") != nullptr;   // A/B aid: per-graph routing
-    if (!split_ok) {
-      // ONE kernel per step, chosen by the step number alone (the raw-tile kernel is correct for
-      // any mask; the choice is a cost estimate).  N <= 64: the tile kernel while EVERY graph is
-      // above the threshold.  N > 64: while the expected count -- a quarter of the way from the
-      // fewest to the most (depot returns are the minority of a tour's steps) -- is.  Per-graph
-      // routing ran BOTH kernels at full cost while a batch straddled the threshold (VRP-100 x
-      // 2048: six steps of 34 + 44 us) and an empty tile launch (4.7 us) for fifty steps after.
-      auto tile_step = [&](int t) {
-        const int lo = least_at(t), hi = most_at(t);
-        return (N <= 64 ? lo : lo + (hi - lo) / 4) >= th;
-      };
-      if (!tile_step(p.t)) return launch_rt(p, flags, st);
-      StepParams pt = p;
-      pt.skip_curs = (p.t + 1 < p.max_steps && tile_step(p.t + 1)) ? 1 : 0;
-      return vrp_launch_tile_mfma_step(pt, st);
-    }
-    const int most = most_at(p.t), least = least_at(p.t);
-    if (most < th) return launch_rt(p, flags, st);
-    StepParams pt = p, pr = p;
-    pt.sel_lo = least >= th ? 0 : th;   // every graph above the threshold: no routing check
-    pt.tile_lo = th;
-    pr.sel_hi = th;
-    if (int r = vrp_launch_tile_mfma_step(pt, st)) return r;
-    if (least >= th) return 0;  // every graph was the tile kernel's
-    return launch_rt(pr, flags, st);
+    // ONE kernel per step, chosen by the step number alone (the raw-tile kernel is correct for
+    // any mask; the choice is a cost estimate).  N <= 64: the tile kernel while EVERY graph is
+    // above the threshold.  N > 64: while the expected count -- a quarter of the way from the
+    // fewest to the most (depot returns are the minority of a tour's steps) -- is.  (Per-graph
+    // routing, until round 3, ran BOTH kernels at full cost while a batch straddled the threshold
+    // -- VRP-100 x 2048: six steps of 34 + 44 us -- and an empty tile launch, 4.7 us, for fifty
+    // steps after: 37.0 against 33.6 us per step.)
+    auto tile_step = [&](int t) {
+      const int lo = least_at(t), hi = most_at(t);
+      return (N <= 64 ? lo : lo + (hi - lo) / 4) >= th;
+    };
+    if (!tile_step(p.t)) return launch_rt(p, flags, st);
+    StepParams pt = p;
+    pt.skip_curs = (p.t + 1 < p.max_steps && tile_step(p.t + 1)) ? 1 : 0;
+    return vrp_launch_tile_mfma_step(pt, st);
   }
   return launch_rt(p, flags, st);
 }

@@ -17,9 +17,6 @@ struct StepParams {
   const float *RT, *cvec;
   int dbg;                      // tuning aid (VRP_TILE_DBG): stop the tile kernel after phase dbg
   int stagger;                  // raw-tile kernel: odd workgroups start this many x 64 cycles late
-  int sel_lo, sel_hi;           // a kernel handles the graphs with sel_lo <= selectable nodes < sel_hi
-  int tile_lo;                  // per-graph routing threshold in force (0: none): a graph that keeps
-                                // at least this many selectable nodes meets the raw-tile kernel again
   int skip_curs;                // raw-tile kernel: the next step is the raw-tile kernel's too (the
                                 // host's per-step schedule), `curs` need not be kept current
   vrp_env env;

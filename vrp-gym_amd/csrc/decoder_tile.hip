@@ -1,9 +1,9 @@
 // Decode + env step from the RAW embedding tile (the "streaming formulation" of SURVEY.md
 // 8d): a graph-step reads its (N,128) fp32 tile ONCE -- exactly the algorithmic 512 N bytes --
 // instead of one 32 N-byte row of the pointer-logit table per selectable node.  It wins
-// wherever many nodes are still selectable.  At 64 < N <= 104 vrp_decode_step launches it for the
-// graphs with at least `sel_lo` selectable nodes and the table kernel (decoder.hip) for the rest;
-// at N <= 40 (large batches) for the first steps of an episode, while every graph qualifies.
+// wherever many nodes are still selectable: vrp_decode_step launches it for the first steps of
+// an episode (64 < N <= 104: about two thirds of them; N <= 40, large batches: while every graph
+// keeps most of its nodes) and the table kernel (decoder.hip) afterwards.
 //
 // Same algebra as the table kernel:
 //   a[h][n]   glimpse weights from the score rows (row0 | SL[last] + base) + scrambled masks
@@ -117,38 +117,22 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     if (!p.decode_only) { accl[gi] = p.io.acc_loss[b]; accp[gi] = p.io.acc_logp[b]; }
   };
 
-  // selectable nodes decide which kernel handles a graph at this step; a workgroup none of
-  // whose graphs is this kernel's leaves at once (hybrid dispatch launches both kernels while
-  // the batch straddles the threshold)
-  // (when the host knows that every graph is this kernel's -- no routing, or a step at which even
-  // the graph with the fewest selectable nodes is above the threshold -- nothing waits for the
-  // mask rows: the score rows and the tile are requested in the same round trip)
-  const bool routed = p.sel_lo > 0 || p.sel_hi < (1 << 30);
+  // (the host picks ONE kernel per step from the step number, launch_step_any: nothing here
+  // waits for the mask rows -- the score rows and the tile are requested in the same round trip)
   int lastn[GPW];
-  {
-    int any = 0;
 #pragma unroll
-    for (int gi = 0; gi < GPW; ++gi) {
-      const int braw = blockIdx.x * GPB + wave * GPW + gi;
-      const bool active = braw < B;
-      const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
-      bg[gi] = b;
-      lastn[gi] = p.t > 0 ? p.last[b] : 0;   // requested with the mask rows, not behind them
+  for (int gi = 0; gi < GPW; ++gi) {
+    const int braw = blockIdx.x * GPB + wave * GPW + gi;
+    const bool active = braw < B;
+    const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
+    bg[gi] = b;
+    lastn[gi] = p.t > 0 ? p.last[b] : 0;   // requested with the mask rows, not behind them
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const bool in = lane + 64 * i < N;
-        own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
-      }
-      proc[gi] = active;
-      if (routed) {
-        int nsel = 0;
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) nsel += __popcll(__ballot(lane + 64 * i < N && !own_mask[gi][i]));
-        proc[gi] = active && nsel >= p.sel_lo && nsel < p.sel_hi;
-      }
-      any |= proc[gi] ? 1 : 0;
+    for (int i = 0; i < NPL; ++i) {
+      const bool in = lane + 64 * i < N;
+      own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
     }
-    if (routed && !__syncthreads_or(any)) return;
+    proc[gi] = active;
   }
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
@@ -517,7 +501,6 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
 #pragma unroll
       for (int i = 0; i < NPL; ++i) if (lane + 64 * i == de) vs[i] = 0;
     }
-    int nsel_next = 0;   // selectable nodes of the next step
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       int mk = vs[i];
@@ -526,7 +509,6 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
         p.env.visited[(size_t)b * N + lane + 64 * i] = (uint8_t)vs[i];
         mask_out[(size_t)b * N + lane + 64 * i] = (uint8_t)mk;
       }
-      nsel_next += __popcll(__ballot(inN[i] && !mk));
     }
     if (lane == 0) {
       p.env.cur[b] = idx;
@@ -541,11 +523,10 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     }
     // (last: a register reload from scratch behind these stores would wait for them to land)
     // latency mode of the table kernel reads next step's row from `curs`: keep it current
-    // -- only when the graph's next step can be the table kernel's: under per-graph routing
-    // (tile_lo > 0) a graph that keeps at least tile_lo selectable nodes comes back to this
-    // kernel, which reads SL and base itself (the update costs 7 us per step at 2048 x 100:
-    // 3.2 KB of table row per graph from HBM, at the very end of the workgroup)
-    if (B <= 2048 && !p.skip_curs && (p.tile_lo <= 0 || nsel_next < p.tile_lo) &&
+    // -- unless the host's schedule gives the next step to this kernel as well, which reads SL
+    // and base itself (the update costs 7 us per step at 2048 x 100: 3.2 KB of table row per
+    // graph from HBM, at the very end of the workgroup)
+    if (B <= 2048 && !p.skip_curs &&
         !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
       const size_t row = (size_t)b * 8 * N;
       const float *arow = p.SL + ((size_t)b * N + idx) * 8 * N;
