@@ -19,23 +19,22 @@ DECODE = ("decode_step_rt_kernel", "decode_persistent_kernel", "decode_step_tile
           "persistent_finalize_kernel")
 
 
-def counter_sum(d, name):
-    """(sum of the counter over all decode kernels, number of env steps they cover)"""
+def counter_sum(d, name, idle_below_kb=0.0):
+    """(sum of the counter over all decode kernels, number of env steps they cover).
+    idle_below_kb: per-step launches that fetched less than this are the no-op launches behind
+    `done` (a fixed-length loop of 2(N-1) launches; they leave at their first instruction) and
+    cover no env step."""
     total, launches, persistent = 0.0, 0, 0
-    tile_ids, rt_ids = set(), set()
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name or not any(k in r["Kernel_Name"] for k in DECODE):
                 continue
-            total += float(r["Counter_Value"])
+            v = float(r["Counter_Value"])
+            total += v
             if "decode_persistent_kernel" in r["Kernel_Name"]:
                 persistent += 1
-            elif "finalize" not in r["Kernel_Name"]:
+            elif "finalize" not in r["Kernel_Name"] and v >= idle_below_kb:
                 launches += 1
-                (tile_ids if "tile" in r["Kernel_Name"] else rt_ids).add(int(r["Dispatch_Id"]))
-    # hybrid dispatch (N > 64) launches the raw-tile and the table kernel back to back for ONE
-    # env step while the batch straddles the threshold: such a pair is one step
-    launches -= sum(1 for i in tile_ids if i + 1 in rt_ids)
     return total, launches, persistent
 
 
@@ -46,9 +45,11 @@ def main():
     res = {}
     for fd in sorted(glob.glob(os.path.join(root, "fetch_*"))):
         w = os.path.basename(fd)[len("fetch_"):]
-        fetch, launches, persistent = counter_sum(fd, "FETCH_SIZE")
+        kind, N, B = int(w.split("_")[0][4:]), int(w.split("_")[1][1:]), int(w.split("_")[2][1:])
+        # a live step fetches at least its graphs' score rows and masks (> 1 KB per graph); a no-op
+        # launch a few bytes per wave: the line is drawn at 256 B per graph (raw counter: 128 B)
+        fetch, launches, persistent = counter_sum(fd, "FETCH_SIZE", idle_below_kb=B * 128 / 1024.0)
         write, _, _ = counter_sum(os.path.join(root, "write_" + w), "WRITE_SIZE")
-        kind, N = int(w.split("_")[0][4:]), int(w.split("_")[1][1:])
         # steps covered: one per per-step launch; a persistent launch covers the rest of an episode
         # (TSP: N-1 steps per episode in all; the probe prints T for the others)
         steps = launches

@@ -252,8 +252,13 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
 
 
+  // the batch was done before this launch (tsp.py:95): nothing to commit, and a fixed-length
+  // loop of 2(N-1) launches spends its tail here (VRP-100 x 2048: 86 of 198 launches, 10.7 us
+  // each when they decoded first, 4.3 us now).  One scalar round trip ahead of the loads below
+  // (checked behind them, a no-op launch still fetched its 9 KB of score rows per graph).
+  // Workgroup-uniform, ahead of any barrier.
+  if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
   // ---- entry: issue every action-independent load --------------------------------
-  const int prev_notdone = (!p.decode_only && p.t > 0) ? p.io.notdone[p.t - 1] : 1;
   const size_t row = (size_t)b * 8 * N;
   // this step's complete glimpse score row: row0 at t = 0, else table row SL[b][last]
   // (one dependent load: last[b] was written by the previous launch)
@@ -310,12 +315,6 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   const double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
   float accl = 0.f, accp = 0.f;
   if (!p.decode_only) { accl = p.io.acc_loss[b]; accp = p.io.acc_logp[b]; }
-  // the batch was done before this launch (tsp.py:95): nothing to commit, and a fixed-length
-  // loop of 2(N-1) launches spends its tail here (VRP-100 x 2048: 86 of 198 launches, 10.7 us
-  // each when they decoded first).  Wave-uniform and workgroup-uniform, ahead of any barrier;
-  // the loads issued above are simply dropped.
-  if (prev_notdone == 0) return;
-
   // selectable nodes (own mask == 0); their RT rows are the only ones fetched
   unsigned long long sel[NPL];
   int nsel = 0;

@@ -616,23 +616,27 @@ int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const fl
   }
   if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
                                  st)) return r;
+  if (use_fused_prologue(N)) {
+    const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
+    if (int r = (N & 3) == 0 ? launch_prologue_vec<true>(p, st) : launch_prologue_vec<false>(p, st))
+      return r;
+  } else {
+    const int P = proj_width(N);
+    float *PROJ = w.PROJ;
+    if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, PROJ, P, B * N, P,
+                                   128, 0, st)) return r;
+    hipLaunchKernelGGL((pair_tables_kernel<8>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ, w.QG,
+                       d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.row0, w.RT);
+    VRP_CHECK_LAUNCH("pair_tables");
+  }
+  // last, so that step 0 finds the copy it reads in the caches (the tables above stream a
+  // gigabyte through them)
   if (kind != VRP_KIND_IRP && tile_pairs_shape(B, N)) {
     const size_t total = (size_t)B * ((N + 1) / 2) * 64;
     hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, emb,
                        N, w.embP, total);
     VRP_CHECK_LAUNCH("pair_rows");
   }
-  if (use_fused_prologue(N)) {
-    const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
-    return (N & 3) == 0 ? launch_prologue_vec<true>(p, st) : launch_prologue_vec<false>(p, st);
-  }
-  const int P = proj_width(N);
-  float *PROJ = w.PROJ;
-  if (int r = vrp_launch_gemm_nt(emb, 128, d.Wproj, 128, d.bproj, nullptr, 0, PROJ, P, B * N, P,
-                                 128, 0, st)) return r;
-  hipLaunchKernelGGL((pair_tables_kernel<8>), dim3(B, 2), dim3(256), 0, st, kind, N, P, PROJ, w.QG,
-                     d.qc0, d.wload, w.SG, w.C0, w.SLD, w.SL, w.row0, w.RT);
-  VRP_CHECK_LAUNCH("pair_tables");
   return 0;
 }
 
