@@ -1,0 +1,87 @@
+"""The RCCL backend on ONE GPU: dist.init_process_group("nccl", world_size=1, device_id=...) and
+every collective of agents/distributed.py on device tensors -- the in-place ReduceOp.AVG
+all-reduce of the persistent flat gradient bucket a real training step leaves behind, the cost
+all-gather, the model broadcast, the buffer averaging, and two whole training epochs through
+agent.train_epoch.  With one rank every collective is the identity, which is exactly what is
+asserted; what the test buys is that the nccl code path (communicator creation on this image,
+AVG on RCCL, device_id binding) has executed on hardware before the first multi-GPU run
+("the nccl backend path has never executed anywhere").  World-size > 1
+semantics are covered over gloo (tests/test_host_logic.py) and, where two GPUs exist, by
+tests/test_bench_multirank.py::test_bench_two_ranks_over_rccl."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+root, port = sys.argv[1], sys.argv[2]
+sys.path[:0] = [os.path.join(root, "vrp-gym_amd"), root]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)       # nccl == RCCL on ROCm
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+from agents import distributed as D
+from agents import VRPAgent
+from gym_vrp.envs import VRPEnv
+D.is_distributed = lambda: True      # one rank: run the collectives anyway
+
+def epoch(collectives):
+    torch.manual_seed(7)
+    env = VRPEnv(num_nodes=20, batch_size=64, num_draw=1, seed=69, device=dev, shard=(0, 1))
+    agent = VRPAgent(seed=69)
+    D.is_distributed = (lambda: True) if collectives else (lambda: False)
+    D.broadcast_model(agent.model); D.broadcast_model(agent.target_model)
+    out = []
+    for _ in range(2):
+        loss, cost, adv = D.global_means(*agent.train_epoch(env, 1))
+        out.append((loss, cost, adv))
+    flat = D._bucket_in_place(agent.model)
+    return agent, out, flat
+
+D.ALLREDUCE_EVENTS = []
+a1, o1, f1 = epoch(True)
+assert f1 is not None and f1.is_cuda          # the all-reduce ran in place on the flat bucket
+assert len(D.ALLREDUCE_EVENTS) == 2           # one collective per epoch
+torch.cuda.synchronize()
+assert all(s.elapsed_time(e) >= 0 for s, e in D.ALLREDUCE_EVENTS)
+D.ALLREDUCE_EVENTS = None
+a2, o2, f2 = epoch(False)
+# one rank: mean over ranks == the rank's own gradient -- identical training trajectories
+assert o1 == o2, (o1, o2)
+for p, q in zip(a1.model.parameters(), a2.model.parameters()):
+    assert torch.equal(p, q)
+
+D.is_distributed = lambda: True
+g = f1.clone()
+dist.all_reduce(f1, op=dist.ReduceOp.AVG)     # AVG on RCCL, in place: identity at world 1
+assert torch.equal(f1, g)
+c, b = D.gather_costs(torch.arange(4., device=dev), torch.arange(4., device=dev) + 10)
+assert c.tolist() == [0., 1., 2., 3.] and b.tolist() == [10., 11., 12., 13.]
+bn = a1.model.encoder.attention_layers[0].bn1.norm
+before = bn.running_mean.clone()
+D.average_buffers(a1.model)
+assert torch.allclose(bn.running_mean, before)
+assert D.rank() == 0 and D.world_size() == 1
+dist.barrier()
+dist.destroy_process_group()
+print("rccl single rank ok")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = str(31500 + os.getpid() % 2000)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(script), ROOT, port], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert "rccl single rank ok" in p.stdout
