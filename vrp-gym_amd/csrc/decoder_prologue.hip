@@ -73,14 +73,20 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
 // that one ds_read_b128 pass serves together (q = 0 with 1, 2 with 3) are 64 floats apart,
 // which makes the 16-byte reads conflict-free.
 #define PT_LD 132
-#define PT_MAXROWS 80
+#define PT_MAXROWS 112
 struct PrologueParams {
   int kind, B, N, G, npacks;
   const float *emb, *Wproj, *bproj, *QG, *qc0, *wload;
   float *SG, *C0, *SLD, *row0, *SL, *RT;
 };
 
-template <int RT_, bool VEC>
+// RING (more than five row tiles: one graph of 80 < N <= 112 rows): the rows' inner dimension
+// travels through a ring of two QUARTERS (k-steps 2 qi, 2 qi + 1 of the eight) instead of sitting
+// in registers whole -- 8 RT_ instead of 32 RT_ registers next to the 24 RT_ accumulators of a half
+// (seven tiles: 392 registers otherwise, plus the stage-2 temporaries, of the 512 a lone wave of
+// a SIMD has).  Quarter qi + 1 is requested ahead of quarter qi's 48 RT_ MFMAs; both halves read
+// the rows (the second time from L2).  Same k order per accumulator.
+template <int RT_, bool VEC, bool RING = (RT_ > 5)>
 __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                              // [4][48][PT_LD] weight slices of this head
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
   if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
   if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
   // tile pairs (tm, tn) that contain two nodes of one graph (wave-uniform bit mask)
-  unsigned needmask = 0;
+  unsigned long long needmask = 0;
   {
     const int rows = G * N;
 #pragma unroll
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
       for (int tn = 0; tn < RT_; ++tn) {
         const int lo_n = (16 * tn) / N, hi_n = min(16 * tn + 15, rows - 1) / N;
         if (16 * tm < rows && 16 * tn < rows && lo_m <= hi_n && lo_n <= hi_m)
-          needmask |= 1u << (tm * RT_ + tn);
+          needmask |= 1ull << (tm * RT_ + tn);
       }
     }
   }
@@ -125,8 +131,25 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
 
   const int koff = 64 * (q & 1) + 32 * (q >> 1);
   const float c48 = 0.14433756729740643f;  // 1/sqrt(48)
-  float ef[RT_][32];
+  float eq[RING ? 2 : 1][RT_][8];
+  auto load_quarter = [&](int pack, int qi, int buf) {
+    const size_t R0 = (size_t)pack * G * N;
+    const int valid = min(G, p.B - pack * G) * N;
+#pragma unroll
+    for (int r = 0; r < RT_; ++r) {
+      const int row = 16 * r + j16;
+      const float4 *src = reinterpret_cast<const float4 *>(
+          p.emb + (R0 + (row < valid ? row : 0)) * VRP_EMB + koff) + 2 * qi;
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (row < valid) { v0 = src[0]; v1 = src[1]; }
+      float *d = eq[RING ? buf : 0][r];
+      d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w;
+      d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+    }
+  };
+  float ef[RING ? 1 : RT_][32];
   auto load_pack = [&](int pack) {
+    if constexpr (RING) { load_quarter(pack, 0, 0); return; }
     const size_t R0 = (size_t)pack * G * N;
     const int valid = min(G, p.B - pack * G) * N;
 #pragma unroll
@@ -185,6 +208,44 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
     for (int H = 0; H < 2; ++H) {
       // ---- stage 1: transposed projections ----------------------------------------------
       f32x4 acc[2][3][RT_];
+      if constexpr (RING) {
+        // key side only (Y = 1: KK / VV of every row tile); the query side is projected tile by
+        // tile in stage 2
+#pragma unroll
+        for (int Y = 1; Y < 2; ++Y)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 bb = *reinterpret_cast<const float4 *>(bl + (2 * H + Y) * 48 + 16 * c + 4 * q);
+#pragma unroll
+            for (int r = 0; r < RT_; ++r) acc[Y][c][r] = f32x4{bb.x, bb.y, bb.z, bb.w};
+          }
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+          if (qi + 1 < 4) load_quarter(pack, qi + 1, (qi + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int Y = 1; Y < 2; ++Y)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float *wrow = wl + ((2 * H + Y) * 48 + 16 * c + j16) * PT_LD + koff;
+#pragma unroll
+              for (int kl = 0; kl < 2; ++kl) {
+                const float4 a = *reinterpret_cast<const float4 *>(wrow + 4 * (2 * qi + kl));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                  for (int r = 0; r < RT_; ++r)
+                    acc[Y][c][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        av[e], eq[qi & 1][r][4 * kl + e], acc[Y][c][r], 0, 0, 0);
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // quarter 0 for whoever runs stage 1 next: this pack's second half, or the next pack
+        if (H == 0) load_quarter(pack, 0, 0);
+        else if (pack + stride < p.npacks) load_quarter(pack + stride, 0, 0);
+      } else
 #pragma unroll
       for (int Y = 0; Y < 2; ++Y)
 #pragma unroll
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
                                                                    acc[Y][c][r], 0, 0, 0);
           }
         }
-      if (H == 1) {  // the next pack's rows: requested before the last stage 2
+      if (!RING && H == 1) {  // the next pack's rows: requested before the last stage 2
         const int nxt = pack + stride;
         if (nxt < p.npacks) load_pack(nxt);
       }
@@ -289,18 +350,68 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
                             fmaf(pa[2] + pb[2], scale, pc[2]), fmaf(pa[3] + pb[3], scale, pc[3]));
         }
       };
+      // RING: the rows of query tile tm (whole inner dimension, 32 registers), tile tm + 1
+      // requested ahead of tile tm's 96 + 12 RT_ MFMAs
+      float et[RING ? 2 : 1][32];
+      auto load_tile = [&](int tm, int buf) {
+        const size_t R0 = (size_t)pack * G * N;
+        const int row = 16 * tm + j16;
+        const float4 *src = reinterpret_cast<const float4 *>(
+            p.emb + (R0 + (row < valid ? row : 0)) * VRP_EMB + koff);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < valid) v = src[k4];
+          float *d = et[RING ? buf : 0] + 4 * k4;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+      };
+      if constexpr (RING) load_tile(0, 0);
 #pragma unroll
       for (int tm = 0; tm < RT_; ++tm) {
+        if constexpr (RING) {
+          if (tm + 1 < RT_) load_tile(tm + 1, (tm + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          // query-side projection of this tile (QL / KM, X = 2 H), same k order as stage 1
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 bb = *reinterpret_cast<const float4 *>(bl + (2 * H) * 48 + 16 * c + 4 * q);
+            acc[0][c][0] = f32x4{bb.x, bb.y, bb.z, bb.w};
+          }
+          // the three column tiles take turns: consecutive MFMAs never share an accumulator
+          const float *wrow = wl + ((2 * H) * 48 + j16) * PT_LD + koff;
+          float4 a[3], an[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[c] = *reinterpret_cast<const float4 *>(wrow + 16 * c * PT_LD);
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            if (k4 + 1 < 8) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                an[c] = *reinterpret_cast<const float4 *>(wrow + 16 * c * PT_LD + 4 * (k4 + 1));
+            }
+            const float av[3][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w},
+                                    {a[2].x, a[2].y, a[2].z, a[2].w}};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                acc[0][c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][e], et[tm & 1][4 * k4 + e],
+                                                                   acc[0][c][0], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[c] = an[c];
+          }
+        }
 #pragma unroll
         for (int tn = 0; tn < RT_; ++tn) {
-          if (!((needmask >> (tm * RT_ + tn)) & 1u)) continue;
+          if (!((needmask >> (tm * RT_ + tn)) & 1ull)) continue;
           f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r4 = 0; r4 < 4; r4 += 2) {
-              da = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], acc[0][c][tm][r4], da, 0, 0, 0);
-              db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4 + 1], acc[0][c][tm][r4 + 1], db, 0, 0, 0);
+              da = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4], acc[0][c][RING ? 0 : tm][r4], da, 0, 0, 0);
+              db = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[1][c][tn][r4 + 1], acc[0][c][RING ? 0 : tm][r4 + 1], db, 0, 0, 0);
             }
           if (VEC) {
             flush();  // previous tile
@@ -352,7 +463,9 @@ static int launch_prologue_vec(const PrologueParams &p, hipStream_t st) {
     case 2: return launch_prologue_tables<2, VEC>(p, st);
     case 3: return launch_prologue_tables<3, VEC>(p, st);
     case 4: return launch_prologue_tables<4, VEC>(p, st);
-    default: return launch_prologue_tables<5, VEC>(p, st);
+    case 5: return launch_prologue_tables<5, VEC>(p, st);
+    case 6: return launch_prologue_tables<6, VEC>(p, st);
+    default: return launch_prologue_tables<7, VEC>(p, st);
   }
 }
 

@@ -99,7 +99,10 @@ static inline bool tile_pairs_shape(int B, int N) {
 static inline size_t pairs_floats(int B, int N) {
   return tile_pairs_shape(B, N) ? (size_t)B * ((N + 1) / 2) * 256 : 0;
 }
-static inline int fused_max_rows(int N) { return (N & 3) == 0 ? 80 : 64; }
+// rows of a (pack of graphs, head) unit of the fused prologue kernel: 80 (five 16-row tiles, packs
+// of up to four graphs), 64 when N is not a multiple of four (element-wise table stores), and
+// ONE graph of up to 112 rows (seven tiles) for 80 < N <= 112
+static inline int fused_max_rows(int N) { return (N & 3) == 0 ? (N > 80 ? 112 : 80) : 64; }
 static inline bool use_rtable(int N) { return N <= VRP_RT_MAX_N; }
 // A/B aid: VRP_PROLOGUE_UNFUSED=1 forces the projection GEMM + pair_tables path at every N
 static inline bool prologue_unfused() {
