@@ -1983,9 +1983,11 @@ __global__ __launch_bounds__(256) void rollout_setup_kernel(
     return;
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < nflags) notdone[threadIdx.x] = 0;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= e.B) return;
-  setup_graph_wave(e, w, b, lane, out + (size_t)b * e.N * VRP_EMB, VRP_EMB, acc_loss, acc_logp);
+  // one workgroup per graph, its four waves share the embedding rows (a wave per graph left two
+  // waves per SIMD to write 512 N bytes each: 67 us at 2048 x 100, 75 us at 8192 x 40)
+  const int b = blockIdx.x;
+  setup_graph_wave(e, w, b, lane, out + (size_t)b * e.N * VRP_EMB, VRP_EMB, acc_loss, acc_logp,
+                   threadIdx.x >> 6, 4);
 }
 
 static int encoder_check(const vrp_encoder_weights *w, int B, int N) {
@@ -2048,7 +2050,7 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
     return launch_encoder_stack<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
   }
   float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;
-  const int env_blocks = (B + 3) / 4;
+  const int env_blocks = B;
   hipLaunchKernelGGL(rollout_setup_kernel, dim3(env_blocks + 2 * w->num_layers), dim3(256), 0, st,
                      *env, *w, train ? 0 : 1, cur, ws.norm, acc_loss, acc_logp, notdone, nflags,
                      env_blocks);
