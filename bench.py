@@ -580,8 +580,8 @@ def main():
     # ---- short runs of the other BASELINE configs (bounded; failures are reported, not fatal)
     if not a.no_extras and a.workload == "tsp20_b512":
         extras = {}
-        todo = [("irp40_b1024_train", 3, 1)] if world > 1 else \
-               [("vrp40_b2048_train", 3, 1), ("irp40_b1024_train", 3, 1), ("vrp100_b2048", 3, 1)]
+        todo = [("irp40_b1024_train", 6, 2)] if world > 1 else \
+               [("vrp40_b2048_train", 6, 2), ("irp40_b1024_train", 6, 2), ("vrp100_b2048", 4, 1)]
         for name, k, w in todo:
             try:
                 e, _, _ = run_workload(name, k, w, device, dist, rank, world)

@@ -172,15 +172,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
         sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(64) void colsum_final_kernel(const double *__restrict__ partial,
-                                                          int chunks, int N,
-                                                          float *__restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= N) return;
+// 16 threads per column (a chain of `chunks` dependent fp64 adds per thread took 21 us)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double *__restrict__ partial,
+                                                           int chunks, int N,
+                                                           float *__restrict__ out, int accumulate) {
+  __shared__ double sh[16][16];
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * N + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  if (c < N) {
+#pragma unroll 4
+    for (int k = part; k < chunks; k += 16) s += partial[(size_t)k * N + c];
+  }
+  sh[part][cl] = s;
+  __syncthreads();
+  if (part == 0 && c < N) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += sh[j][cl];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)t;
+  }
 }
 
 extern "C" int64_t vrp_colsum_workspace_bytes(int R, int N) {
@@ -194,7 +205,7 @@ int vrp_launch_colsum(const float *Y, int ldy, int R, int N, float *out, int acc
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, st, Y, ldy, R,
                      N, rpc, (double *)ws);
   VRP_CHECK_LAUNCH("colsum_partial");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, st,
                      (const double *)ws, chunks, N, out, accumulate);
   VRP_CHECK_LAUNCH("colsum_final");
   return 0;

@@ -307,22 +307,28 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float *__restrict__
     partial[(size_t)blockIdx.x * 256 + 128 + c] = sh[1][c] + sh[1][c + 128];
   }
 }
-// stats[j] = sum_k partial[k][j], k ascending; four independent chains per thread keep the
-// loads in flight, combined in a fixed order
-__global__ __launch_bounds__(256) void bn_stats_reduce_kernel(const double *__restrict__ partial,
-                                                              int blocks,
-                                                              double *__restrict__ stats) {
-  const int j = threadIdx.x;
+// stats[j] = sum_k partial[k][j]: 1024 threads, quarter q = tid >> 8 of the block partials with
+// four independent chains per thread (the loads stay in flight), chains and quarters combined in
+// a fixed order -- the result does not depend on scheduling (one thread per column: 34 us)
+__global__ __launch_bounds__(1024) void bn_stats_reduce_kernel(const double *__restrict__ partial,
+                                                               int blocks,
+                                                               double *__restrict__ stats) {
+  __shared__ double sh[4][256];
+  const int j = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int per = (blocks + 3) / 4;
+  const int k1 = min(blocks, (q + 1) * per);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int k = 0;
-  for (; k + 3 < blocks; k += 4) {
+  int k = q * per;
+  for (; k + 3 < k1; k += 4) {
     a0 += partial[(size_t)(k + 0) * 256 + j];
     a1 += partial[(size_t)(k + 1) * 256 + j];
     a2 += partial[(size_t)(k + 2) * 256 + j];
     a3 += partial[(size_t)(k + 3) * 256 + j];
   }
-  for (; k < blocks; ++k) a0 += partial[(size_t)k * 256 + j];
-  stats[j] = (a0 + a1) + (a2 + a3);
+  for (; k < k1; ++k) a0 += partial[(size_t)k * 256 + j];
+  sh[q][j] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (q == 0) stats[j] = ((sh[0][j] + sh[1][j]) + sh[2][j]) + sh[3][j];
 }
 
 // sums: [256 final | BN_MAX_BLOCKS x 256 partials] doubles
@@ -332,7 +338,7 @@ static int launch_bn_stats(const float *x, int rows, double *sums, hipStream_t s
   if (blocks > BN_MAX_BLOCKS) blocks = BN_MAX_BLOCKS;
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, st, x, rows, sums + 256);
   VRP_CHECK_LAUNCH("bn_stats");
-  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(1), dim3(256), 0, st, sums + 256, blocks, sums);
+  hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3(1), dim3(1024), 0, st, sums + 256, blocks, sums);
   VRP_CHECK_LAUNCH("bn_stats_reduce");
   return 0;
 }
@@ -768,6 +774,31 @@ __device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_enc
                                                  float *__restrict__ acc_logp, int part = 0,
                                                  int parts = 1) {
   const int N = e.N;
+  // every global load of the graph first, ahead of the stores below (the compiler keeps loads
+  // behind stores that may alias them, and a cold round trip is ~2 us)
+  // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
+  float fx[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int n = lane + 64 * i;
+    const size_t r = (size_t)b * N + (n < N ? n : 0);
+    fx[i][0] = (float)e.pos[2 * r];
+    fx[i][1] = (float)e.pos[2 * r + 1];
+    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
+  }
+  // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
+  float wn[2][3], bnv[2], wd[2][2], bdv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
+    bnv[j] = w.node_embed_bias[c];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
+    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
+  }
   if (lane == 0 && part == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
   // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
   // VRP_ENV_RESET_ON_ROLLOUT: the episode starts here (tsp.py:150-160,172-174; irp.py:47,184):
@@ -797,29 +828,6 @@ __device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_enc
   const unsigned long long d0 = __ballot(e.kind == VRP_KIND_VRP ? (lane < N && v0) : lane == dep);
   const unsigned long long d1 =
       __ballot(e.kind == VRP_KIND_VRP ? (lane + 64 < N && v1) : lane + 64 == dep);
-  // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
-  float fx[2][3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int n = lane + 64 * i;
-    const size_t r = (size_t)b * N + (n < N ? n : 0);
-    fx[i][0] = (float)e.pos[2 * r];
-    fx[i][1] = (float)e.pos[2 * r + 1];
-    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
-  }
-  // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
-  float wn[2][3], bnv[2], wd[2][2], bdv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = lane + 64 * j;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
-    bnv[j] = w.node_embed_bias[c];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
-    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
-  }
   const bool has_depot = w.depot_embed_weight != nullptr && e.kind != VRP_KIND_TSP;
   for (int n = part; n < N; n += parts) {
     const int src = n & 63;
