@@ -17,8 +17,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // tile of X[r0:r1]^T Y[r0:r1] with v_mfma_f32_32x32x2_f32 (A[i][k=r] = X[r][i]: lanes run
 // along i, so the LDS reads of a row-major (r, col) tile are conflict-free) and writes it to
 // slab s; a second kernel sums the slabs in order.
+#ifndef TN_BR
 #define TN_BR 32
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const float *__restrict__ X, int ldx,
+#endif
+// measured (tools/train_probe.py, VRP-40 x 2048 epoch, 18 products of 81920 rows): two workgroups
+// per CU and 512 of them 124 us per product, three and 768: 117, four and 1024: 116; 64-row slabs
+// (half the barriers) 127
+#ifndef TN_MINWG
+#define TN_MINWG 4
+#endif
+#ifndef TN_TARGET
+#define TN_TARGET 1024   // workgroups per launch (tiles x row splits): four per CU
+#endif
+__global__ __launch_bounds__(256, TN_MINWG) void gemm_tn_kernel(const float *__restrict__ X, int ldx,
                                                          const float *__restrict__ Y, int ldy,
                                                          float *__restrict__ slabs, int R, int N1,
                                                          int N2, int rows_per_split) {
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 // least 64 rows; the partial tiles (slabs) are summed in split order.
 static int tn_splits(int R, int N1, int N2) {
   const int tiles = (N1 / 128) * (N2 / 128);
-  int nsplit = (512 + tiles - 1) / tiles;
+  int nsplit = (TN_TARGET + tiles - 1) / tiles;
   const int max_by_rows = (R + 63) / 64;
   if (nsplit > max_by_rows) nsplit = max_by_rows;
   if (nsplit > 128) nsplit = 128;
