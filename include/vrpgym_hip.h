@@ -162,7 +162,11 @@ int vrp_decode_prologue(int kind, const void *derived, int B, int N, const float
  *        VRP_STEP_TILE_KERNEL = use the raw-embedding-tile kernel instead of the
  *        table-driven one;
  *        VRP_STEP_NO_FIRST_ROW = do not append vrp_decode_first_row to step 0;
- *        VRP_STEP_THROUGHPUT_KERNEL = large-batch variant of the table kernel at any B. */
+ *        VRP_STEP_THROUGHPUT_KERNEL = large-batch variant of the table kernel at any B.
+ * The kernel-selection flags (TILE / TABLE / THROUGHPUT) must be the same for every step of an
+ * episode: which kernel takes step t is a schedule fixed by (kind, B, N, t, flags), and a step
+ * kernel leaves behind what the NEXT step's kernel of that schedule reads (the latency-mode
+ * score row). */
 #define VRP_STEP_SAMPLE 1
 #define VRP_STEP_DECODE_ONLY 2
 #define VRP_STEP_TILE_KERNEL 4 /* use the raw-embedding-tile kernel (N <= 104) */
