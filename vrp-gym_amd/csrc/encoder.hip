@@ -1549,6 +1549,16 @@ int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const
 // query tiles outermost so that only one row of score tiles is live (N <= 128: eight tiles).
 // K and V fragments of the head are loaded once per graph (16-byte / 4-byte pieces of the
 // 1536-byte q|k|v rows), Q per query tile.
+// exp_nonpos (common.h) without the clamp: the arguments here are differences of finite scores
+// (this kernel is VALU-bound on its softmax: 28 exponentials per lane and query tile at N = 100)
+__device__ __forceinline__ float att_exp(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.9259629911e-8f;
+  const float t = x * l2e_hi;
+  float r = fmaf(x, l2e_hi, -t);
+  r = fmaf(x, l2e_lo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147180559945f, e);
+}
 template <int NT>
 __global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float *__restrict__ qkv,
                                                                       float *__restrict__ att, int N) {
@@ -1566,10 +1576,15 @@ __global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float
     for (int r4 = 0; r4 < 4; ++r4)
       vv[t][r4] = base[(size_t)min(16 * t + 4 * q + r4, N - 1) * 384 + 256 + h * 16 + i16];
   }
+  // the query rows of tile tm + 1 are requested before tile tm is worked on (a round trip per
+  // tile in front of its first MFMA otherwise)
+  float4 a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(i16, N - 1) * 384 + h * 16 + 4 * q);
 #pragma unroll
   for (int tm = 0; tm < NT; ++tm) {
     if (16 * tm >= N) break;
-    const float4 a = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * tm + i16, N - 1) * 384 + h * 16 + 4 * q);
+    const float4 a = a_next;
+    if (tm + 1 < NT)
+      a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * (tm + 1) + i16, N - 1) * 384 + h * 16 + 4 * q);
     const float4 qf = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
     f32x4v st[NT];  // st[tn][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
 #pragma unroll
@@ -1581,12 +1596,13 @@ __global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float
       d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].w, qf.w, d, 0, 0, 0);
       st[tn] = d;
     }
+    // (only the last key tile can reach beyond N: 16 (NT - 1) < N by the choice of NT)
     float mx = -INFINITY;
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)
-        if (16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[tn][r4]);
+        if (tn + 1 < NT || 16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[tn][r4]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -1594,7 +1610,7 @@ __global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float pw = (16 * tn + 4 * q + r4 < N) ? exp_nonpos(st[tn][r4] - mx) : 0.f;
+        const float pw = (tn + 1 < NT || 16 * tn + 4 * q + r4 < N) ? att_exp(st[tn][r4] - mx) : 0.f;
         st[tn][r4] = pw;
         sum += pw;
       }
