@@ -67,10 +67,38 @@ KIND_NAMES = "TSP VRP IRP".split()
 
 
 # ---------------------------------------------------------------------- multi-rank launch
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT calling into HIP: the KFD topology in sysfs
+    lists every agent (GPU nodes have simd_count > 0, CPU nodes 0); *_VISIBLE_DEVICES narrows it.
+    Only where sysfs has no KFD topology (not an amdgpu host) does torch get asked."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    n = None
+    if nodes:
+        n = 0
+        for path in nodes:
+            try:
+                with open(path) as fh:
+                    props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                continue
+    if n is None:
+        return torch.cuda.device_count()
+    render = glob.glob("/dev/dri/renderD*")  # a container is handed only its GPUs' render nodes
+    if render:
+        n = min(n, len(render))
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(a, argv):
     """--gpus N outside torchrun: start the N ranks as a CHILD process group and relay its
-    exit code.  Nothing in this process has initialised the GPU (device_count() does not)."""
-    ndev = torch.cuda.device_count()
+    exit code.  Nothing in this process touches the GPU runtime: the GPUs are counted in sysfs."""
+    ndev = visible_gpu_count()
     env = dict(os.environ)
     if ndev < a.gpus and env.get("VRPGYM_BENCH_ONE_GPU") != "1":
         sys.exit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible "
@@ -519,6 +547,14 @@ def main():
     one_gpu = os.environ.get("VRPGYM_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
+        if world > 2:
+            # more than two processes on ONE GPU: their persistent step grids (each sized against
+            # the whole device, serialised only within a process) would not all be resident --
+            # one launch per step instead.  Never the case with one process per GPU.
+            os.environ["VRP_NO_PERSISTENT"] = "1"
+    if world > 1 and not one_gpu and torch.cuda.device_count() < world:
+        # (the parent counted in sysfs; a rank sees what the runtime really offers)
+        sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None

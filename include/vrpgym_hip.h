@@ -188,9 +188,12 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
  * at once, MEASURED: the compute units a census kernel finds usable (a CU mask or a partition
  * mode shrinks them) x the largest per-CU count for which a census launch of the kernel itself
  * had every workgroup see all the others (starting from the occupancy query's answer).  vrp_rollout* use the
- * persistent kernel only for B <= this, decided before the episode starts (otherwise one launch
- * per step).  The first call on a device synchronises a private stream (call it once outside
- * any stream capture; vrp-gym_amd does when it loads the library). */
+ * persistent kernel only for B <= this AND max_steps + 1 <= 2N (the hand-off words hold 2N step
+ * rows), decided before the episode starts (otherwise one launch per step).  The first call on a
+ * device synchronises the device and a private stream (call it once outside any stream capture,
+ * with nothing in flight; vrpgym_hip.require_gpu does when it first sees the GPU).  A census that
+ * comes out more than one workgroup per CU under the occupancy query was disturbed by other work
+ * and is not cached: the next call measures again. */
 int vrp_persistent_capacity(void);
 
 /* Name of the kernel vrp_decode_step launches for this shape and these flags (what a
@@ -247,6 +250,13 @@ int vrp_rollout_steps_range(int kind, const void *derived, const vrp_decoder_wei
  * np.random.get_state(), advanced in place; all pointers are HOST pointers. */
 int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
                             double *pos_out_host, int64_t *depots_host, double *demands_host);
+
+/* The same stream advanced over all B graphs, storing only graphs [first, first+count) (outputs
+ * sized for `count` graphs): what a rank of a sharded env (rank r owns rows
+ * [rB/R, (r+1)B/R) of the seed-ordered stream) needs -- the rest is drawn and discarded natively. */
+int vrp_draw_instances_host_range(uint32_t *key_host, int32_t *pos_host, int B, int N, int first,
+                                  int count, double *pos_out_host, int64_t *depots_host,
+                                  double *demands_host);
 
 /* E1' Device-side instance sampler for throughput runs: the
  * reference's distributions (vrp_graph.py:28-43) from a counter-based Philox4x32-10
@@ -336,6 +346,11 @@ int vrp_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *b
 int vrp_gemm_nt_gated(const float *A, int lda, const float *W, int ldw, const float *residual,
                       int ldr, const float *gate, float *C, int ldc, int M, int N, int K,
                       void *stream);
+
+/* Test hook: the map from 32 random bits to the Exp(1) noise of the in-kernel sampler
+ * (Categorical.sample's q, agents/graph_decoder.py:104-107, throughput mode): out[i] in (0, inf)
+ * for every input word. */
+int vrp_debug_exp1_from_bits(const uint32_t *bits, float *out, int n, void *stream);
 
 const char *vrp_last_error(void);
 int vrp_abi_version(void);

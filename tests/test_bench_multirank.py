@@ -75,6 +75,54 @@ def test_bench_sharded_training_two_ranks():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload", ["tsp20_b512", "irp40_b1024_train"])
+def test_bench_eight_ranks_one_gpu(workload):
+    """The world size the driver's scaling run uses: port selection, eight shards of one
+    seed-ordered stream, and for the training workload the 8-way gradient all-reduce, the 8-way
+    gather_costs behind the paired t-test and average_buffers -- all ranks on cuda:0 over gloo
+    (the rendezvous, sharding and collective CALL pattern are the real ones; RCCL is not)."""
+    args = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--no-north-star", "--no-extras", "--workload", workload]
+    p = _bench(args, {"VRPGYM_BENCH_ONE_GPU": "1"}, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    assert out["n_gpus"] == 8 and out["one_gpu_test_mode"] is True
+    assert out["backend"] == "gloo" and len(out["devices"]) == 8
+    B = 512 if workload == "tsp20_b512" else 1024
+    assert out["config"]["global_batch"] == 8 * B
+    assert out["value"] > 0 and out["mean_tour_cost"] == out["mean_tour_cost"]  # not NaN
+    if workload.endswith("_train"):
+        tr = out["training"]
+        assert tr["rollouts_per_step"] == 4 and tr["allreduce_ms_per_step"] > 0
+        assert tr["grad_bucket_bytes"] == 4 * (1154944 - 128)
+    else:
+        assert out["config"]["steps_per_rollout"] == 19
+        assert 6.0 < out["mean_tour_cost"] < 7.6
+
+
+def test_gpu_count_without_the_hip_runtime():
+    """spawn_ranks counts GPUs in sysfs (KFD topology), never through HIP in the parent."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n = mod.visible_gpu_count()
+    assert isinstance(n, int) and n >= 0
+    print("GPUs counted without HIP:", n, "torch:", torch.cuda.device_count())
+    if torch.cuda.is_available():
+        assert n >= 1
+    old = os.environ.get("HIP_VISIBLE_DEVICES")
+    os.environ["HIP_VISIBLE_DEVICES"] = "0"
+    try:
+        assert mod.visible_gpu_count() <= 1
+    finally:
+        if old is None:
+            del os.environ["HIP_VISIBLE_DEVICES"]
+        else:
+            os.environ["HIP_VISIBLE_DEVICES"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["tsp20_b512", "irp40_b1024_train"])
 def test_bench_two_ranks_over_rccl(workload):
     """The real backend path, whenever the box has two GPUs: one process per GPU,
     dist.init_process_group("nccl") (= RCCL), distinct devices asserted inside bench.py, the

@@ -29,7 +29,8 @@ class _TourLogProb(torch.autograd.Function):
         # (somebody accumulates over several backward calls) autograd gets ordinary tensors.
         flat, views, _ = runtime.grad_bucket(model, kind)
         by_param = {id(p): p for p in model.parameters()}
-        direct = all(by_param[i].grad is None for i in views)
+        direct = (getattr(model, "grad_bucket_enabled", True)
+                  and all(by_param[i].grad is None for i in views))
         out = views if direct else None
         dparams, dgrads, d_emb = runtime.decoder_backward(
             model.decoder, kind, res.emb, res.actions[:T], res.mask_trace[:T], loads,

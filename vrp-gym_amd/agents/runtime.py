@@ -471,7 +471,13 @@ def rollout(model, env, greedy, train=False, forced=None, noise=None, trace=Fals
             # throughput mode: the step kernels draw their Exp(1) noise themselves (Philox,
             # counter = graph / node / step); one seed per rollout from the CPU generator, so
             # torch.manual_seed still makes a run reproducible.  No (max_steps, B, N) tensor.
-            io.noise_seed = int(torch.empty((), dtype=torch.int64).random_().item()) | 1
+            # Data-parallel ranks seed torch identically and index their graphs locally: mix
+            # the shard's first global graph index into the key, or every rank would explore
+            # with the same noise.
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            first = int(getattr(env, "_slice", slice(0, 0)).start or 0)
+            seed ^= (first * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+            io.noise_seed = seed | 1
         else:
             if noise is None:
                 gen_state = torch.get_rng_state()
@@ -580,14 +586,22 @@ def grad_bucket(model, kind):
     decoder._first_node for IRP never get one and are left out), plus the per-parameter views
     into it.  The backward kernels write straight into the views, `.grad` IS the view, and the
     data-parallel all-reduce runs on the flat buffer in place: no cat, no copy-back
-    (one collective on one bucket)."""
+    (one collective on one bucket).
+
+    ALIASING CONTRACT (differs from torch autograd, which allocates fresh gradient tensors):
+    the next backward overwrites the bucket in place, so a gradient tensor kept across
+    `zero_grad()` (`old = [p.grad for p in ...]`, gradient-surgery helpers) changes with it --
+    clone what must survive a step, or set `model.grad_bucket_enabled = False` to get ordinary
+    freshly allocated gradients (the all-reduce then packs and unpacks like any DDP bucket)."""
     hit = getattr(model, "_grad_bucket", None)
     dev = _dev(model)
     if hit is not None and hit[0].device == dev and hit[2] == kind:
         return hit
-    irp = kind == hip.KIND_IRP
-    skip = {id(model.decoder._first_node)} if irp else {id(model.decoder._context_proj.weight)}
-    params = [p for p in model.parameters() if p.requires_grad and id(p) not in skip]
+    # exactly the parameters the backward kernels write (the two *_param_list orders are the
+    # grads structs'); anything else keeps .grad = None, like torch autograd
+    written = {id(p) for p in decoder_param_list(model.decoder, kind) + encoder_param_list(model.encoder)
+               if p is not None}
+    params = [p for p in model.parameters() if p.requires_grad and id(p) in written]
     flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
     views, off = {}, 0
     for p in params:

@@ -78,11 +78,19 @@ __device__ __forceinline__ void vrp_philox4x32_10(uint32_t (&c)[4], uint32_t k0,
 // Exp(1) noise q of Categorical.sample's argmax(p / q) (agents/graph_decoder.py:104-107) for
 // step t, graph b, node n, drawn in the kernel: counter = (b, n, t, tag), key = seed.  NOT the
 // reference's CPU generator stream (parity runs ship host-drawn noise through io.noise).
+// 32 random bits -> q in (0, inf): u = (23 bits + 1/2) * 2^-23 lies in [2^-24, 1 - 2^-24] and
+// every such value is exact in fp32 (a 24-bit significand), so u never rounds to 1 and -log(u)
+// never to -0 (with 24 bits + 1/2 the largest draw rounded to 1.0: q = -0, ratio p/q = -inf on
+// the ONE selectable node of a forced move, and a masked node won the argmax); the clamp keeps q
+// positive whatever the fast logarithm returns next to 1.
+__device__ __forceinline__ float vrp_exp1_from_bits(uint32_t bits) {
+  const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
+  return fmaxf(-__logf(u), 1e-30f);
+}
 __device__ __forceinline__ float vrp_exp1_noise(uint64_t seed, int t, int b, int n) {
   uint32_t c[4] = {(uint32_t)b, (uint32_t)n, (uint32_t)t, 0x45585031u};
   vrp_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-  const float u = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1)
-  return -__logf(u);
+  return vrp_exp1_from_bits(c[0]);
 }
 
 // ---- wave-level reductions (all 64 lanes participate) -----------------------

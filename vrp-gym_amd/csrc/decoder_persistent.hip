@@ -397,9 +397,9 @@ __global__ __launch_bounds__(64) void cu_census_kernel() {
 struct PersistDevice {
   int capacity = -1;             // resident single-wave workgroups, -1 = not measured yet
   int cus = 0;
+  int retries = 0;               // censuses thrown away because they looked disturbed
   hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
-  hipStream_t last_stream = nullptr;
-  bool multi_stream = false;     // persistent launches have come from more than one stream
+  hipStream_t last_stream = nullptr;  // identity of that launch's stream (compared, never used)
 };
 static PersistDevice g_pdev[VRP_MAX_DEVICES];
 // (process-wide state besides the thread-local error string: the measured capacity per device and
@@ -422,7 +422,12 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
   if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
   if (cs == hipStreamCaptureStatusNone) {
     // the census synchronises: never inside a stream capture (the figure of the device
-    // properties serves until an eager call gets here)
+    // properties serves until an eager call gets here).  It must not compete for CU slots with
+    // work this process has in flight (a rollout's encoder enqueued just before the first
+    // eligibility check): drain the device first.  vrp-gym_amd measures when it loads the library
+    // (vrpgym_hip.require_gpu), before anything is enqueued.
+    if (capturing_guard) (void)hipStreamSynchronize(capturing_guard);
+    else (void)hipDeviceSynchronize();
     unsigned zero[64] = {0}, bits[64];
     hipStream_t st = nullptr;
     bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
@@ -446,7 +451,6 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
     // workgroup per CU less, and so on.
     per_cu = per_cu > 32 ? 32 : per_cu;
     pd.cus = cus;
-    pd.capacity = 0;
     int32_t *res = nullptr;
     hipStream_t st2 = nullptr;
     if (hipGetSymbolAddress((void **)&res, HIP_SYMBOL(g_residency)) != hipSuccess ||
@@ -455,7 +459,9 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
       pd.capacity = cus * (per_cu > 1 ? per_cu - 1 : 0);
       return pd.capacity;
     }
-    for (int k = per_cu; k >= 1 && pd.capacity == 0; --k) {
+    const int query_per_cu = per_cu;
+    int measured = 0;
+    for (int k = per_cu; k >= 1 && measured == 0; --k) {
       int32_t zero2[2] = {0, 0}, got[2] = {0, 0};
       PersistParams cp = {};
       cp.census = res;
@@ -467,9 +473,18 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
       ok2 = ok2 && hipMemcpyAsync(got, res, sizeof(got), hipMemcpyDeviceToHost, st2) == hipSuccess;
       ok2 = ok2 && hipStreamSynchronize(st2) == hipSuccess;
       if (!ok2) { (void)hipGetLastError(); break; }
-      if (got[1] == cus * k) pd.capacity = cus * k;
+      if (got[1] == cus * k) measured = cus * k;
     }
     (void)hipStreamDestroy(st2);
+    // The query is at most one workgroup per CU high.  A census that lost more than that was
+    // disturbed (another process or stream held CU slots while it ran): use the figure for this
+    // call but do not keep it -- the next call measures again (at most a few times).
+    if (measured < cus * (query_per_cu - 1) && pd.retries < 4) {
+      ++pd.retries;
+      pd.capacity = -1;
+      return measured;
+    }
+    pd.capacity = measured;
     return pd.capacity;
   }
   per_cu = per_cu > 32 ? 32 : per_cu;
@@ -491,6 +506,7 @@ bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
                 VRP_STEP_TABLE_KERNEL | VRP_STEP_NO_PERSISTENT)))
     return false;
   if (B > 2048) return false;  // beyond this the one-launch-per-step kernel is the faster one
+  if (max_steps + 1 > 2 * N) return false;  // hist holds 2N rows (decoder_ws.h: hist_rows)
   static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;  // tests: skip the
   if (force) return true;                                               // residency check
   int dev = 0;
@@ -515,22 +531,17 @@ void vrp_persistent_serialize_begin(hipStream_t st, void **token) {
   PersistDevice *pd = (dev >= 0 && dev < VRP_MAX_DEVICES && cs == hipStreamCaptureStatusNone)
                           ? &g_pdev[dev] : nullptr;
   std::lock_guard<std::mutex> guard(g_pdev_lock);
-  if (pd && pd->last_stream && pd->last_stream != st) {
-    if (!pd->multi_stream) {
-      (void)hipStreamSynchronize(pd->last_stream);
-      pd->multi_stream = true;
-    } else if (pd->last) {
-      (void)hipStreamWaitEvent(st, pd->last, 0);
-    }
-  }
+  // the previous persistent launch of this device came from another stream: wait for the event
+  // recorded behind it (an event outlives its stream; no handle of a possibly destroyed stream
+  // is ever used)
+  if (pd && pd->last && pd->last_stream != st) (void)hipStreamWaitEvent(st, pd->last, 0);
   *token = pd;
 }
 void vrp_persistent_serialize_end(hipStream_t st, void *token) {
   PersistDevice *pd = (PersistDevice *)token;
   if (!pd) return;
   std::lock_guard<std::mutex> guard(g_pdev_lock);
-  pd->last_stream = st;
-  if (!pd->multi_stream) return;
+  pd->last_stream = st;  // compared only, never dereferenced
   if (!pd->last && hipEventCreateWithFlags(&pd->last, hipEventDisableTiming) != hipSuccess) {
     pd->last = nullptr;
     (void)hipGetLastError();

@@ -58,36 +58,55 @@ struct MT {
 
 // key: numpy's 624-word MT19937 state (in/out); *pos: its position (in/out).
 // pos_out (B,N,2) f64, depots (B) i64, demands (B,N) f64.  Host pointers.
-extern "C" int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
-                                       double *pos_out_host, int64_t *depots_host,
-                                       double *demands_host) {
+// Graphs [first, first + count) of the B the stream is advanced over are stored (outputs hold
+// `count` graphs); the others are drawn and discarded -- MT19937 has no cheap skip-ahead and the
+// permutation's rejection sampling makes the number of draws per graph data-dependent, so a rank
+// of a sharded env replays the whole stream natively (~1 us per graph) but keeps only its rows.
+extern "C" int vrp_draw_instances_host_range(uint32_t *key_host, int32_t *pos_host, int B, int N,
+                                             int first, int count, double *pos_out_host,
+                                             int64_t *depots_host, double *demands_host) {
   VRP_REQUIRE(key_host && pos_host && pos_out_host && depots_host && demands_host,
               "draw_instances: NULL argument");
   VRP_REQUIRE(B > 0 && N > 0 && N <= 65536, "draw_instances: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(first >= 0 && count >= 0 && first + count <= B,
+              "draw_instances: bad range first=%d count=%d of %d", first, count, B);
   VRP_REQUIRE(*pos_host >= 0 && *pos_host <= 624, "draw_instances: bad generator position");
   MT g{key_host, *pos_host};
   const double scale = 0.2449 * N + 26.12;  // vrp_graph.py:41
   uint32_t *perm = new uint32_t[N];
   for (int b = 0; b < B; ++b) {
-    double *p = pos_out_host + (size_t)b * N * 2;
-    for (int i = 0; i < 2 * N; ++i) p[i] = g.sample();          // rand(N,2)
-    for (int i = 0; i < N; ++i) perm[i] = (uint32_t)i;          // permutation(N)[:1]
+    const bool keep = b >= first && b < first + count;
+    double *p = pos_out_host + (size_t)(b - first) * N * 2;
+    if (keep) for (int i = 0; i < 2 * N; ++i) p[i] = g.sample();  // rand(N,2)
+    else for (int i = 0; i < 4 * N; ++i) (void)g.next();          //   (two words per sample)
+    for (int i = 0; i < N; ++i) perm[i] = (uint32_t)i;            // permutation(N)[:1]
     for (int i = N - 1; i > 0; --i) {
       const uint32_t j = g.interval((uint32_t)i);
       const uint32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
     }
-    depots_host[b] = perm[0];
-    double *d = demands_host + (size_t)b * N;
+    if (!keep) {
+      for (int i = 0; i < 2 * N; ++i) (void)g.next();             // uniform(1,10,(N,1))
+      continue;
+    }
+    depots_host[b - first] = perm[0];
+    double *d = demands_host + (size_t)(b - first) * N;
     for (int i = 0; i < N; ++i) {
       const double u = g.sample();
-      const double v = 1.0 + 9.0 * u;                           // uniform(1,10)
+      const double v = 1.0 + 9.0 * u;                             // uniform(1,10)
       d[i] = v / scale;
     }
-    d[perm[0]] = 0.0;                                           // vrp_graph.py:43
+    d[perm[0]] = 0.0;                                             // vrp_graph.py:43
   }
   delete[] perm;
   *pos_host = g.pos;
   return 0;
+}
+
+extern "C" int vrp_draw_instances_host(uint32_t *key_host, int32_t *pos_host, int B, int N,
+                                       double *pos_out_host, int64_t *depots_host,
+                                       double *demands_host) {
+  return vrp_draw_instances_host_range(key_host, pos_host, B, N, 0, B, pos_out_host, depots_host,
+                                       demands_host);
 }
 
 // ------------------------------------------------------------------ device-side sampler
@@ -202,5 +221,20 @@ extern "C" int vrp_random_rollout(const vrp_env *env, uint64_t seed, uint64_t ep
                        episode, first_graph, t, acc_loss, notdone, actions);
     VRP_CHECK_LAUNCH("random_step");
   }
+  return 0;
+}
+
+// ---- test hook: the bits -> Exp(1) map of the in-kernel sampler (common.h), so that a test can
+// feed it the extreme draws (0, 0xFFFFFFFF) and assert 0 < q < inf
+__global__ void exp1_from_bits_kernel(const uint32_t *__restrict__ bits, float *__restrict__ out,
+                                      int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = vrp_exp1_from_bits(bits[i]);
+}
+extern "C" int vrp_debug_exp1_from_bits(const uint32_t *bits, float *out, int n, void *stream) {
+  VRP_REQUIRE(bits && out && n > 0, "debug_exp1_from_bits: bad argument");
+  hipLaunchKernelGGL(exp1_from_bits_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, bits, out, n);
+  VRP_CHECK_LAUNCH("exp1_from_bits");
   return 0;
 }

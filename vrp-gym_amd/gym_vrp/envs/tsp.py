@@ -116,11 +116,14 @@ class TSPEnv(GymEnv):
         if self._generator == "device":
             self._draw_on_device()
         else:
-            pos, depots, demands = draw_instances(self._global_batch, self.num_nodes, 1)
+            # a shard keeps its own rows only; the rest of the global stream is drawn and
+            # discarded natively (no (B_global, N, 2) arrays per rank)
             s = self._slice
+            pos, depots, demands = draw_instances(self._global_batch, self.num_nodes, 1,
+                                                  keep=(s.start, s.stop - s.start))
             self.sampler = VRPNetwork(self.batch_size, self.num_nodes, 1,
                                       plot_demand=self._PLOT_DEMAND,
-                                      _arrays=(pos[s], depots[s], demands[s]))
+                                      _arrays=(pos, depots, demands))
             self._depots_host = self.sampler.get_depots()
             self._upload_instances()
         self._reset_state()

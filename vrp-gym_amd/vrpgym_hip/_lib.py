@@ -106,6 +106,8 @@ def _declare(lib):
         "vrp_rollout_steps_range": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp,
                                           P(RolloutIO), i32, i32, i32, i32, vp]),
         "vrp_draw_instances_host": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+        "vrp_draw_instances_host_range": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "vrp_debug_exp1_from_bits": (i32, [vp, vp, i32, vp]),
         "vrp_draw_instances_device": (i32, [C.c_uint64, C.c_uint64, i32, i32, i32, vp, vp, vp, vp]),
         "vrp_random_rollout": (i32, [P(Env), C.c_uint64, C.c_uint64, i32, i32, vp, vp, vp, vp]),
         "vrp_encoder_tape_bytes": (i64, [i32, i32, i32, i32]),
@@ -157,12 +159,24 @@ def lib():
     return _LIB
 
 
+_CENSUS_DONE = set()
+
+
 def require_gpu():
+    """The library, on a machine with a GPU.  The first call per device also takes the
+    persistent step kernel's residency census (vrp_persistent_capacity) while nothing of this
+    process is in flight, so the measurement is not disturbed by a rollout's own kernels."""
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("vrp-gym_amd needs an AMD GPU (MI355X/gfx950) visible to "
                            "PyTorch-ROCm; there is no CPU fallback")
-    return lib()
+    L = lib()
+    dev = torch.cuda.current_device()
+    if dev not in _CENSUS_DONE:
+        _CENSUS_DONE.add(dev)
+        if not torch.cuda.is_current_stream_capturing():
+            L.vrp_persistent_capacity()
+    return L
 
 
 def check(rc):
