@@ -117,11 +117,21 @@ def spawn_ranks(a, argv):
 # ---------------------------------------------------------------------- helpers
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N_traffic.json:
-    separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None if absent."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    separate FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied) -- but ONLY if they were
+    collected on the kernels this library was built from (the file carries vrp_source_hash() of
+    the build it measured; tools/collect_profiles.sh).  Counters cannot be read inside this
+    run (they need rocprofv3 around the process), so a stale or missing file gives None: the
+    line never carries bytes of other kernels."""
+    import glob
+    import vrpgym_hip as hip
+    mine = hip.lib().vrp_source_hash().decode()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                return json.load(fh)["workloads"][workload]["hbm_bytes_per_launch"]
+            with open(path) as fh:
+                doc = json.load(fh)
+            if doc.get("source_hash") != mine:
+                continue
+            return doc["workloads"][workload]["hbm_bytes_per_launch"]
         except Exception:
             continue
     return None

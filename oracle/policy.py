@@ -220,7 +220,7 @@ class DecoderEpisode:
         """graph_decoder.py:100-107.  Sampling = argmax(softmax(u)/q), q~Exp(1)
         (torch.multinomial's single-draw path); `noise` lets a test inject q."""
         if greedy:
-            return u.argmax(-1), torch.zeros(self.B)
+            return u.argmax(-1), torch.zeros(self.B, dtype=u.dtype)
         logits = u - u.logsumexp(-1, keepdim=True)
         probs = torch.softmax(logits, dim=-1)
         if noise is None:
@@ -239,18 +239,26 @@ class DecoderEpisode:
 # ---------------------------------------------------------------------------
 # R1-R3: rollouts
 # ---------------------------------------------------------------------------
-def split_state(kind, raw):
+def split_state(kind, raw, dtype=torch.float):
     """State columns the models read: TSP graph_tsp_agent.py:72-81, VRP
     graph_vrp_agent.py:63-70 (QUIRK: depot_mask := visited column 3),
-    IRP graph_irp_agent.py:68-91."""
+    IRP graph_irp_agent.py:68-91.  The reference casts the fp64 state to fp32; `dtype`
+    (fp64 evaluations of the same model) widens AFTER that rounding, so every precision
+    sees the same network inputs."""
     if kind == IRP:
-        st = torch.tensor(raw[0], dtype=torch.float)
-        load = torch.tensor(raw[1], dtype=torch.float)
+        st = torch.tensor(raw[0], dtype=torch.float).to(dtype)
+        load = torch.tensor(raw[1], dtype=torch.float).to(dtype)
         return st[:, :, :3], st[:, :, 3].bool(), st[:, :, -1], load
-    st = torch.tensor(raw, dtype=torch.float)
+    st = torch.tensor(raw, dtype=torch.float).to(dtype)
     if kind == VRP:
         return st[:, :, :2], st[:, :, 3].bool(), st[:, :, -1], None
     return st[:, :, :2], None, st[:, :, 3], None
+
+
+def as_double(sd):
+    """fp64 copy of a state dict (integer buffers unchanged)."""
+    return OrderedDict((k, v.double() if v.is_floating_point() else v.clone())
+                       for k, v in sd.items())
 
 
 def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
@@ -263,10 +271,14 @@ def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
     then that of the forced action) so that two implementations can be compared
     past a near-tie where their argmax legitimately differs."""
     kind = env.kind
-    x, depot_mask, mask, load = split_state(kind, env.get_state())
+    # the precision of the weights decides the precision of the evaluation (fp64 state dicts:
+    # the "exact" value of the same model on the same fp32 inputs, what fp32 results are
+    # measured against in tools/make_golden.py and the train-mode parity tests)
+    dtype = sd["decoder._kp.weight"].dtype
+    x, depot_mask, mask, load = split_state(kind, env.get_state(), dtype)
     B = x.shape[0]
     acc_loss = torch.zeros(B)
-    acc_logp = torch.zeros(B)
+    acc_logp = torch.zeros(B, dtype=dtype)
     emb = encoder_forward(sd, x, depot_mask, train=train, heads=heads)
     ep = DecoderEpisode(sd, emb)
     done, T = False, 0
@@ -292,7 +304,7 @@ def rollout(sd, env, greedy, train=False, heads=8, noise_fn=None, trace=None,
             trace[-1]["visited_after"] = np.array(env.visited, dtype=np.float64)
         acc_loss = acc_loss + torch.tensor(reward, dtype=torch.float)
         acc_logp = acc_logp + logp
-        _, _, mask, load = split_state(kind, env.get_state())
+        _, _, mask, load = split_state(kind, env.get_state(), dtype)
         T += 1
     return acc_loss, acc_logp, T
 

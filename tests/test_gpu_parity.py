@@ -268,6 +268,65 @@ def _log_roots(*row):
             f.write(",".join(str(v) for v in row) + "\n")
 
 
+def _log_train(*row):
+    """With VRPGYM_TRAIN_PARITY_LOG=<file> every train-mode comparison appends the HIP path's
+    error against the fp64 evaluation, its bound and the fp32 oracle's error on the same inputs
+    (profiles/r04_train_mode_parity.csv is such a log)."""
+    path = os.environ.get("VRPGYM_TRAIN_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(",".join(f"{v:.3e}" if isinstance(v, float) else str(v) for v in row) + "\n")
+
+
+def _train_mode_statistics():
+    """tests/golden/train_mode_error.json (tools/make_golden.py trainrollouts): how far the
+    REFERENCE's own fp32 train-mode rollouts sit from an fp64 evaluation of the same model on
+    the same action path, and the same figure for the fp32 oracle -- for the seven committed
+    trainrollout_* shapes ("cases") and over a random sweep of shapes / seeds ("sweep")."""
+    import json
+    with open(os.path.join(G, "train_mode_error.json")) as f:
+        return json.load(f)
+
+
+_TRAIN_KEYS = ("du_max", "dlogp_step_max", "dlogp_acc_max")
+_TRAIN_FLOORS = (1e-5, 5e-6, 5e-6)   # half the eval-mode tolerances (2e-5 logits, 1e-5 log-prob)
+
+
+def _reference_to_oracle_ratio():
+    """Largest ratio (reference fp32 error) / (oracle fp32 error), both against fp64, over every
+    measured case whose errors are above the floors (below them the ratio is rounding noise and
+    the floors decide)."""
+    st = _train_mode_statistics()
+    out = []
+    for k, fl in zip(_TRAIN_KEYS, _TRAIN_FLOORS):
+        rs = [c["reference_fp32_vs_fp64"][k] / c["oracle_fp32_vs_fp64"][k]
+              for c in st["cases"] + st["sweep"]
+              if c["oracle_fp32_vs_fp64"][k] > fl / 2 and c["reference_fp32_vs_fp64"][k] > fl / 2]
+        out.append(max(rs))
+    return out
+
+
+def _train_bounds(kind, B, N, o32):
+    """Bounds for the HIP path's train-mode error AGAINST THE FP64 EVALUATION (per-step logits,
+    per-step log-prob, accumulated log-prob) = 2 x the reference's own fp32 error.  Batch-
+    statistics BatchNorm amplifies fp32 re-association noise with the batch (B*N rows) and the
+    episode length, so north_star's flat 1e-5 is not what the reference itself achieves: at VRP
+    33 x 100 its logits sit 4.2e-5 and its per-step log-probs 2.2e-5 from the fp64 values, and
+    two legitimate fp32 evaluations (reference, oracle) 1.06e-4 from each other.
+
+    The reference's error on THIS test's inputs is estimated from the fp32 oracle's (`o32`,
+    measured by the caller against the same fp64 trace) times the largest reference/oracle ratio
+    the committed measurements show (the maximum of an error trace is heavy-tailed: over the
+    random sweep the reference's maximum is up to that many times the oracle's on the same
+    inputs); where the shape has a committed measurement of its own, at least that."""
+    ratio = _reference_to_oracle_ratio()
+    ref = [r * o for r, o in zip(ratio, o32)]
+    for c in _train_mode_statistics()["cases"]:
+        if (c["kind"], c["B"], c["N"]) == (kind, B, N):
+            ref = [max(a, c["reference_fp32_vs_fp64"][k]) for a, k in zip(ref, _TRAIN_KEYS)]
+    return tuple(2.0 * max(r, f) for r, f in zip(ref, _TRAIN_FLOORS))
+
+
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
                      ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
                      throughput_kernel=False, table_kernel=False, agent=None, fused=False):
@@ -337,6 +396,26 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     # the scrambled glimpse mask couples it to graphs that flipped earlier.)
     U = torch.stack([st["u"] for st in forced_trace])                   # (T,B,N)
     A = torch.as_tensor(acts)[:, :, None]
+    du_bound = dl_bound = acc_bound = None
+    if train:
+        # Train mode is judged against the fp64 evaluation of the same model on the same
+        # action path, with bounds tied to the reference's own measured fp32 error
+        # (_train_bounds).  The fp32 oracle's error on these very inputs is measured here too.
+        trace64 = []
+        torch.manual_seed(torch_seed)
+        with torch.no_grad():
+            _, olp64, oT64 = opol.rollout(opol.as_double(sd), deepcopy(oe), greedy, train=True,
+                                          trace=trace64, forced=acts)
+        assert oT64 == T
+        U64 = torch.stack([st["u"] for st in trace64])
+        LP64 = torch.stack([st["logp"] for st in trace64])
+        fin64 = torch.isfinite(U64)
+        assert torch.equal(fin64, torch.isfinite(U))
+        o32 = ((U.double()[fin64] - U64[fin64]).abs().max().item(),
+               (torch.stack([st["logp"] for st in forced_trace]).double() - LP64).abs().max().item(),
+               (olp.double() - olp64).abs().max().item())
+        du_bound, dl_bound, acc_bound = _train_bounds(kind, B, N, o32)
+        U = U64   # ties are judged on the exact logits
     if greedy:
         slack = U.max(dim=2).values - U.gather(2, A)[..., 0]
     else:
@@ -344,9 +423,11 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         ratio = torch.softmax(U - U.logsumexp(-1, keepdim=True), dim=-1) / Q
         best = ratio.max(dim=2).values
         slack = (best - ratio.gather(2, A)[..., 0]) / best              # relative
-    # train-mode BatchNorm noise on the logits reaches 7.4e-5 (see below): 2 x 1e-4
-    gap = 2e-4 if train else TIE_GAP
-    assert slack.max().item() < gap, slack.max().item()
+    # eval mode: TIE_GAP on the fp32 oracle's logits.  Train mode: the slack is measured on the
+    # fp64 logits and every HIP logit may sit du_bound away from them, so a choice can trail the
+    # exact maximum by twice that.
+    gap = 2 * du_bound if train else TIE_GAP
+    assert slack.max().item() < gap, (slack.max().item(), gap)
     # graphs with a tie flip: the HIP choice is not the oracle's own pick on the same state (an
     # EXACT tie of the oracle's logits counts -- slack 0, the oracle takes the lowest index, our
     # logits differ in the last bits: seen once in 640 sweep cases, VRP 100 x 63 step 112)
@@ -362,8 +443,19 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
             top = torch.topk(forced_trace[t]["u"][b], 2)
             return (f"graph {b} step {t}: HIP chose {int(acts[t, b])}, oracle {int(oacts[t, b])}, "
                     f"slack {slack[t, b].item():.3e}, oracle top-2 logits {top.values.tolist()} at {top.indices.tolist()}")
-        assert not div_oracle, "diverged from the oracle without any near tie: " + _where()
-        assert T == oT
+        if not train:
+            assert not div_oracle, "diverged from the oracle without any near tie: " + _where()
+            assert T == oT
+        elif div_oracle:
+            # HIP followed the fp64 pick at every step, so it is the free-running fp32 ORACLE
+            # that left the exact path: its choice at the earliest divergence must be a near tie
+            # of the exact logits / ratios
+            t0 = min(div_oracle.values())
+            score = U[t0] if greedy else ratio[t0]
+            for b in [b for b, t in div_oracle.items() if t == t0]:
+                top, theirs = score[b].max().item(), score[b, int(oacts[t0, b])].item()
+                miss = top - theirs if greedy else (top - theirs) / top
+                assert miss < gap, (b, t0, miss, _where())
     if ref_T is not None and not div_ref:
         assert T == ref_T
     if div_ref:
@@ -383,33 +475,48 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     exempt[list(div_ref)] = True
     loss, logp = res.acc_loss.cpu(), res.acc_logp.cpu()
     assert (loss - ol).abs().max().item() < TOL, (loss - ol).abs().max().item()
-    assert (logp - olp).abs().max().item() < TOL * (1 if greedy else max(1, T / 4)), \
-        (logp - olp).abs().max().item()
+    acc_tol = TOL * (1 if greedy else max(1, T / 4))
+    if train:
+        # against the fp64 sum, within twice the reference's own accumulated error
+        acc_err = (logp.double() - olp64).abs().max().item()
+        assert acc_err < (TOL if greedy else acc_bound), (acc_err, acc_bound)
+        # two fp32 evaluations may sit on opposite sides of the exact value
+        acc_tol = max(acc_tol, 0.0 if greedy else acc_bound + o32[2])
+    assert (logp - olp).abs().max().item() < acc_tol, (logp - olp).abs().max().item()
     if ref_loss is not None:
         ok = ~exempt
         assert np.max(np.abs(loss.numpy() - ref_loss)[ok]) < TOL
-        assert np.max(np.abs(logp.numpy() - ref_logp)[ok]) < TOL * (1 if greedy else max(1, T / 4))
-    # per-step logits along the same action path
+        assert np.max(np.abs(logp.numpy() - ref_logp)[ok]) < acc_tol
+    # per-step logits along the same action path.  Logits live in [-10, 10].  Eval mode:
+    # within 2e-5 of the fp32 oracle.  Train mode: within du_bound of the FP64 logits (twice
+    # what the reference's own fp32 logits are off by, _train_bounds).
+    worst_du = 0.0
     for t in range(0 if fused else T):
         u = res.logits[t].cpu()
-        ou = forced_trace[t]["u"]
+        ou = trace64[t]["u"] if train else forced_trace[t]["u"]
         fin = torch.isfinite(ou)
         assert torch.equal(fin, torch.isfinite(u)), t
-        # logits live in [-10, 10]; train-mode BatchNorm (batch statistics of rounded
-        # activations) amplifies fp32 re-association noise: up to 7.4e-5 seen in a 480-case sweep
-        # (tools/parity_sweep.py), 1.0e-4 once in 1050 cases (VRP 33 x 100, step 107 of 198, with
-        # either prologue); 2e-5 in eval mode
-        assert (u[fin] - ou[fin]).abs().max().item() < (2e-4 if train else 2e-5), \
-            (t, (u[fin] - ou[fin]).abs().max())
+        err = (u.to(ou.dtype)[fin] - ou[fin]).abs().max().item()
+        worst_du = max(worst_du, err)
+        assert err < (du_bound if train else 2e-5), (t, err, du_bound)
+    worst_dl = 0.0
     if not greedy:
         # north_star: log-prob within 1e-5 -- held PER STEP (log p(a_t) of every sampled
-        # action, eval mode); the accumulated sum of T such terms is therefore bounded by
-        # T x 1e-5 and checked above at the tighter 1e-5 x max(1, T/4).  Train mode: the
-        # batch-statistics BatchNorm noise on the logits (see above) carries over.
+        # action) against the fp32 oracle in eval mode; the accumulated sum of T such terms is
+        # checked above at 1e-5 x max(1, T/4).  Train mode: per step within dl_bound of the fp64
+        # log-prob.
         slp = res.step_logp[:T].cpu()
-        olp_t = torch.stack([st["logp"] for st in forced_trace])
-        worst = (slp - olp_t).abs().max().item()
-        assert worst < (5e-5 if train else TOL), worst
+        if train:
+            worst_dl = (slp.double() - LP64).abs().max().item()
+            assert worst_dl < dl_bound, (worst_dl, dl_bound)
+        else:
+            olp_t = torch.stack([st["logp"] for st in forced_trace])
+            worst_dl = (slp - olp_t).abs().max().item()
+            assert worst_dl < TOL, worst_dl
+    if train:
+        _log_train(kind, B, N, greedy, T, tile_kernel, throughput_kernel, table_kernel, fused,
+                   worst_du, du_bound, o32[0], worst_dl, dl_bound, o32[1],
+                   (logp.double() - olp64).abs().max().item(), acc_bound, o32[2])
     return res, exempt
 
 
@@ -427,6 +534,23 @@ def test_rollout_against_reference(name, path, mode):
                      ref_logp=z["acc_logp"], ref_T=int(z["T"]), tile_kernel=mode == "tile",
                      throughput_kernel=mode == "table_wide",
                      table_kernel=mode in ("table", "table_wide"))
+
+
+@pytest.mark.parametrize("mode", ["default", "table", "tile"])
+@pytest.mark.parametrize("name,path", _load("trainrollout_*.npz"))
+def test_train_mode_rollout_against_reference(name, path, mode):
+    """The reference's own train-mode (batch-statistics BatchNorm) sampled rollouts: same
+    actions (near-tie rule on the fp64 logits), cost within 1e-5, per-step logits / log-probs
+    within twice the reference's measured distance from the fp64 evaluation, accumulated
+    log-prob likewise, and directly against the reference's recorded sums."""
+    z = np.load(path)
+    N = int(z["N"])
+    if mode == "tile" and N > 104:
+        pytest.skip("raw-tile kernel: N <= 104")
+    _compare_rollout(int(z["kind"]), int(z["B"]), N, False, 69, 69, int(z["torch_seed"]),
+                     ref_actions=z["actions"], ref_loss=z["acc_loss"], ref_logp=z["acc_logp"],
+                     ref_T=int(z["T"]), train=True, tile_kernel=mode == "tile",
+                     table_kernel=mode == "table")
 
 
 @pytest.mark.parametrize("kind,B,N,greedy,train", [
@@ -1142,3 +1266,24 @@ def test_in_kernel_sampling_noise(kind, B, N):
     ma, mh = -a.acc_loss.mean().item(), -h.acc_loss.mean().item()
     sd = a.acc_loss.std().item() / (B ** 0.5)
     assert abs(ma - mh) < 6 * sd + 0.01 * mh, (ma, mh, sd)
+
+
+def test_in_kernel_noise_is_strictly_positive_and_finite():
+    """The bits -> Exp(1) map of the in-kernel sampler: q in (0, inf) for EVERY 32-bit draw.
+    (q = -0.0 at the largest draw made p/q = -inf on the one selectable node of a forced move
+    and let a masked node win the argmax: advisor finding, round 3.)"""
+    import vrpgym_hip as hip
+    lib = hip.lib()
+    edge = torch.tensor([0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFF00,
+                         0xFFFFFFFE, 0xFFFFFFFF], dtype=torch.int64)
+    rnd = torch.randint(0, 2 ** 32, (1 << 20,), dtype=torch.int64)
+    bits = torch.cat([edge, rnd]).numpy().astype(np.uint32)
+    d_bits = torch.from_numpy(bits.view(np.int32)).cuda()
+    out = torch.empty(len(bits), dtype=torch.float32, device="cuda")
+    hip.check(lib.vrp_debug_exp1_from_bits(d_bits.data_ptr(), out.data_ptr(), len(bits),
+                                           hip.current_stream()))
+    q = out.cpu().numpy()
+    assert np.all(q > 0) and np.all(np.isfinite(q)) and not np.any(np.signbit(q))
+    u = ((bits >> 9).astype(np.float64) + 0.5) / 2.0 ** 23
+    assert np.max(np.abs(q - (-np.log(u))) / np.maximum(-np.log(u), 1e-6)) < 1e-3
+    assert abs(q[len(edge):].mean() - 1.0) < 5e-3      # Exp(1)

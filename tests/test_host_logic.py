@@ -139,7 +139,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert lib.vrp_abi_version() == 4
+    assert lib.vrp_abi_version() == 5
+    assert len(lib.vrp_source_hash()) == 16
     assert lib.vrp_decoder_derived_bytes() > 0
     assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
     assert lib.vrp_decoder_workspace_bytes(0, 512, 20) > 2 * 512 * 20 * 8 * 20 * 4
@@ -248,7 +249,7 @@ assert vrpgym_hip.library_path().endswith("_asan.so")
 header = open(os.path.join(%(root)r, "include", "vrpgym_hip.h")).read()
 for n in sorted(set(re.findall(r"\b(vrp_[a-z_0-9]+)\s*\(", header))):
     assert hasattr(lib, n), n
-assert lib.vrp_abi_version() == 4 and lib.vrp_decoder_derived_bytes() > 0
+assert lib.vrp_abi_version() == 5 and lib.vrp_decoder_derived_bytes() > 0
 for B, N in ((1, 2), (512, 20), (8192, 40), (2048, 100), (5, 128)):
     assert lib.vrp_encoder_workspace_bytes(B, N, 512) > 0
     for kind in (0, 1, 2):

@@ -9,6 +9,9 @@ R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
+# identity of the build every number below is measured on (bench.py reports roofline.traffic only
+# from a file carrying the hash of the library it runs)
+python3 -c "import sys; sys.path.insert(0, 'vrp-gym_amd'); import vrpgym_hip; print(vrpgym_hip.lib().vrp_source_hash().decode())" > $OUT/source_hash.txt
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o p -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_prof.log 2>&1
 for shp in 0,20,512 0,40,8192 1,40,8192 2,40,8192 1,100,2048,0,1; do

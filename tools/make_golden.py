@@ -343,6 +343,139 @@ def gen_rollouts():
         json.dump(STATS, f, indent=1)
 
 
+# ---------------------------------------------------------------- (vi') train-mode rollouts
+def _err_stats(trace_a, trace_b, T):
+    """max / mean |d logit| over selectable nodes and max |d logp| per step between two
+    teacher-forced traces of the same action path."""
+    du, dl, n, su = 0.0, 0.0, 0, 0.0
+    for t in range(T):
+        ua, ub = trace_a[t]["u"].double(), trace_b[t]["u"].double()
+        fin = torch.isfinite(ua)
+        assert torch.equal(fin, torch.isfinite(ub))
+        d = (ua[fin] - ub[fin]).abs()
+        du = max(du, d.max().item())
+        su += d.sum().item()
+        n += d.numel()
+        dl = max(dl, (trace_a[t]["logp"].double() - trace_b[t]["logp"].double()).abs().max().item())
+    return du, su / max(n, 1), dl
+
+
+def _measure_train_case(kind, B, N, greedy, env_seed=69, agent_seed=69, torch_seed=77):
+    """One train-mode rollout of the REFERENCE plus three evaluations on ITS action path: the
+    reference's own per-step logits / log-probs (fp32), the fp32 oracle's, and the fp64
+    oracle's.  Returns (stats dict, arrays for a fixture)."""
+    real_tanh = torch.tanh
+    ag = REF_AGENT[kind](seed=agent_seed)
+    env = REF_ENV[kind](N, B, 1, env_seed)
+    ag.model.train()
+    acts, step_lp, step_u = [], [], []
+    orig_step = env.step
+
+    def rec_step(a, _o=orig_step, _acts=acts):
+        _acts.append(np.array(a)[:, 0].copy())
+        return _o(a)
+
+    env.step = rec_step
+    dec_fwd = ag.model.decoder.forward
+
+    def rec_fwd(*a, _f=dec_fwd, _lp=step_lp, **k):
+        idx, lp = _f(*a, **k)
+        _lp.append(lp.detach().reshape(-1).clone())
+        return idx, lp
+
+    ag.model.decoder.forward = rec_fwd
+
+    # the decoder's logits are a local of GraphDecoder.forward (graph_decoder.py:97): its
+    # torch.tanh call is the only one on the path, record what it returns
+    def rec_tanh(x, _u=step_u):
+        y = real_tanh(x)
+        _u.append((y.detach() * 10).reshape(y.shape[0], -1).clone())
+        return y
+
+    torch.tanh = rec_tanh
+    try:
+        torch.manual_seed(torch_seed)
+        with torch.no_grad():
+            loss, logp = ag.model(env, greedy)
+    finally:
+        torch.tanh = real_tanh
+    racts = np.array(acts)
+    T = len(racts)
+    assert len(step_u) == T and len(step_lp) == T
+    sd, _ = opol.init_state_dicts(kind, agent_seed)
+    traces = {}
+    for tag, sdx in (("o32", sd), ("o64", opol.as_double(sd))):
+        oe = oenv.OracleEnv(kind, N, B, 1, env_seed)
+        torch.manual_seed(torch_seed)
+        tr = []
+        with torch.no_grad():
+            ol, olp, oT = opol.rollout({k: v.clone() for k, v in sdx.items()}, oe, greedy,
+                                       train=True, forced=racts, trace=tr)
+        assert oT == T
+        traces[tag] = (tr, ol, olp)
+    ref_tr = [{"u": step_u[t].masked_fill(~torch.isfinite(traces["o64"][0][t]["u"]),
+                                          float("-inf")),
+               "logp": step_lp[t]} for t in range(T)]
+    r64 = _err_stats(ref_tr, traces["o64"][0], T)
+    o64 = _err_stats(traces["o32"][0], traces["o64"][0], T)
+    r32 = _err_stats(ref_tr, traces["o32"][0], T)
+    acc_r = (logp.double() - traces["o64"][2]).abs().max().item()
+    acc_o = (traces["o32"][2].double() - traces["o64"][2]).abs().max().item()
+    st = {"kind": kind, "B": B, "N": N, "greedy": bool(greedy), "T": T,
+          "seeds": [env_seed, agent_seed, torch_seed],
+          "reference_fp32_vs_fp64": {"du_max": r64[0], "du_mean": r64[1],
+                                     "dlogp_step_max": r64[2], "dlogp_acc_max": acc_r},
+          "oracle_fp32_vs_fp64": {"du_max": o64[0], "du_mean": o64[1],
+                                  "dlogp_step_max": o64[2], "dlogp_acc_max": acc_o},
+          "reference_vs_oracle_fp32": {"du_max": r32[0], "dlogp_step_max": r32[2]}}
+    return st, dict(actions=racts, acc_loss=loss.numpy(), acc_logp=logp.numpy(),
+                    step_logp=torch.stack(step_lp).numpy())
+
+
+def gen_train_rollouts():
+    """Train-mode (batch-statistics BatchNorm) rollouts of the REFERENCE, and how far its fp32
+    results sit from an fp64 evaluation of the same model on the same action path -- next to
+    the same figure for the fp32 oracle.  The GPU parity tests bound the HIP path's train-mode
+    error against the fp64 evaluation by twice the reference's own (tests/test_gpu_parity.py:
+    _train_bounds).  Output: tests/golden/train_mode_error.json = {"cases": the seven shapes
+    whose rollouts are also committed as trainrollout_*.npz, "sweep": the same statistics over
+    random shapes / seeds / greedy-or-sampled (no fixtures), from which the tests take the
+    largest reference-to-oracle error ratio}."""
+    import json
+    import random
+    print("[train-mode rollouts]")
+    cases, sweep = [], []
+
+    def show(st):
+        r, o, x = (st["reference_fp32_vs_fp64"], st["oracle_fp32_vs_fp64"],
+                   st["reference_vs_oracle_fp32"])
+        print(f"   kind={st['kind']} B={st['B']} N={st['N']} greedy={st['greedy']} T={st['T']}: "
+              f"|du| ref {r['du_max']:.2e} oracle {o['du_max']:.2e} (ref-vs-oracle {x['du_max']:.2e}); "
+              f"step |dlogp| ref {r['dlogp_step_max']:.2e} oracle {o['dlogp_step_max']:.2e}; "
+              f"acc ref {r['dlogp_acc_max']:.2e} oracle {o['dlogp_acc_max']:.2e}")
+
+    for kind, B, N in [(1, 33, 100), (1, 64, 40), (2, 31, 33), (0, 32, 40), (2, 24, 100),
+                       (0, 48, 20), (1, 16, 10)]:
+        st, arrs = _measure_train_case(kind, B, N, False)
+        st["case"] = f"trainrollout_k{kind}_B{B}_N{N}_sample"
+        show(st)
+        cases.append(st)
+        save(st["case"], kind=kind, B=B, N=N, greedy=False, torch_seed=77, T=st["T"], **arrs)
+    rng = random.Random(2026)
+    for _ in range(int(os.environ.get("VRPGYM_TRAIN_SWEEP", "120"))):
+        kind = rng.choice([0, 1, 2])
+        N = rng.choice([5, 9, 16, 17, 20, 31, 33, 40, 50, 63, 65, 80, 100, 108, 128])
+        B = rng.choice([2, 7, 8, 9, 33, 64])
+        if N > 64:
+            B = min(B, 33)
+        st, _ = _measure_train_case(kind, B, N, rng.random() < 0.5, rng.randint(0, 999),
+                                    rng.choice([69, 1, 7]), rng.randint(0, 999))
+        show(st)
+        sweep.append(st)
+    with open(os.path.join(OUT, "train_mode_error.json"), "w") as f:
+        json.dump({"cases": cases, "sweep": sweep}, f, indent=1)
+
+
 # ---------------------------------------------------------------- KATs of the reference's tests
 def gen_kats():
     print("[reference test KATs through the oracle]")
@@ -418,10 +551,11 @@ def math_sqrt(x):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["kats", "instances", "envtraces", "weights", "encoder",
-                             "decoder", "rollouts", "trainstep"]
+                             "decoder", "rollouts", "trainstep", "trainrollouts"]
     table = {"kats": gen_kats, "instances": gen_instances, "envtraces": gen_env_traces,
              "weights": gen_weight_hashes, "encoder": gen_encoder, "decoder": gen_decoder,
-             "rollouts": gen_rollouts, "trainstep": gen_train_step}
+             "rollouts": gen_rollouts, "trainstep": gen_train_step,
+             "trainrollouts": gen_train_rollouts}
     for w in which:
         table[w]()
     print("done")

@@ -16,6 +16,7 @@ import os
 import sys
 
 DECODE = ("decode_step_rt_kernel", "decode_persistent_kernel", "decode_step_tile_mfma_kernel",
+          "decode_step_tile_zmfma_kernel",
           "persistent_finalize_kernel")
 
 
@@ -65,7 +66,12 @@ def main():
         res[w] = {"fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1),
                   "decode_launches": launches + persistent, "steps": steps,
                   "hbm_bytes_per_launch": int((2 * fetch + write) * 1024 / max(steps, 1))}
-    doc = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace "
+    sha = None
+    sha_file = os.path.join(os.path.dirname(root.rstrip("/")), "source_hash.txt")
+    if os.path.exists(sha_file):
+        sha = open(sha_file).read().strip()
+    doc = {"source_hash": sha,
+           "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace "
                    "only) around tools/step_probe.py; FETCH_SIZE doubled as MI355X_MICROARCH.md "
                    "prescribes for gfx950, KB -> bytes x1024; HBM bytes of all decode kernels per "
                    "env step (tools/pmc_traffic.py)",

@@ -12,7 +12,14 @@ void vrp_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *vrp_last_error(void) { return g_err; }
-extern "C" int vrp_abi_version(void) { return 4; }
+extern "C" int vrp_abi_version(void) { return 5; }
+// sha256 (first 16 hex digits) over the kernel sources this library was built from, set by the
+// Makefile: measurements kept under profiles/ (PMC traffic) carry it, and bench.py reports them
+// only for the build they were taken on
+#ifndef VRP_SOURCE_SHA
+#define VRP_SOURCE_SHA "unknown"
+#endif
+extern "C" const char *vrp_source_hash(void) { return VRP_SOURCE_SHA; }
 
 // Episode accumulators := 0.  A kernel rather than hipMemsetAsync: memset nodes inside a
 // captured hipGraph were observed to race with the kernels that follow them (ROCm 7.0

@@ -604,8 +604,9 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
   p.skip_curs = 0;
-  static const int dbg = getenv("VRP_TILE_DBG") ? atoi(getenv("VRP_TILE_DBG")) : 0;
-  p.dbg = dbg;
+  // tuning aid, read at every call (tools/tile_phase_probe.py changes it between launches)
+  const char *dbg = getenv("VRP_TILE_DBG");
+  p.dbg = dbg ? atoi(dbg) : 0;
   static const int stagger = getenv("VRP_TILE_STAGGER") ? atoi(getenv("VRP_TILE_STAGGER")) : 0;
   p.stagger = stagger;
   p.env = *env;
@@ -682,19 +683,22 @@ static bool hybrid_shape(int kind, int B, int N) {
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
-  const char *tile = N <= 40    ? "decode_step_tile_mfma_kernel<40, 2, 8>"
-                     : N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8>"
-                                : "decode_step_tile_mfma_kernel<104, 1, 8>";
+  const bool v2 = !tile_v1_forced() && vrp_tile2_supported(N);
+  const char *tile = v2 ? (N <= 40 ? "decode_step_tile_zmfma_kernel<40, 2>" : "decode_step_tile_zmfma_kernel<100, 1>")
+                        : N <= 40    ? "decode_step_tile_mfma_kernel<40, 2, 8>"
+                          : N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8>"
+                                     : "decode_step_tile_mfma_kernel<104, 1, 8>";
   if (flags & VRP_STEP_TILE_KERNEL) return tile;
   if (N > 64 && vrp_tile_mfma_supported(N) && !(flags & VRP_STEP_THROUGHPUT_KERNEL) &&
       getenv("VRP_TILE_LARGE_N")) return tile;
-  if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL))
-    return N <= 40 ? "decode_step_tile_mfma_kernel<40, 2, 8> (first steps) | decode_step_rt_kernel<1, 4>"
-                   : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
-                          ? (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> (first steps) | decode_step_rt_kernel<2, 1>"
-                                      : "decode_step_tile_mfma_kernel<104, 1, 8> (first steps) | decode_step_rt_kernel<2, 1>")
-                          : (N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8> (first steps) | decode_step_rt_kernel<2, 4>"
-                                      : "decode_step_tile_mfma_kernel<104, 1, 8> (first steps) | decode_step_rt_kernel<2, 4>"));
+  if (hybrid_shape(kind, B, N) && !(flags & VRP_STEP_TABLE_KERNEL)) {
+    static thread_local char name[160];
+    const char *rt = N <= 40 ? "decode_step_rt_kernel<1, 4>"
+                             : (B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL)
+                                    ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>");
+    snprintf(name, sizeof(name), "%s (first steps) | %s", tile, rt);
+    return name;
+  }
   const bool small = B <= 2048 && !(flags & VRP_STEP_THROUGHPUT_KERNEL);
   if (N <= 64) return small ? "decode_step_rt_kernel<1, 1>" : "decode_step_rt_kernel<1, 4>";
   return small ? "decode_step_rt_kernel<2, 1>" : "decode_step_rt_kernel<2, 4>";

@@ -78,3 +78,5 @@ void vrp_persistent_serialize_begin(hipStream_t st, void **token);
 void vrp_persistent_serialize_end(hipStream_t st, void *token);
 bool vrp_tile_mfma_supported(int N);
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st);
+bool vrp_tile2_supported(int N);
+int vrp_launch_tile2_step(const StepParams &p, hipStream_t st);

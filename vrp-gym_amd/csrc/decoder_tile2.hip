@@ -1,72 +1,82 @@
-// Decode + env step from the RAW embedding tile (the "streaming formulation" of SURVEY.md
-// 8d): a graph-step reads its (N,128) fp32 tile ONCE -- exactly the algorithmic 512 N bytes --
-// instead of one 32 N-byte row of the pointer-logit table per selectable node.  It wins
-// wherever many nodes are still selectable: vrp_decode_step launches it for the first steps of
-// an episode (64 < N <= 104: about two thirds of them; N <= 40, large batches: while every graph
-// keeps most of its nodes) and the table kernel (decoder.hip) afterwards.
+// Decode + env step from the RAW embedding tile, second generation (round 4): the same step as
+// decoder_tile.hip -- a graph-step reads its (N,128) fp32 tile ONCE, exactly the algorithmic
+// 512 N bytes of SURVEY.md 8d -- with the tile held in the operand layout of the matrix cores,
+// so that the glimpse sums run on them WHILE the rest of the tile still streams in, and the
+// pointer logits need a 16-lane (one DPP row) reduction instead of a 64-lane one:
 //
-// Same algebra as the table kernel:
-//   a[h][n]   glimpse weights from the score rows (row0 | SL[last] + base) + scrambled masks
-//   z_h       = sum_n a[h][n] e_n                             (8 x 128)   VALU, lane = 2 dims
-//   o_h       = Wv_h z_h + bv_h,  w = M o + mb                matrix cores, 16 graphs per tile
-//   u_n       = 10 tanh(e_n . w + cvec_n)                     VALU + cross-lane reduce-scatter
-// Workgroup = 8 waves = 8*GPW graphs.  A wave keeps its graphs' tiles in registers (lane =
-// two embedding columns: e[n] is a float2; filled two rows per 16-byte load from the row-paired
-// copy DecWs::embP where the prologue built one, else row by row) through both passes over them.
-// The two weight folds are batched over the workgroup's graphs as the 16 rows of
-// v_mfma_f32_16x16x4_f32 (A = z / o rows from LDS, B = weight fragments streamed from L2 in
-// MFMA fragment order, Derived::WvP/MP: the 384 KB of folded weights are shared by every
-// workgroup and step).  The partial dot products
-// e_n . w of a lane's two columns are summed over the 64 lanes by a butterfly reduce-scatter
-// that leaves node n's total in lane n -- the layout the action/env code wants.
+//   lane (r, c) = (lane >> 4, lane & 15) holds, for k-step j and half hf, the float4
+//       T[j][hf] = e[node 4 j + r][columns 64 hf + 4 c .. 4 c + 3]
+//   (one load instruction = four rows x 256 contiguous bytes, straight from `emb`: no paired
+//   copy of the embeddings, no pair_rows_kernel).
+//
+//   a[h][n]   glimpse weights from the score rows + scrambled masks (graph_decoder.py:93-94),
+//             lane = node, through LDS                                        VALU, as before
+//   z_h       = sum_n a[h][n] e_n  =  v_mfma_f32_16x16x4_f32 with A[m = head][k = r] =
+//             a[h][4 j + r] (LDS, one dword per k-step) and B[k = r][n = c] = T[j][hf].{x,y,z,w}:
+//             eight accumulators (hf, element), 2 NMAX MFMAs per graph, issued in the order the
+//             rows land -- the matrix pipe works under the tile loads instead of 16 N packed
+//             FMAs per lane running behind them (round 3: 19.5 us of loads, THEN 12.9 us of
+//             vector issue, THEN 4.2 us of folds per step at 2048 x 100)
+//   o = Wv z + bv, w = M o + mb   the two weight folds, unchanged (decoder_tile.hip)
+//   u_n       = 10 tanh(e_n . w + cvec_n): eight FMAs per node in the lane (its 8 columns), then
+//             a reduce-scatter over the 16 lanes of the row (DPP only: row_ror:8, row_half_mirror,
+//             two quad_perms; 45 instructions per 16 nodes) and one trip through LDS to the
+//             lane = node layout the action / env code wants (round 3: 64-lane butterfly, 252
+//             instructions per 64 nodes + 2 per node of products)
+//
+// Everything after the logits (argmax / Categorical sample, env.step on registers, traces) is
+// the code of decoder_tile.hip.
 #include "decoder_step.h"
 
-#define TL_ZG 1028  // zs: floats between graphs (8 heads x 128 + 4: conflict-free b128 reads)
-#define TL_OS 388   // os: floats per graph row (384 + 4)
-#define TL_WS 132   // ws: floats per graph row
+#define T2_ZG 1028  // zs: floats between graphs (8 heads x 128 + 4: conflict-free b128 reads)
+#define T2_OS 388   // os: floats per graph row (384 + 4)
+#define T2_WS 132   // ws: floats per graph row
+#define T2_US 128   // us: pointer-logit pre-activations of a graph, lane = node order
 
-// sum over the 64 lanes of v[i] (i = node 0..63 of this block) -> lane n returns node n's total
-template <int LEN>
-__device__ __forceinline__ float reduce_scatter64(float (&v)[LEN], int lane) {
-  if constexpr (LEN == 1) {
-    return v[0];
-  } else {
-    constexpr int H = LEN / 2;           // lanes with bit H set keep the upper half
-    const bool up = (lane & H) != 0;
-    float nv[H];
+#define T2_DPP_ADD(x, ctrl) ((x) + VRP_DPP(0.f, (x), (ctrl), 0xF))
+
+// v[i] (i = 0..15) summed over the 16 lanes of each DPP row; lane c of a row returns the total of
+// v[c].  Recursive halving; partners c^8 (row_ror:8), c^7 (row_half_mirror), c^2, c^1 (quad_perm):
+// the lanes a value has been summed over double at every level and stay disjoint, the kept half
+// follows bit 3, 2, 1, 0 of c.
+__device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int c) {
+  float a[8], b[4], d[2];
+  const bool u8 = (c & 8) != 0, u4 = (c & 4) != 0, u2 = (c & 2) != 0, u1 = (c & 1) != 0;
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
-      const float keep = up ? v[i + H] : v[i];
-      const float send = up ? v[i] : v[i + H];
-      nv[i] = keep + __shfl_xor(send, H, 64);
-    }
-    return reduce_scatter64<H>(nv, lane);
+  for (int i = 0; i < 8; ++i) {
+    const float keep = u8 ? v[i + 8] : v[i], send = u8 ? v[i] : v[i + 8];
+    a[i] = keep + VRP_DPP(0.f, send, 0x128, 0xF);   // row_ror:8
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = u4 ? a[i + 4] : a[i], send = u4 ? a[i] : a[i + 4];
+    b[i] = keep + VRP_DPP(0.f, send, 0x141, 0xF);   // row_half_mirror
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = u2 ? b[i + 2] : b[i], send = u2 ? b[i] : b[i + 2];
+    d[i] = keep + VRP_DPP(0.f, send, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+  }
+  const float keep = u1 ? d[1] : d[0], send = u1 ? d[0] : d[1];
+  return keep + VRP_DPP(0.f, send, 0xB1, 0xF);      // quad_perm [1,0,3,2]
 }
 
-// NW = waves per workgroup.  8: one 16-graph (GPW = 2) or 8-graph workgroup fills a CU, every
-// phase of its graphs runs in lockstep.  4: half the graphs per workgroup (the MFMA tiles run with
-// 8 or 4 of their 16 rows in use) and TWO workgroups per CU that drift apart, so the tile loads of
-// one run under the folds and logits of the other.
-template <int NMAX, int GPW, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepParams p) {
+template <int NMAX, int GPW>
+__global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepParams p) {
+  constexpr int NW = 8;
+  constexpr int KS = NMAX / 4;             // k-steps of four nodes
   constexpr int NPL = (NMAX + 63) / 64;
-  constexpr int GPB = NW * GPW;  // graphs per workgroup (<= 16 = rows of one MFMA tile)
-  constexpr int ROWS = NW == 8 ? 16 : GPB;   // rows of the LDS operand images (power of two)
-  constexpr int HPW = 8 / NW;                // heads (fold 1) / 16-column tiles (fold 2) per wave
+  constexpr int GPB = NW * GPW;            // graphs per workgroup (<= 16 = rows of one MFMA tile)
+  constexpr int ROWS = 16;
+  static_assert(NMAX % 4 == 0 && GPB <= 16, "tile shape");
   if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
-  // Every workgroup alternates between a phase that only loads (the tile) and phases that only
-  // compute; launched together they do so in lockstep and the memory system idles while the
-  // CUs compute.  Every other workgroup of an XCD (blocks b and b + 8 share one) starts late, so
-  // that one half of the chip loads at up to twice its share while the other half computes.
-  if (p.stagger > 0 && ((blockIdx.x >> 3) & 1))
-    for (int i = 0; i < p.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *a_s = smem;                      // [GPB][NMAX*8]  a[g][n][h]
-  float *zs = a_s + GPB * NMAX * 8;       // [ROWS][TL_ZG]  z[g][h][128]
-  float *os = zs + ROWS * TL_ZG;          // [ROWS][TL_OS]  o[g][384]
-  float *ws = os + ROWS * TL_OS;          // [ROWS][TL_WS]  w[g][128]
+  float *zs = a_s + GPB * NMAX * 8;       // [ROWS][T2_ZG]  z[g][h][128]
+  float *os = zs + ROWS * T2_ZG;          // [ROWS][T2_OS]  o[g][384]
+  float *ws = os + ROWS * T2_OS;          // [ROWS][T2_WS]  w[g][128]
+  float *us = ws + ROWS * T2_WS;          // [GPB][T2_US]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,10 +84,10 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   const int par = p.t & 1;
   const uint8_t *mask_in = p.env.mask + (size_t)par * B * N;
   uint8_t *mask_out = p.env.mask + (size_t)(par ^ 1) * B * N;
-  const int i16 = lane & 15, q = lane >> 4;
+  const int i16 = lane & 15, q = lane >> 4;   // (c, r) of the header comment
 
   // ---- per-graph state kept across the matrix phase ---------------------------------------
-  float2 e[GPW][NMAX];
+  float4 T[GPW][KS][2];
   int own_mask[GPW][NPL], vis[GPW][NPL];
   double2 xy[GPW][NPL];
   double dem[GPW][NPL];
@@ -87,8 +97,8 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   float accl[GPW], accp[GPW];
   bool proc[GPW];
   // env row, noise, accumulators of a graph (lane = node).  Two nodes per lane (N > 64): the
-  // tile alone takes 208 registers, so these are fetched after the matrix phase (in flight
-  // during the reduce-scatter) instead of being carried through it.
+  // tile alone takes 200 registers, so these are fetched after the matrix phase (in flight
+  // during the logit sums) instead of being carried through it.
   constexpr bool DEFER = NPL > 1;
   auto load_env = [&](int gi, int b) {
 #pragma unroll
@@ -110,6 +120,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
 #ifdef VRP_MUTATION_NOISE_SHIFT  // test-the-tests build: off-by-one noise index
       if (p.sample && p.io.noise) q_noise[gi][i] = p.io.noise[((size_t)p.t * B + b) * N + (l + 1) % N];
 #endif
+      if (DEFER) own_mask[gi][i] = mask_in[(size_t)b * N + l];
     }
     cur[gi] = p.decode_only ? 0 : p.env.cur[b];
     dep[gi] = p.decode_only ? 0 : p.env.depot[b];
@@ -117,8 +128,6 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     if (!p.decode_only) { accl[gi] = p.io.acc_loss[b]; accp[gi] = p.io.acc_logp[b]; }
   };
 
-  // (the host picks ONE kernel per step from the step number, launch_step_any: nothing here
-  // waits for the mask rows -- the score rows and the tile are requested in the same round trip)
   int lastn[GPW];
 #pragma unroll
   for (int gi = 0; gi < GPW; ++gi) {
@@ -127,10 +136,12 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
     bg[gi] = b;
     lastn[gi] = p.t > 0 ? p.last[b] : 0;   // requested with the mask rows, not behind them
+    if (!DEFER) {
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const bool in = lane + 64 * i < N;
-      own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
+      for (int i = 0; i < NPL; ++i) {
+        const bool in = lane + 64 * i < N;
+        own_mask[gi][i] = mask_in[(size_t)b * N + (in ? lane + 64 * i : 0)];
+      }
     }
     proc[gi] = active;
   }
@@ -144,9 +155,9 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
     if (!proc[gi]) continue;  // wave-uniform
     // ---- loads.  Order matters (they return in order): the score rows and masks first, then
-    // the first half of the tile; the glimpse weights are computed while the tile streams in,
-    // the second half is requested behind them and the sums below consume rows as they land.
-    constexpr int NH = NMAX / 2;
+    // the first half of the tile; the glimpse weights are computed while it streams in, the
+    // second half is requested behind them and the MFMAs below consume k-steps as they land.
+    constexpr int KH = (KS + 1) / 2;
     const size_t row = (size_t)b * 8 * N;
     const float *srow = p.row0 + row;
     if (p.t > 0) {
@@ -166,24 +177,18 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
         sl_[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
         mo[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
       }
-    // the tile: from the row-paired copy two rows per 16-byte load (prologue: pair_rows_kernel),
-    // else row by row
-    const float2 *src = reinterpret_cast<const float2 *>(p.emb + (size_t)b * N * VRP_EMB) + lane;
-    const float4 *srcP = p.embP ? reinterpret_cast<const float4 *>(p.embP) +
-                                      (size_t)b * ((N + 1) / 2) * 64 + lane : nullptr;
-    static_assert(NH % 2 == 0, "the first half of the tile is a whole number of row pairs");
-    if (srcP) {
+    // the tile, in MFMA operand order: k-step j, half hf = rows 4j..4j+3, 256 bytes of each
+    const float4 *src = reinterpret_cast<const float4 *>(p.emb + (size_t)b * N * VRP_EMB) +
+                        (size_t)q * (VRP_EMB / 4) + i16;
+    auto load_kstep = [&](int j) {
+      const bool in = 4 * j + q < N;
 #pragma unroll
-      for (int i = 0; i < NH / 2; ++i) {
-        const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-        e[gi][2 * i] = make_float2(v.x, v.y);
-        e[gi][2 * i + 1] = make_float2(v.z, v.w);
-      }
-    } else {
+      for (int hf = 0; hf < 2; ++hf)
+        T[gi][j][hf] = in ? src[(size_t)j * (4 * VRP_EMB / 4) + 16 * hf]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
 #pragma unroll
-      for (int n = 0; n < NH; ++n)
-        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
-    }
+    for (int j = 0; j < KH; ++j) load_kstep(j);
     __builtin_amdgcn_sched_barrier(0);
     float sc[NPL][8];  // score + additive scrambled mask
 #pragma unroll
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       }
     }
     if (!DEFER) load_env(gi, b);
-    if (p.dbg == 1) { if (e[gi][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
+    if (p.dbg == 1) { if (T[gi][0][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
 
     // ---- glimpse attention weights (lane = n), one wave-wide shift for all eight heads -----
     {
@@ -235,74 +240,59 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
           if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
       }
     }
-    if (srcP) {
 #pragma unroll
-      for (int i = NH / 2; i < NMAX / 2; ++i) {
-        const float4 v = (2 * i < N) ? srcP[(size_t)i * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-        e[gi][2 * i] = make_float2(v.x, v.y);
-        e[gi][2 * i + 1] = make_float2(v.z, v.w);
-      }
-    } else {
-#pragma unroll
-      for (int n = NH; n < NMAX; ++n)
-        e[gi][n] = (n < N) ? src[(size_t)n * 64] : make_float2(0.f, 0.f);
-    }
+    for (int j = KH; j < KS; ++j) load_kstep(j);
     __builtin_amdgcn_sched_barrier(0);
     // a_s of this graph is written and read by this wave only: LDS ops of one wave are ordered
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-    // ---- z_h[2l..2l+1] = sum_n a[h][n] * e[n][2l..2l+1] -------------------------------------
+    // ---- z_h = sum_n a[h][n] e_n on the matrix cores, k-steps in the order they land --------
     {
-      float2 z[8];
+      f32x4 zacc[2][4];
 #pragma unroll
-      for (int h = 0; h < 8; ++h) z[h] = make_float2(0.f, 0.f);
-      const float4 *ap = reinterpret_cast<const float4 *>(a_s + (size_t)g * NMAX * 8);
-      // the weights of node n + 1 are read (LDS broadcast) before node n's sixteen FMAs are
-      // issued: left to the compiler, every node started with an LDS round trip
-      float4 a0 = ap[0], a1 = ap[1];
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int n = 0; n < NMAX; ++n) {
-        const float4 c0 = a0, c1 = a1;
-        if (n + 1 < NMAX) { a0 = ap[2 * n + 2]; a1 = ap[2 * n + 3]; }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n < N) {
-          const float av[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        for (int el = 0; el < 4; ++el) zacc[hf][el] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // A[m = lane & 15][k = lane >> 4] = a[head m & 7][node 4 j + k]  (rows 8..15 repeat the heads)
+      const float *ap = a_s + (size_t)g * NMAX * 8 + q * 8 + (i16 & 7);
+      float an = ap[0];
 #pragma unroll
-          for (int h = 0; h < 8; ++h) {
-            z[h].x = fmaf(av[h], e[gi][n].x, z[h].x);
-            z[h].y = fmaf(av[h], e[gi][n].y, z[h].y);
-          }
+      for (int j = 0; j < KS; ++j) {
+        const float ac = an;
+        if (j + 1 < KS) an = ap[(j + 1) * 32];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float4 t = T[gi][j][hf];
+          zacc[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.x, zacc[hf][0], 0, 0, 0);
+          zacc[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.y, zacc[hf][1], 0, 0, 0);
+          zacc[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.z, zacc[hf][2], 0, 0, 0);
+          zacc[hf][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.w, zacc[hf][3], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      // D[m = 4 q + i][n = c] = z[head 4 q + i][column 64 hf + 4 c + element]: lanes q < 2 hold
+      // the eight heads; one 16-byte store per (hf, i)
+      if (q < 2) {
 #pragma unroll
-      for (int h = 0; h < 8; ++h)
-        *reinterpret_cast<float2 *>(zs + g * TL_ZG + h * 128 + 2 * lane) = z[h];
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(zs + g * T2_ZG + (4 * q + i) * 128 + 64 * hf + 4 * i16) =
+                make_float4(zacc[hf][0][i], zacc[hf][1][i], zacc[hf][2][i], zacc[hf][3][i]);
+      }
     }
   }
   if (p.dbg == 1 || p.dbg == 2) return;
   __syncthreads();
 
   // ---- matrix phase: o = Wv z + bv (wave = head), then w = M o + mb (wave = 16 columns) ----
-  // The weight fragments come from L2 (~600 cycles): they are requested PF k-steps ahead of
-  // their MFMAs, and the first ones of the second product before the barrier in between.
-  constexpr int PF = 3;    // first product: a k-step is 12 MFMAs (384 cycles of matrix pipe)
-  constexpr int PF2 = NMAX > 64 ? 5 : 8;   // second product: 4 MFMAs per k-step (128 cycles) against the same ~600-
-                           // cycle fragment latency; the ring reuses the first product's registers
-  // Inner dimensions are spread over the four 16-lane groups as k = 16 S + 4 q + e (S = k-step,
-  // e = element of the lane's float4): the four lanes that read one weight row in one
-  // instruction cover 64 consecutive bytes, so a fragment load touches 16 cache lines instead
-  // of 64 (the vector memory pipe looks lines up one by one, and eight waves stream 384 KB of
-  // weights through it in this phase).  Same permutation on the LDS operand.
-  const int koff2 = 4 * q;
-  const int arow_g = i16 & (ROWS - 1);  // MFMA row -> graph (rows beyond the workgroup's graphs
-                                        // repeat them; their results are dropped)
+  // (decoder_tile.hip: fragments of the folded weights in MFMA order from L2, requested PF
+  // k-steps ahead; inner dimensions spread over the lane groups as k = 16 S + 4 q + e)
+  constexpr int PF = 3;
+  constexpr int PF2 = NMAX > 64 ? 5 : 8;
+  const int koff = 4 * q;
   float4 mw[PF2];
-#pragma unroll 1
-  for (int hh = 0; hh < HPW; ++hh) {
-    const int koff = 4 * q;
-    const int h = wave * HPW + hh;
-    // fragment (k4, c) of head h, in MFMA operand order (Derived::WvP): 64 consecutive float4
+  {
+    const int h = wave;
     const float4 *wbase = reinterpret_cast<const float4 *>(p.WvP) + (size_t)h * 24 * 64 + lane;
     float4 wq[PF][3];
 #pragma unroll
@@ -315,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       const float bb = p.bv[h * VRP_HD + 16 * c + i16];  // D column = lane & 15
       acc[c] = f32x4{bb, bb, bb, bb};
     }
-    const float *arow = zs + arow_g * TL_ZG + h * 128 + koff;   // A row = graph
+    const float *arow = zs + i16 * T2_ZG + h * 128 + koff;   // A row = graph
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -338,25 +328,17 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)  // D: row = graph 4q + r4, column = lane & 15
-        if (4 * q + r4 < ROWS) os[(4 * q + r4) * TL_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
+        os[(4 * q + r4) * T2_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
   }
-  {  // the second product's first fragments travel across the barrier
-    const float4 *mrow0 = reinterpret_cast<const float4 *>(p.MP) + (size_t)(wave * HPW) * 24 * 64 + lane;
+  const float4 *mrow = reinterpret_cast<const float4 *>(p.MP) + (size_t)wave * 24 * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < PF2; ++j) mw[j] = mrow0[j * 64];
-  }
+  for (int j = 0; j < PF2; ++j) mw[j] = mrow[j * 64];  // travel across the barrier
   __syncthreads();
-#pragma unroll 1
-  for (int cc = 0; cc < HPW; ++cc) {
-    const int ct = wave * HPW + cc;
-    const float4 *mrow = reinterpret_cast<const float4 *>(p.MP) + (size_t)ct * 24 * 64 + lane;
-    if (cc > 0) {
-#pragma unroll
-      for (int j = 0; j < PF2; ++j) mw[j] = mrow[j * 64];
-    }
+  {
+    const int ct = wave;
     const float mbv = p.mb[ct * 16 + i16];
     f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
-    const float *arow = os + arow_g * TL_OS + koff2;
+    const float *arow = os + i16 * T2_OS + koff;
 #pragma unroll
     for (int k4 = 0; k4 < 24; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -370,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     }
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4)
-      if (4 * q + r4 < ROWS) ws[(4 * q + r4) * TL_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
+      ws[(4 * q + r4) * T2_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
   }
   __syncthreads();
 
@@ -384,18 +366,37 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
     bool inN[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) inN[i] = lane + 64 * i < N;
-    const float2 wv = *reinterpret_cast<const float2 *>(ws + g * TL_WS + 2 * lane);
-    if (DEFER) load_env(gi, b);  // in flight during the reduce-scatter
+    const float4 w0 = *reinterpret_cast<const float4 *>(ws + g * T2_WS + 4 * i16);
+    const float4 w1 = *reinterpret_cast<const float4 *>(ws + g * T2_WS + 64 + 4 * i16);
+    if (DEFER) load_env(gi, b);  // in flight during the logit sums
+    // e_n . w over the lane's eight columns, then over the 16 lanes of the row: lane c of row r
+    // ends up with node 4 (c + 16 k) + r of batch k; through LDS to lane = node
+    float *ug = us + g * T2_US;
+#pragma unroll
+    for (int k = 0; k < (KS + 15) / 16; ++k) {
+      float pv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int j = 16 * k + i;
+        if (j < KS) {
+          const float4 t0 = T[gi][j][0], t1 = T[gi][j][1];
+          float s = t0.x * w0.x;
+          s = fmaf(t0.y, w0.y, s); s = fmaf(t0.z, w0.z, s); s = fmaf(t0.w, w0.w, s);
+          s = fmaf(t1.x, w1.x, s); s = fmaf(t1.y, w1.y, s); s = fmaf(t1.z, w1.z, s);
+          pv[i] = fmaf(t1.w, w1.w, s);
+        } else {
+          pv[i] = 0.f;
+        }
+      }
+      const float tot = row_reduce_scatter16(pv, i16);
+      if (16 * k + i16 < KS) ug[4 * (16 * k + i16) + q] = tot;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): us of this graph is this wave's own
+    __builtin_amdgcn_wave_barrier();
     float u[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-      float pv[64];
-#pragma unroll
-      for (int k = 0; k < 64; ++k) {
-        const int n = 64 * i + k;
-        pv[k] = (n < NMAX) ? fmaf(wv.x, e[gi][n < NMAX ? n : 0].x, wv.y * e[gi][n < NMAX ? n : 0].y) : 0.f;
-      }
-      const float x = reduce_scatter64<64>(pv, lane);
+      const float x = (lane + 64 * i < NMAX) ? ug[lane + 64 * i] : 0.f;
       if (p.dbg == 4) { if (x == 123.f) p.curs[0] = x; continue; }
       u[i] = (inN[i] && !own_mask[gi][i]) ? 10.f * tanhf(x + cv[gi][i]) : -INFINITY;  // graph_decoder.py:97-98
       if (p.io.logits && inN[i]) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
@@ -521,11 +522,8 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       if (p.io.actions) p.io.actions[(size_t)p.t * B + b] = idx;
       if (p.io.step_logp) p.io.step_logp[(size_t)p.t * B + b] = logp;
     }
-    // (last: a register reload from scratch behind these stores would wait for them to land)
     // latency mode of the table kernel reads next step's row from `curs`: keep it current
-    // -- unless the host's schedule gives the next step to this kernel as well, which reads SL
-    // and base itself (the update costs 7 us per step at 2048 x 100: 3.2 KB of table row per
-    // graph from HBM, at the very end of the workgroup)
+    // -- unless the host's schedule gives the next step to this kernel as well
     if (B <= 2048 && !p.skip_curs &&
         !(p.t == 0 && p.kind != VRP_KIND_IRP)) {
       const size_t row = (size_t)b * 8 * N;
@@ -541,42 +539,28 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
   }
 }
 
-template <int NMAX, int GPW, int NW>
-static int launch_tile(const StepParams &p, hipStream_t st) {
-  constexpr int GPB = NW * GPW;
-  constexpr int ROWS = NW == 8 ? 16 : GPB;
-  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + ROWS * (TL_ZG + TL_OS + TL_WS));
+template <int NMAX, int GPW>
+static int launch_tile2(const StepParams &p, hipStream_t st) {
+  constexpr int GPB = 8 * GPW;
+  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + 16 * (T2_ZG + T2_OS + T2_WS) +
+                                      (size_t)GPB * T2_US);
   static VrpAttrOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_mfma_kernel<NMAX, GPW, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_zmfma_kernel<NMAX, GPW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      vrp_set_error("decode_step_tile: cannot raise dynamic LDS to %zu bytes", lds);
+      vrp_set_error("decode_step_tile2: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
     attr_set.mark();
   }
-  hipLaunchKernelGGL((decode_step_tile_mfma_kernel<NMAX, GPW, NW>), dim3((p.B + GPB - 1) / GPB),
-                     dim3(64 * NW), lds, st, p);
-  VRP_CHECK_LAUNCH("decode_step_tile_mfma");
+  hipLaunchKernelGGL((decode_step_tile_zmfma_kernel<NMAX, GPW>), dim3((p.B + GPB - 1) / GPB),
+                     dim3(512), lds, st, p);
+  VRP_CHECK_LAUNCH("decode_step_tile_zmfma");
   return 0;
 }
 
-bool vrp_tile_mfma_supported(int N) { return N <= 104; }
+bool vrp_tile2_supported(int N) { return N <= 100; }
 
-// VRP_TILE_WAVES=4: two 4-wave workgroups per CU instead of one of eight (A/B aid; measured
-// SLOWER -- 132 vs 72 us at 8192 x 40, 87 vs 55 us at 2048 x 100: with half the MFMA rows in
-// use the weight folds, which stream 384 KB of weights per workgroup from L2, cost twice as much)
-static int tile_waves() {
-  static const int v = getenv("VRP_TILE_WAVES") ? atoi(getenv("VRP_TILE_WAVES")) : 8;
-  return v;
-}
-
-int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st) {
-  // round 4: the tile in MFMA operand order, glimpse sums on the matrix cores (decoder_tile2.hip)
-  if (!tile_v1_forced() && vrp_tile2_supported(p.N)) return vrp_launch_tile2_step(p, st);
-  if (tile_waves() == 8)   // N <= 100 (configs[4]) has its own instance: 8 registers less of tile
-    return p.N <= 40    ? launch_tile<40, 2, 8>(p, st)
-           : p.N <= 100 ? launch_tile<100, 1, 8>(p, st)
-                        : launch_tile<104, 1, 8>(p, st);
-  return p.N <= 40 ? launch_tile<40, 2, 4>(p, st) : launch_tile<104, 1, 4>(p, st);
+int vrp_launch_tile2_step(const StepParams &p, hipStream_t st) {
+  return p.N <= 40 ? launch_tile2<40, 2>(p, st) : launch_tile2<100, 1>(p, st);
 }

@@ -93,7 +93,15 @@ struct DecWs {
 __host__ __device__ static inline int hist_rows(int N) { return 2 * N; }
 // shapes on which the default dispatch sends steps to the raw-tile kernel (decoder.hip,
 // hybrid_shape; IRP excepted there): they get the row-paired copy of the embeddings
+// Round 4: the second-generation tile kernel (decoder_tile2.hip, N <= 100) reads `emb` itself in
+// the matrix cores' operand order and needs no copy; only the first-generation kernel does
+// (100 < N <= 104, or everywhere with the A/B aid VRP_TILE_V1=1).
+static inline bool tile_v1_forced() {
+  static const bool v = getenv("VRP_TILE_V1") != nullptr;
+  return v;
+}
 static inline bool tile_pairs_shape(int B, int N) {
+  if (!tile_v1_forced()) return N > 100 && N <= 104;
   return (N > 64 && N <= 104) || (B > 2048 && N > 32 && N <= 40);
 }
 static inline size_t pairs_floats(int B, int N) {

@@ -130,6 +130,7 @@ def _declare(lib):
         "vrp_step_kernel_name": (C.c_char_p, [i32, i32, i32, i32]),
         "vrp_persistent_capacity": (i32, []),
         "vrp_encoder_kernel_name": (C.c_char_p, [P(EncoderWeights), i32, i32, i32]),
+        "vrp_source_hash": (C.c_char_p, []),
         "vrp_last_error": (C.c_char_p, []),
         "vrp_abi_version": (i32, []),
     }
