@@ -327,6 +327,18 @@ def _train_bounds(kind, B, N, o32):
     return tuple(2.0 * max(r, f) for r, f in zip(ref, _TRAIN_FLOORS))
 
 
+def _train_mean_bound(o32_mean):
+    """The MEAN logit error is a stable statistic (the maxima above are heavy-tailed: over the
+    sweep the reference's own maximum is 4.15x the oracle's once, <= 1.65x otherwise): a
+    systematic loss of accuracy shows here first.  Bound: 1.25 x the reference's mean error,
+    estimated from the fp32 oracle's mean on these inputs times the largest reference/oracle
+    ratio of means over the measured cases (~1.1)."""
+    st = _train_mode_statistics()
+    r = max(c["reference_fp32_vs_fp64"]["du_mean"] / c["oracle_fp32_vs_fp64"]["du_mean"]
+            for c in st["cases"] + st["sweep"] if c["oracle_fp32_vs_fp64"]["du_mean"] > 2e-7)
+    return 1.25 * r * max(o32_mean, 2e-7)
+
+
 def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_actions=None,
                      ref_loss=None, ref_logp=None, ref_T=None, train=False, tile_kernel=False,
                      throughput_kernel=False, table_kernel=False, agent=None, fused=False):
@@ -411,6 +423,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         LP64 = torch.stack([st["logp"] for st in trace64])
         fin64 = torch.isfinite(U64)
         assert torch.equal(fin64, torch.isfinite(U))
+        o32_mean = (U.double()[fin64] - U64[fin64]).abs().mean().item()
         o32 = ((U.double()[fin64] - U64[fin64]).abs().max().item(),
                (torch.stack([st["logp"] for st in forced_trace]).double() - LP64).abs().max().item(),
                (olp.double() - olp64).abs().max().item())
@@ -490,15 +503,21 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     # per-step logits along the same action path.  Logits live in [-10, 10].  Eval mode:
     # within 2e-5 of the fp32 oracle.  Train mode: within du_bound of the FP64 logits (twice
     # what the reference's own fp32 logits are off by, _train_bounds).
-    worst_du = 0.0
+    worst_du, sum_du, n_du = 0.0, 0.0, 0
     for t in range(0 if fused else T):
         u = res.logits[t].cpu()
         ou = trace64[t]["u"] if train else forced_trace[t]["u"]
         fin = torch.isfinite(ou)
         assert torch.equal(fin, torch.isfinite(u)), t
-        err = (u.to(ou.dtype)[fin] - ou[fin]).abs().max().item()
+        d = (u.to(ou.dtype)[fin] - ou[fin]).abs()
+        err = d.max().item()
         worst_du = max(worst_du, err)
+        sum_du += d.sum().item()
+        n_du += d.numel()
         assert err < (du_bound if train else 2e-5), (t, err, du_bound)
+    if train and n_du:
+        mean_bound = _train_mean_bound(o32_mean)
+        assert sum_du / n_du < mean_bound, (sum_du / n_du, mean_bound, o32_mean)
     worst_dl = 0.0
     if not greedy:
         # north_star: log-prob within 1e-5 -- held PER STEP (log p(a_t) of every sampled
@@ -516,7 +535,8 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     if train:
         _log_train(kind, B, N, greedy, T, tile_kernel, throughput_kernel, table_kernel, fused,
                    worst_du, du_bound, o32[0], worst_dl, dl_bound, o32[1],
-                   (logp.double() - olp64).abs().max().item(), acc_bound, o32[2])
+                   (logp.double() - olp64).abs().max().item(), acc_bound, o32[2],
+                   sum_du / max(n_du, 1), o32_mean)
     return res, exempt
 
 

@@ -684,7 +684,9 @@ extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
   const bool v2 = !tile_v1_forced() && vrp_tile2_supported(N);
-  const char *tile = v2 ? (N <= 40 ? "decode_step_tile_zmfma_kernel<40, 2>" : "decode_step_tile_zmfma_kernel<100, 1>")
+  const char *tile = v2 ? (kind == VRP_KIND_IRP
+                               ? (N <= 40 ? "decode_step_tile_zmfma_kernel<40, 2, true>" : "decode_step_tile_zmfma_kernel<100, 1, true>")
+                               : (N <= 40 ? "decode_step_tile_zmfma_kernel<40, 2, false>" : "decode_step_tile_zmfma_kernel<100, 1, false>"))
                         : N <= 40    ? "decode_step_tile_mfma_kernel<40, 2, 8>"
                           : N <= 100 ? "decode_step_tile_mfma_kernel<100, 1, 8>"
                                      : "decode_step_tile_mfma_kernel<104, 1, 8>";

@@ -32,6 +32,18 @@
 #define T2_OS 388   // os: floats per graph row (384 + 4)
 #define T2_WS 132   // ws: floats per graph row
 #define T2_US 128   // us: pointer-logit pre-activations of a graph, lane = node order
+#ifndef T2_PF
+#define T2_PF 2     // first weight fold, N > 64: k-steps of fragments requested ahead
+#endif
+#ifndef T2_PF2
+#define T2_PF2 4    // second weight fold, N > 64
+#endif
+#ifndef T2_KQ
+#define T2_KQ 8     // k-steps of the tile requested before the glimpse weights are computed
+#endif
+#ifndef T2_TILE_AUX
+#define T2_TILE_AUX 2  // cache policy of the tile loads: 2 = nt (once-read stream), 0 = default
+#endif
 
 #define T2_DPP_ADD(x, ctrl) ((x) + VRP_DPP(0.f, (x), (ctrl), 0xF))
 
@@ -61,14 +73,29 @@ __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], int 
   return keep + VRP_DPP(0.f, send, 0xB1, 0xF);      // quad_perm [1,0,3,2]
 }
 
-template <int NMAX, int GPW>
+typedef float t2_v4f __attribute__((vector_size(16)));
+
+// IRP: compile-time env kind split (IRP reads the load-dependent score row and the demands; as a
+// run-time test every one of those loads sat behind a branch of its own).  NT: nontemporal tile
+// loads (tools/micro/stream_rate.hip: a once-read stream of this geometry moves 6.4-6.5 TB/s with
+// `nt`, 6.0 without).
+template <int NMAX, int GPW, bool IRP>
 __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepParams p) {
   constexpr int NW = 8;
   constexpr int KS = NMAX / 4;             // k-steps of four nodes
   constexpr int NPL = (NMAX + 63) / 64;
   constexpr int GPB = NW * GPW;            // graphs per workgroup (<= 16 = rows of one MFMA tile)
-  constexpr int ROWS = 16;
-  static_assert(NMAX % 4 == 0 && GPB <= 16, "tile shape");
+  constexpr int ROWS = GPB;                // rows of the LDS operand images (8 or 16: MFMA rows
+                                           // beyond the workgroup's graphs repeat them)
+  // Two nodes per lane (N > 64): 25 k-steps are 200 registers, and with the 32 accumulators of the
+  // glimpse sums the allocator spills tile registers -- each reload a scratch load, the youngest
+  // entry of the in-order vmcnt queue, whose wait drains every tile load in flight.  The last
+  // KL k-steps therefore live in LDS (2 KB per graph and k-step, in lane order: the image IS the
+  // register layout); they are requested FIRST, land with the score rows and are written to LDS
+  // before the bulk of the tile is requested.
+  constexpr int KL = NMAX > 64 ? 2 : 0;    // k-steps held in LDS
+  constexpr int KR = KS - KL;              // k-steps held in registers
+  static_assert(NMAX % 4 == 0 && GPB <= 16 && (ROWS & (ROWS - 1)) == 0, "tile shape");
   if (!p.decode_only && p.t > 0 && p.io.notdone[p.t - 1] == 0) return;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
   float *os = zs + ROWS * T2_ZG;          // [ROWS][T2_OS]  o[g][384]
   float *ws = os + ROWS * T2_OS;          // [ROWS][T2_WS]  w[g][128]
   float *us = ws + ROWS * T2_WS;          // [GPB][T2_US]
+  float4 *tl = reinterpret_cast<float4 *>(us + GPB * T2_US);   // [GPB][KL][2][64] tile k-steps in LDS
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
   const int i16 = lane & 15, q = lane >> 4;   // (c, r) of the header comment
 
   // ---- per-graph state kept across the matrix phase ---------------------------------------
-  float4 T[GPW][KS][2];
+  float4 T[GPW][KR > 0 ? KR : 1][2];
   int own_mask[GPW][NPL], vis[GPW][NPL];
   double2 xy[GPW][NPL];
   double dem[GPW][NPL];
@@ -112,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       if (!p.decode_only) {
         xy[gi][i] = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + l];
         if (in) vis[gi][i] = p.env.visited[(size_t)b * N + l];
-        if (p.kind == VRP_KIND_IRP) dem[gi][i] = p.env.demand[(size_t)b * N + l];
+        if (IRP) dem[gi][i] = p.env.demand[(size_t)b * N + l];
       }
       q_noise[gi][i] = !p.sample ? 1.f
                        : p.io.noise ? p.io.noise[((size_t)p.t * B + b) * N + l]
@@ -154,10 +182,14 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
 #pragma unroll
     for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
     if (!proc[gi]) continue;  // wave-uniform
-    // ---- loads.  Order matters (they return in order): the score rows and masks first, then
-    // the first half of the tile; the glimpse weights are computed while it streams in, the
-    // second half is requested behind them and the MFMAs below consume k-steps as they land.
-    constexpr int KH = (KS + 1) / 2;
+    // ---- loads.  Order matters: they return in order, and so does every wait.  (1) the score
+    // rows and masks the glimpse weights need; (2) the first k-steps of the tile, enough to keep
+    // the memory pipe busy while the weights are computed; (3) -- behind the weights -- the
+    // rest, which the MFMAs below consume k-step by k-step as it lands.  sched_barriers pin the
+    // three groups: left alone the compiler sinks score loads behind tile loads, and the wait for
+    // them drains the tile (round 4 first cut: the whole first half landed before the softmax
+    // started, 25 us of loads for 17 us worth of bytes).
+    constexpr int KQ = KR < T2_KQ ? KR : T2_KQ;
     const size_t row = (size_t)b * 8 * N;
     const float *srow = p.row0 + row;
     if (p.t > 0) {
@@ -165,7 +197,25 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       srow = p.SL + ((size_t)b * N + last) * 8 * N;
     }
     const bool add_base = p.base && p.t > 0;
-    load0[gi] = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+    load0[gi] = IRP ? p.env.load[b] : 1.0;
+    // the tile, in MFMA operand order: k-step j, half hf = rows 4j..4j+3, 256 bytes of each.
+    // Buffer loads: the descriptor covers exactly this graph's N rows, a row beyond N reads as
+    // zeros (no predicate, no zero-fill, one scalar offset per k-step)
+    const __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.emb + (size_t)b * N * VRP_EMB), 0, N * VRP_EMB * 4, 0x00020000);
+    const int tile_voff = q * (VRP_EMB * 4) + i16 * 16;
+    auto tile_load = [&](int j, int hf) {
+      // (whole-vector bit cast: __builtin_bit_cast of ONE element of a vector value reads
+      // element 0 whatever the element named -- hipcc 7.2)
+      const t2_v4f v = __builtin_bit_cast(t2_v4f, __builtin_amdgcn_raw_buffer_load_b128(
+          tile_rsrc, tile_voff + 256 * hf, j * (4 * VRP_EMB * 4), T2_TILE_AUX));
+      return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    float4 tlv[KL > 0 ? KL : 1][2];
+#pragma unroll
+    for (int j = 0; j < KL; ++j)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) tlv[j][hf] = tile_load(KR + j, hf);
     float sv[NPL][8], bv_[NPL][8], sl_[NPL][8];
     int mo[NPL][8];
 #pragma unroll
@@ -174,21 +224,16 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       for (int h = 0; h < 8; ++h) {
         sv[i][h] = srow[h * N + ln[i]];
         bv_[i][h] = add_base ? p.base[row + h * N + ln[i]] : 0.f;
-        sl_[i][h] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + h * N + ln[i]] : 0.f;
+        sl_[i][h] = IRP ? p.SLD[row + h * N + ln[i]] : 0.f;
         mo[i][h] = mask_in[(size_t)((b * 8 + h) % B) * N + ln[i]];  // QUIRK D3: other graphs
       }
-    // the tile, in MFMA operand order: k-step j, half hf = rows 4j..4j+3, 256 bytes of each
-    const float4 *src = reinterpret_cast<const float4 *>(p.emb + (size_t)b * N * VRP_EMB) +
-                        (size_t)q * (VRP_EMB / 4) + i16;
+    __builtin_amdgcn_sched_barrier(0);
     auto load_kstep = [&](int j) {
-      const bool in = 4 * j + q < N;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-        T[gi][j][hf] = in ? src[(size_t)j * (4 * VRP_EMB / 4) + 16 * hf]
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int hf = 0; hf < 2; ++hf) T[gi][j][hf] = tile_load(j, hf);
     };
 #pragma unroll
-    for (int j = 0; j < KH; ++j) load_kstep(j);
+    for (int j = 0; j < KQ; ++j) load_kstep(j);
     __builtin_amdgcn_sched_barrier(0);
     float sc[NPL][8];  // score + additive scrambled mask
 #pragma unroll
@@ -197,10 +242,16 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       for (int h = 0; h < 8; ++h) {
         float v = sv[i][h];
         if (add_base) v += bv_[i][h];
-        if (p.kind == VRP_KIND_IRP) v = fmaf((float)load0[gi], sl_[i][h], v);
+        if (IRP) v = fmaf((float)load0[gi], sl_[i][h], v);
         sc[i][h] = v + (float)mo[i][h];
       }
     }
+    // (the LDS k-steps were requested before the score rows: they have landed with them)
+    float4 *tlg = tl + (size_t)g * KL * 128 + lane;
+#pragma unroll
+    for (int j = 0; j < KL; ++j)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) tlg[(2 * j + hf) * 64] = tlv[j][hf];
     if (!DEFER) load_env(gi, b);
     if (p.dbg == 1) { if (T[gi][0][0].x + sc[0][0] == 123.f) p.curs[0] = 1.f; continue; }
 
@@ -241,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       }
     }
 #pragma unroll
-    for (int j = KH; j < KS; ++j) load_kstep(j);
+    for (int j = KQ; j < KR; ++j) load_kstep(j);
     __builtin_amdgcn_sched_barrier(0);
     // a_s of this graph is written and read by this wave only: LDS ops of one wave are ordered
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
@@ -262,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
         if (j + 1 < KS) an = ap[(j + 1) * 32];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const float4 t = T[gi][j][hf];
+          const float4 t = j < KR ? T[gi][j < KR ? j : 0][hf] : tlg[(2 * (j - KR) + hf) * 64];
           zacc[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.x, zacc[hf][0], 0, 0, 0);
           zacc[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.y, zacc[hf][1], 0, 0, 0);
           zacc[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, t.z, zacc[hf][2], 0, 0, 0);
@@ -287,8 +338,12 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
   // ---- matrix phase: o = Wv z + bv (wave = head), then w = M o + mb (wave = 16 columns) ----
   // (decoder_tile.hip: fragments of the folded weights in MFMA order from L2, requested PF
   // k-steps ahead; inner dimensions spread over the lane groups as k = 16 S + 4 q + e)
-  constexpr int PF = 3;
-  constexpr int PF2 = NMAX > 64 ? 5 : 8;
+  // (N > 64: the tile alone holds 200 of the 256 registers; one fragment set less in flight than
+  // decoder_tile.hip keeps the kernel free of spills -- a spilled tile register is reloaded by a
+  // scratch load, the youngest entry of the in-order vmcnt queue, and the wait for it drains
+  // every tile load in flight)
+  constexpr int PF = NMAX > 64 ? T2_PF : 3;
+  constexpr int PF2 = NMAX > 64 ? T2_PF2 : 8;
   const int koff = 4 * q;
   float4 mw[PF2];
   {
@@ -305,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       const float bb = p.bv[h * VRP_HD + 16 * c + i16];  // D column = lane & 15
       acc[c] = f32x4{bb, bb, bb, bb};
     }
-    const float *arow = zs + i16 * T2_ZG + h * 128 + koff;   // A row = graph
+    const float *arow = zs + (i16 & (ROWS - 1)) * T2_ZG + h * 128 + koff;   // A row = graph
 #pragma unroll
     for (int k4 = 0; k4 < 8; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)  // D: row = graph 4q + r4, column = lane & 15
-        os[(4 * q + r4) * T2_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
+        if (4 * q + r4 < ROWS) os[(4 * q + r4) * T2_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
   }
   const float4 *mrow = reinterpret_cast<const float4 *>(p.MP) + (size_t)wave * 24 * 64 + lane;
 #pragma unroll
@@ -338,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     const int ct = wave;
     const float mbv = p.mb[ct * 16 + i16];
     f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: k4 even / odd
-    const float *arow = os + i16 * T2_OS + koff;
+    const float *arow = os + (i16 & (ROWS - 1)) * T2_OS + koff;
 #pragma unroll
     for (int k4 = 0; k4 < 24; ++k4) {
       const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
@@ -352,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     }
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4)
-      ws[(4 * q + r4) * T2_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
+      if (4 * q + r4 < ROWS) ws[(4 * q + r4) * T2_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
   }
   __syncthreads();
 
@@ -366,9 +421,9 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     bool inN[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) inN[i] = lane + 64 * i < N;
+    const float4 *tlg = tl + (size_t)g * KL * 128 + lane;
     const float4 w0 = *reinterpret_cast<const float4 *>(ws + g * T2_WS + 4 * i16);
     const float4 w1 = *reinterpret_cast<const float4 *>(ws + g * T2_WS + 64 + 4 * i16);
-    if (DEFER) load_env(gi, b);  // in flight during the logit sums
     // e_n . w over the lane's eight columns, then over the 16 lanes of the row: lane c of row r
     // ends up with node 4 (c + 16 k) + r of batch k; through LDS to lane = node
     float *ug = us + g * T2_US;
@@ -379,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       for (int i = 0; i < 16; ++i) {
         const int j = 16 * k + i;
         if (j < KS) {
-          const float4 t0 = T[gi][j][0], t1 = T[gi][j][1];
+          const float4 t0 = j < KR ? T[gi][j < KR ? j : 0][0] : tlg[(2 * (j - KR)) * 64];
+          const float4 t1 = j < KR ? T[gi][j < KR ? j : 0][1] : tlg[(2 * (j - KR) + 1) * 64];
           float s = t0.x * w0.x;
           s = fmaf(t0.y, w0.y, s); s = fmaf(t0.z, w0.z, s); s = fmaf(t0.w, w0.w, s);
           s = fmaf(t1.x, w1.x, s); s = fmaf(t1.y, w1.y, s); s = fmaf(t1.z, w1.z, s);
@@ -390,6 +446,10 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
       }
       const float tot = row_reduce_scatter16(pv, i16);
       if (16 * k + i16 < KS) ug[4 * (16 * k + i16) + q] = tot;
+      // the env row / noise / accumulators of a two-nodes-per-lane graph: requested once the
+      // first sixteen k-steps of the tile are dead (their registers are what these land in),
+      // in flight during the second batch of logit sums
+      if (DEFER && k == 0) load_env(gi, b);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): us of this graph is this wave's own
     __builtin_amdgcn_wave_barrier();
@@ -480,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     const double dy = node_f64(py, cu) - node_f64(py, idx);
     const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
     double load = 1.0;
-    if (p.kind == VRP_KIND_IRP) {                               // irp.py:80-86
+    if (IRP) {                                                  // irp.py:80-86
       load = load0[gi] - node_f64(dm, idx);
       if (idx == de) load = 1.0;
     }
@@ -505,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       int mk = vs[i];
-      if (p.kind == VRP_KIND_IRP && inN[i] && dm[i] - load > 0.0) mk = 1;  // irp.py:151-153
+      if (IRP && inN[i] && dm[i] - load > 0.0) mk = 1;            // irp.py:151-153
       if (inN[i]) {
         p.env.visited[(size_t)b * N + lane + 64 * i] = (uint8_t)vs[i];
         mask_out[(size_t)b * N + lane + 64 * i] = (uint8_t)mk;
@@ -513,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     }
     if (lane == 0) {
       p.env.cur[b] = idx;
-      if (p.kind == VRP_KIND_IRP) p.env.load[b] = load;
+      if (IRP) p.env.load[b] = load;
       p.io.acc_loss[b] = accl[gi] + (float)(-dist);  // fp32 accumulate in step order, tsp_agent:85
       p.io.acc_logp[b] = accp[gi] + logp;
       p.last[b] = idx;
@@ -539,21 +599,22 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
   }
 }
 
-template <int NMAX, int GPW>
+template <int NMAX, int GPW, bool IRP>
 static int launch_tile2(const StepParams &p, hipStream_t st) {
   constexpr int GPB = 8 * GPW;
-  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + 16 * (T2_ZG + T2_OS + T2_WS) +
-                                      (size_t)GPB * T2_US);
+  constexpr int KL = NMAX > 64 ? 2 : 0;
+  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + GPB * (T2_ZG + T2_OS + T2_WS) +
+                                      (size_t)GPB * T2_US + (size_t)GPB * KL * 512);
   static VrpAttrOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_zmfma_kernel<NMAX, GPW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_step_tile_zmfma_kernel<NMAX, GPW, IRP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("decode_step_tile2: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
     attr_set.mark();
   }
-  hipLaunchKernelGGL((decode_step_tile_zmfma_kernel<NMAX, GPW>), dim3((p.B + GPB - 1) / GPB),
+  hipLaunchKernelGGL((decode_step_tile_zmfma_kernel<NMAX, GPW, IRP>), dim3((p.B + GPB - 1) / GPB),
                      dim3(512), lds, st, p);
   VRP_CHECK_LAUNCH("decode_step_tile_zmfma");
   return 0;
@@ -562,5 +623,7 @@ static int launch_tile2(const StepParams &p, hipStream_t st) {
 bool vrp_tile2_supported(int N) { return N <= 100; }
 
 int vrp_launch_tile2_step(const StepParams &p, hipStream_t st) {
-  return p.N <= 40 ? launch_tile2<40, 2>(p, st) : launch_tile2<100, 1>(p, st);
+  if (p.kind == VRP_KIND_IRP)
+    return p.N <= 40 ? launch_tile2<40, 2, true>(p, st) : launch_tile2<100, 1, true>(p, st);
+  return p.N <= 40 ? launch_tile2<40, 2, false>(p, st) : launch_tile2<100, 1, false>(p, st);
 }
