@@ -29,7 +29,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
                       fractions on the same algorithmic bytes
   roofline_north_star the same at 8192 x 40 TSP (the north-star target shape);
   roofline_north_star_vrp / roofline_cfg5: VRP 8192 x 40 greedy, VRP 2048 x 100 sampling
-  other_configs       short runs of the training / sampling configs (ms per step)
+  other_configs       short runs of the training / sampling configs (ms per step; the training
+                      ones carry roofline_train: algorithmic flops per epoch vs the fp32 MFMA peak)
   cpu_baseline        the CPU oracle (oracle/, a port of the reference) on this host
 """
 import argparse
@@ -221,7 +222,12 @@ def timed_training(env, agent, steps, warmup, dist):
     runtime.ROLLOUT_LOG = distributed.ALLREDUCE_EVENTS = None
     sum_T = sum(r.T for r in log)  # env steps per graph over every rollout of the timed epochs
     ar_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)
-    return dt, sum_T, len(log) // max(steps, 1), float(-cost.item()), ar_ms
+    # an epoch's rollouts in order: sampled model, sampled baseline, greedy model, greedy baseline
+    per = max(len(log) // max(steps, 1), 1)
+    Ts = [r.T for r in log]
+    t_sampled = float(np.mean([t for i, t in enumerate(Ts) if i % per < 2])) if Ts else 0.0
+    t_greedy = float(np.mean([t for i, t in enumerate(Ts) if i % per >= 2])) if per > 2 else t_sampled
+    return dt, sum_T, per, float(-cost.item()), ar_ms, (t_sampled, t_greedy)
 
 
 def _event():
@@ -416,6 +422,63 @@ def encoder_roofline(kind, N, B, device, reps=20):
             "launches_timed": reps}
 
 
+def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
+    """Algorithmic fp32 flops of one REINFORCE epoch (TSPAgent.train's loop body,
+    graph_tsp_agent.py:174-189 + baseline_update :275-306), per GPU:
+
+      encoder forward  x4   model (train mode, taped) + baseline for the sampled pair, model +
+                            baseline for the greedy pair: B N (1 180 160 + 1 536 N) each
+                            (projections, attention, feed-forward of 3 layers)
+      encoder backward x1   2x a forward (input- and weight-gradient products)
+      prologue         x4   per-episode decoder tables: B N 2 (4*384*128 + 2*8*48 N)
+      decode steps          sum over the four rollouts of B T (196 608 + 4 352 N)
+      decoder backward x1   the T sampled steps re-run un-folded (graph_decoder.py:75-107):
+                            forward = B T (2*384*384 [query] + 2*2*8*48 N [scores, values] +
+                            2*384*384 [out_proj] + 2*128*384 [_att_output] + 2*128 N [logits])
+                            + B N 2*128*(384+384+128) [K, V, _kp projections]; backward = 2x that,
+                            plus the forward recompute = 3x
+    Adam, the t-test and BatchNorm reductions are not matrix work and are left out."""
+    enc = B * N * (1180160 + 1536 * N)
+    pro = B * N * 2 * (4 * 384 * 128 + 2 * 8 * 48 * N)
+    steps = B * (2 * T_sampled + 2 * T_greedy) * (196608 + 4352 * N)
+    dec_fwd = (B * T_sampled * (2 * 384 * 384 + 2 * 2 * 8 * 48 * N + 2 * 384 * 384 + 2 * 128 * 384
+                                + 2 * 128 * N) + B * N * 2 * 128 * (384 + 384 + 128))
+    parts = {"encoder_forward_x4": 4 * enc, "encoder_backward": 2 * enc, "prologue_x4": 4 * pro,
+             "decode_steps": steps, "decoder_backward": 3 * dec_fwd}
+    return sum(parts.values()), parts
+
+
+def gemm_kernel_roofline(device, M=81920, N=384, K=128, reps=20):
+    """The training path's most frequent tall GEMM (the train-mode in_proj of VRP-40 x 2048:
+    M = B N rows, bias only; vrp_gemm_nt -> gemm_rows_kernel) timed with HIP events."""
+    import vrpgym_hip as hip
+    lib = hip.lib()
+    A = torch.randn(M, K, device=device)
+    W = torch.randn(N, K, device=device) * 0.1
+    b = torch.randn(N, device=device)
+    C = torch.empty(M, N, device=device)
+    st = hip.current_stream(device)
+
+    def run():
+        hip.check(lib.vrp_gemm_nt(A.data_ptr(), K, W.data_ptr(), K, b.data_ptr(), None, 0,
+                                  C.data_ptr(), N, M, N, K, 0, st))
+    for _ in range(3):
+        run()
+    e0, e1 = _event(), _event()
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    tf = 2.0 * M * N * K / us / 1e6
+    return {"kernel": "gemm_rows_kernel<5>", "shape": [M, N, K], "avg_launch_us": round(us, 2),
+            "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "hbm_bytes": 4 * (M * K + M * N + N * K),
+            "hbm_frac_at_this_time": round(4 * (M * K + M * N + N * K) / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+
 def device_identity(device):
     """What tells two GPUs apart: uuid / PCI bus id where torch exposes them."""
     p = torch.cuda.get_device_properties(device)
@@ -479,7 +542,7 @@ def run_workload(name, steps, warmup, device, dist, rank, world, blocks=1):
         from agents import distributed
         distributed.broadcast_model(agent.model)
         distributed.broadcast_model(agent.target_model)
-        dt, sum_T, rollouts, cost, ar_ms = timed_training(env, agent, steps, warmup, dist)
+        dt, sum_T, rollouts, cost, ar_ms, (t_s, t_g) = timed_training(env, agent, steps, warmup, dist)
         dts = [dt]
         graph_steps = sum_T * B
         node_steps = graph_steps * N
@@ -487,6 +550,18 @@ def run_workload(name, steps, warmup, device, dist, rank, world, blocks=1):
         extra = {"rollouts_per_step": rollouts, "allreduce_ms_per_step": round(ar_ms, 4),
                  "grad_bucket_bytes": 4 * sum(p.numel() for p in agent.model.parameters()
                                               if p.grad is not None)}
+        flops, parts = training_flops_per_epoch(kind, N, B, t_s, t_g)
+        tf = flops / (dt / steps) / 1e12
+        extra["roofline_train"] = {
+            "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "algorithmic_gflop_per_epoch": round(flops / 1e9, 2),
+            "gflop_by_part": {k: round(v / 1e9, 2) for k, v in parts.items()},
+            "steps_per_rollout": {"sampled": round(t_s, 1), "greedy": round(t_g, 1)},
+            "ms_per_epoch": round(dt / steps * 1e3, 3),
+            "note": "whole epoch (rollouts incl. their HBM-bound decode loops, backward, Adam, "
+                    "t-test) against the fp32 matrix peak; flop model: "
+                    "bench.training_flops_per_epoch"}
     else:
         dts, T, cost = timed_rollouts(env, agent, mode == "greedy", steps, warmup, dist,
                                       blocks=blocks)
@@ -622,6 +697,9 @@ def main():
     if mode == "train":
         out["training"] = {k: r[k] for k in ("rollouts_per_step", "allreduce_ms_per_step",
                                              "grad_bucket_bytes")}
+        out["roofline"] = r["roofline_train"]
+        if rank == 0:
+            out["roofline"]["dominant_kernel"] = gemm_kernel_roofline(device, B * N, 384, 128)
 
     # ---- short runs of the other BASELINE configs (bounded; failures are reported, not fatal)
     if not a.no_extras and a.workload == "tsp20_b512":

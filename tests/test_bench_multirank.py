@@ -18,6 +18,20 @@ def _bench(args, extra_env=None, timeout=900):
     env.update(extra_env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    if p.returncode != 0:
+        # the tail of a torchrun failure is its summary table; keep the whole stream where a
+        # gpurun call brings it back, and put the lines that name the cause in front
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            tag = "_".join(a.strip("-") for a in args)[:80]
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_stderr_{tag}.log"), "w") as fh:
+                fh.write(p.stderr)
+        except OSError:
+            pass
+        cause = [l for l in p.stderr.splitlines()
+                 if any(k in l for k in ("Error", "error", "HSA", "hip", "abort", "what():", "Assert"))
+                 and "ChildFailedError" not in l][:30]
+        p.stderr = "\n".join(cause) + "\n...\n" + p.stderr
     return p
 
 
@@ -43,7 +57,7 @@ def test_bench_refuses_more_ranks_than_gpus():
 def test_bench_spawns_two_ranks_rollout():
     p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                 "--no-north-star", "--no-extras"], {"VRPGYM_BENCH_ONE_GPU": "1"})
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["one_gpu_test_mode"] is True
     assert out["backend"] == "gloo" and out["rccl_ranks"] == 0 and len(out["devices"]) == 2
@@ -63,7 +77,7 @@ def test_bench_sharded_training_two_ranks():
     """configs[3]'s per-GPU shard with the all-reduce, t-test gather and buffer averaging."""
     p = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                 "--workload", "irp40_b1024_train"], {"VRPGYM_BENCH_ONE_GPU": "1"})
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048
     tr = out["training"]
@@ -83,7 +97,7 @@ def test_bench_eight_ranks_one_gpu(workload):
     args = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
             "--no-north-star", "--no-extras", "--workload", workload]
     p = _bench(args, {"VRPGYM_BENCH_ONE_GPU": "1"}, timeout=1500)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 8 and out["one_gpu_test_mode"] is True
     assert out["backend"] == "gloo" and len(out["devices"]) == 8
@@ -135,7 +149,7 @@ def test_bench_two_ranks_over_rccl(workload):
     env = {k: v for k, v in os.environ.items() if k != "VRPGYM_BENCH_ONE_GPU"}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"].startswith("nccl")
     assert "one_gpu_test_mode" not in out
@@ -150,7 +164,7 @@ def test_bench_two_ranks_over_rccl(workload):
 @pytest.mark.gpu
 def test_bench_single_rank_line_has_contract_keys():
     p = _bench(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-north-star"])
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
