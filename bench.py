@@ -302,7 +302,7 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
         return [round(float(np.mean(pairs[t::T])) * 1e6, 2) for t in range(T)]
 
     name = lib.vrp_step_kernel_name(kind, B, N, sflags)
-    fused = name == b"decode_persistent_kernel"
+    fused = b"persistent" in name   # steps 1 .. T-1 run as ONE launch
     kern = []
     for _ in range(reps):
         cenv = start_episode()

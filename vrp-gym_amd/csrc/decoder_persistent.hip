@@ -491,6 +491,16 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
   return cus * (per_cu > 1 ? per_cu - 1 : 0);
 }
 
+// compute units a launch can use on the current device (the census' first half); 0 if unknown
+int vrp_usable_cus() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  (void)persistent_capacity_of(dev, nullptr);
+  if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
+  return g_pdev[dev].cus;
+}
+
 extern "C" int vrp_persistent_capacity(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }

@@ -90,7 +90,10 @@ struct DecWs {
 // the fused projection+table prologue packs <= 80 rows (five 16-row tiles) per wave when
 // N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
 #define VRP_FUSED_MAX_N 80
-__host__ __device__ static inline int hist_rows(int N) { return 2 * N; }
+// rows of the hand-off words (one row = one 8-byte word per graph): a step's mask is one word
+// up to 63 nodes (decoder_persistent.hip), two above (the tile-resident kernel of decoder_tile2.hip),
+// for up to 2N steps (max_steps + 1 <= 2N)
+__host__ __device__ static inline int hist_rows(int N) { return N > 63 ? 4 * N : 2 * N; }
 // shapes on which the default dispatch sends steps to the raw-tile kernel (decoder.hip,
 // hybrid_shape; IRP excepted there): they get the row-paired copy of the embeddings
 // Round 4: the second-generation tile kernel (decoder_tile2.hip, N <= 100) reads `emb` itself in

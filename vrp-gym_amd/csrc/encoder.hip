@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void qa8_load_w(float (&w)[3][32], const float *__res
 template <int NTMAX, bool ALIAS = false, typename Pre = NoPre, int KL = VRP_KLAYOUT>
 __device__ __forceinline__ void qa8_project(const float *X_s, float *Q_s, const float (&w)[3][32],
                                             const float *__restrict__ bin, int lane, int wave,
-                                            Pre pre = Pre()) {
+                                            Pre pre = Pre(), int vrows = 1 << 30) {
   const int i16 = lane & 15, q = lane >> 4;
   f32x4q acc[NTMAX][3];
 #pragma unroll
@@ -1130,7 +1130,8 @@ __device__ __forceinline__ void qa8_project(const float *X_s, float *Q_s, const 
     for (int rt = 0; rt < NTMAX; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)  // D: row = 4*(lane>>4) + r, col = lane & 15
-        Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb[ct];
+        if (rt * 16 + 4 * q + r < vrows)   // (rows beyond the buffer: the one-graph large-N kernel)
+          Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][ct][r] + bb[ct];
   }
 }
 
@@ -1739,32 +1740,38 @@ __device__ __forceinline__ float att_exp(float x) {
   const float e = __builtin_amdgcn_exp2f(t);
   return fmaf(e, r * 0.693147180559945f, e);
 }
-template <int NT>
-__global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float *__restrict__ qkv,
-                                                                      float *__restrict__ att, int N) {
-  const int lane = threadIdx.x & 63;
-  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// one graph, head h: `base` = its q|k|v rows (global memory or LDS), LD floats apart.
+// HOLD: the head's K and V fragments sit in registers for the whole graph (global memory: loaded
+// once); !HOLD (LDS image): they are read again for every query tile -- 56 registers less.
+template <int NT, int LD, bool HOLD>
+__device__ __forceinline__ void attention_rows_mfma(const float *base, float *__restrict__ out,
+                                                    int N, int lane, int h) {
   const int i16 = lane & 15, q = lane >> 4;
-  const float *base = qkv + (size_t)blockIdx.x * N * 384;
-  float *out = att + (size_t)blockIdx.x * N * VRP_EMB;
   float4 kf[NT];
   float vv[NT][4];
+  auto load_kv = [&]() {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    kf[t] = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * t + i16, N - 1) * 384 + 128 + h * 16 + 4 * q);
+    for (int t = 0; t < NT; ++t) {
+      kf[t] = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * t + i16, N - 1) * LD + 128 + h * 16 + 4 * q);
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4)
-      vv[t][r4] = base[(size_t)min(16 * t + 4 * q + r4, N - 1) * 384 + 256 + h * 16 + i16];
-  }
+      for (int r4 = 0; r4 < 4; ++r4)
+        vv[t][r4] = base[(size_t)min(16 * t + 4 * q + r4, N - 1) * LD + 256 + h * 16 + i16];
+    }
+  };
+  if (HOLD) load_kv();
   // the query rows of tile tm + 1 are requested before tile tm is worked on (a round trip per
   // tile in front of its first MFMA otherwise)
-  float4 a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(i16, N - 1) * 384 + h * 16 + 4 * q);
+  float4 a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(i16, N - 1) * LD + h * 16 + 4 * q);
 #pragma unroll
   for (int tm = 0; tm < NT; ++tm) {
     if (16 * tm >= N) break;
+    if (!HOLD) {
+      asm volatile("" ::: "memory");   // (no hoisting of the seven tiles' reads out of the loop)
+      load_kv();
+    }
     const float4 a = a_next;
     if (tm + 1 < NT)
-      a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * (tm + 1) + i16, N - 1) * 384 + h * 16 + 4 * q);
+      a_next = *reinterpret_cast<const float4 *>(base + (size_t)min(16 * (tm + 1) + i16, N - 1) * LD + h * 16 + 4 * q);
     const float4 qf = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
     f32x4v st[NT];  // st[tn][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
 #pragma unroll
@@ -1813,6 +1820,15 @@ __global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float
                       (o0[3] + o1[3]) * inv);
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void encoder_attention_mfma_kernel(const float *__restrict__ qkv,
+                                                                      float *__restrict__ att, int N) {
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  attention_rows_mfma<NT, 384, true>(qkv + (size_t)blockIdx.x * N * 384,
+                               att + (size_t)blockIdx.x * N * VRP_EMB, N, lane, h);
 }
 
 static int launch_attention_mfma(const float *qkv, float *att, int B, int N, hipStream_t st) {
@@ -1906,6 +1922,99 @@ static int launch_qkv_attn8(const float *x, const float *Win, const float *bin, 
                      lds, st, x, Win, bin, att, B, N, G, ntiles);
   VRP_CHECK_LAUNCH("encoder_qkv_attn8");
   return 0;
+}
+
+// ---- the same for ONE graph of 64 < N <= 102 nodes per workgroup pass (eval mode) -----------
+// Round 4.  At N = 100 (configs[4]) the 80-row kernel above has no whole graph to put into its
+// five row tiles, so the layer ran the projection as a GEMM (q|k|v written: 315 MB at 2048 x 100)
+// and encoder_attention_mfma_kernel read it back: 229 + 181 us per layer.  A graph's q|k|v is
+// N x 384 floats: with rows of 388 that is 155 KB at N = 100 -- it fits the 160 KB of LDS if the
+// input tile does not need a place of its own at the same time.  Layout: Q_s = rows 0 .. N-1 of
+// q|k|v from offset 0; the (<= 112 x 132) input tile X_s from the offset of Q_s row 64.  The
+// projection runs in two row halves: rows 0..63 (four tiles) read X_s rows 0..63 and write Q_s
+// rows 0..63 -- below X_s, no overlap --, then rows 64.. read the rest of X_s, every wave passes
+// a barrier, and their q|k|v rows go where X_s was.  Attention = the large-N routine
+// (attention_rows_mfma: query tiles outermost, one row of score tiles live) on the LDS image.
+// Persistent workgroups (grid = CUs): weight fragments stay in registers, the next graph's rows
+// are requested while the current one is in the matrix cores.
+template <int NT>
+__global__ __launch_bounds__(512) void encoder_qkv_attn_graph_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ Win,
+                                                                      const float *__restrict__ bin,
+                                                                      float *__restrict__ att, int B,
+                                                                      int N) {
+  constexpr int RTW = 16 * NT, PF = RTW * 32 / 512;
+  static_assert(NT >= 5 && NT <= 7, "64 < N <= 102");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Q_s = smem;
+  float *X_s = smem + 64 * QA_QLD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float w[3][32];
+  qa8_load_w<0>(w, Win, lane, wave);
+  float4 pf[PF];
+  auto fetch = [&](int g) {
+    const size_t row0 = (size_t)g * N;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < N) pf[u] = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+    }
+  };
+  int g = blockIdx.x;
+  if (g < B) fetch(g);
+  for (; g < B; g += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = pf[u];   // rows >= N: zeros
+    }
+    __syncthreads();
+    qa8_project<4, false, NoPre, 0>(X_s, Q_s, w, bin, lane, wave);
+    qa8_project<NT - 4, true, NoPre, 0>(X_s + 64 * QA_XLD, Q_s + 64 * QA_QLD, w, bin, lane, wave,
+                                        NoPre(), N - 64);
+    __syncthreads();
+    // (requested here, not ahead of the projection: its accumulators and these 4 PF registers do
+    // not fit side by side; the attention phase is long enough to cover the round trip)
+    if (g + (int)gridDim.x < B) fetch(g + gridDim.x);
+    attention_rows_mfma<NT, QA_QLD, false>(Q_s, att + (size_t)g * N * VRP_EMB, N, lane, wave);
+    __syncthreads();   // everybody done with Q_s before the next graph lands in X_s
+  }
+}
+
+static int launch_qkv_attn_graph(const float *x, const float *Win, const float *bin, float *att,
+                                 int B, int N, hipStream_t st) {
+  const int NT = (N + 15) / 16;
+  // Q_s rows 0..N-1, or X_s (16 NT rows of 132 floats) behind Q_s row 64 -- whichever ends later
+  const size_t fl = (size_t)N * QA_QLD > (size_t)64 * QA_QLD + (size_t)16 * NT * QA_XLD
+                        ? (size_t)N * QA_QLD : (size_t)64 * QA_QLD + (size_t)16 * NT * QA_XLD;
+  const size_t lds = fl * sizeof(float);
+  const void *fn = NT == 5 ? reinterpret_cast<const void *>(&encoder_qkv_attn_graph_kernel<5>)
+                 : NT == 6 ? reinterpret_cast<const void *>(&encoder_qkv_attn_graph_kernel<6>)
+                           : reinterpret_cast<const void *>(&encoder_qkv_attn_graph_kernel<7>);
+  static VrpAttrOnce attr_set[3];
+  if (!attr_set[NT - 5].done()) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      vrp_set_error("qkv_attn_graph: cannot raise dynamic LDS to 160 KB");
+      return 1;
+    }
+    attr_set[NT - 5].mark();
+  }
+  const dim3 grid(min(B, 256)), block(512);
+  if (NT == 5) hipLaunchKernelGGL(encoder_qkv_attn_graph_kernel<5>, grid, block, lds, st, x, Win, bin, att, B, N);
+  else if (NT == 6) hipLaunchKernelGGL(encoder_qkv_attn_graph_kernel<6>, grid, block, lds, st, x, Win, bin, att, B, N);
+  else hipLaunchKernelGGL(encoder_qkv_attn_graph_kernel<7>, grid, block, lds, st, x, Win, bin, att, B, N);
+  VRP_CHECK_LAUNCH("encoder_qkv_attn_graph");
+  return 0;
+}
+// (N such that q|k|v rows and the input tile fit 160 KB of LDS, and enough graphs to fill the chip)
+static bool qkv_attn_graph_applies(int train, int B, int N) {
+  static const bool off = getenv("VRP_UNFUSED_QKV") != nullptr;
+  if (off || train || N <= 64 || B < 256) return false;
+  const int NT = (N + 15) / 16;
+  const size_t a = (size_t)N * QA_QLD, b = (size_t)64 * QA_QLD + (size_t)16 * NT * QA_XLD;
+  return (a > b ? a : b) * sizeof(float) <= 160 * 1024;
 }
 
 // What the decoder prologue needs from the finished embeddings (graph_decoder.py:75-77 and the
@@ -2297,6 +2406,9 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       // large batches, eval mode: in_proj + attention of 80 / N whole graphs per workgroup
       // (only when the graphs fill at least three quarters of the five row tiles)
       if (int r = launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
+    } else if (qkv_attn_graph_applies(train, B, N)) {
+      // 64 < N <= 102, eval mode: in_proj + attention of one graph per workgroup pass, q|k|v in LDS
+      if (int r = launch_qkv_attn_graph(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
     } else {
       if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
                                      ws.qkv, 384, R, 384, 128, 0, st)) return r;
