@@ -142,6 +142,9 @@ typedef struct vrp_rollout_io {
   uint64_t noise_seed;    /* sampling with noise == NULL: the Exp(1) noise is drawn inside    */
                           /*   the step kernels from a Philox stream keyed by this seed       */
                           /*   (counter = graph, node, step): throughput mode, no parity      */
+  float logit_clip;       /* C of GraphDecoder.forward(..., C=10) (graph_decoder.py:56,97):   */
+                          /*   u = C tanh(.); 0 = the reference's default 10.  The backward   */
+                          /*   pass (vrp_decoder_backward) is built for 10 only               */
 } vrp_rollout_io;
 
 /* D2  Per-episode constants of GraphDecoder.forward (agents/graph_decoder.py:75-83):

@@ -1309,3 +1309,37 @@ def test_in_kernel_noise_is_strictly_positive_and_finite():
     u = ((bits >> 9).astype(np.float64) + 0.5) / 2.0 ** 23
     assert np.max(np.abs(q - (-np.log(u))) / np.maximum(-np.log(u), 1e-6)) < 1e-3
     assert abs(q[len(edge):].mean() - 1.0) < 5e-3      # Exp(1)
+
+
+@pytest.mark.parametrize("C", [5.0, 10.0, 20.0])
+def test_decoder_clipping_constant(C):
+    """GraphDecoder.forward(..., C) (graph_decoder.py:56,97): u = C tanh(.), so against the
+    reference's recorded C = 10 logits u_C = (C / 10) u_10 on the unmasked nodes: the greedy
+    node is the same, the sampled one is argmax(softmax(u_C) / q) with the CPU noise stream.
+    (First step of an episode: the later recorded steps assume the C = 10 choices.)"""
+    z = np.load(os.path.join(G, "decoder_k1_B64_N20.npz"))
+    agent = _agents()[1](seed=69)
+    dec = agent.model.decoder
+    emb = torch.tensor(z["emb"])
+    B, N = emb.shape[:2]
+    mask = torch.tensor(z["mask"][0])
+    u = torch.tensor(z["u"][0]) * (C / 10.0)
+    dec.reset()
+    idx, _ = dec(emb, mask=mask, C=C, rollout=True)
+    assert torch.equal(idx[:, 0].cpu(), u.argmax(-1))
+    dec.reset()
+    torch.manual_seed(1234)
+    idx, logp = dec(emb, mask=mask, C=C, rollout=False)
+    torch.manual_seed(1234)
+    noise = torch.empty(B, N).exponential_(1)
+    lsm = u - u.logsumexp(-1, keepdim=True)
+    ratio = torch.softmax(lsm, -1) / noise
+    want, got = ratio.argmax(-1), idx[:, 0].cpu()
+    flip = got != want
+    if flip.any():   # only on a near tie of the ratios
+        best = ratio.max(-1).values
+        mine = ratio.gather(1, got[:, None])[:, 0]
+        assert (((best - mine) / best)[flip] < TIE_GAP).all()
+    want_lp = lsm.gather(1, got[:, None])[:, 0]
+    assert (logp.reshape(-1).cpu() - want_lp).abs().max().item() < 2 * TOL * max(1.0, C / 10.0)
+    dec.reset()

@@ -148,7 +148,7 @@ def test_c_abi_exports_every_declared_symbol():
     import ctypes
     assert ctypes.sizeof(vrpgym_hip.Env) == 16 + 7 * 8
     assert ctypes.sizeof(vrpgym_hip.DecoderWeights) == 11 * 8
-    assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 11 * 8
+    assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 12 * 8   # + logit_clip (float, padded)
     assert ctypes.sizeof(vrpgym_hip.DecoderGrads) == 11 * 8
     assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 16 + 4 * 8 + 8 * 18 * 8
 

@@ -35,8 +35,7 @@ class GraphDecoder(nn.Module):
         """One decoding step (graph_decoder.py:51-115) -> (idx (B,1) int64, log_prob).
         Stateful like the reference: the first call of an episode uses the learned
         placeholders, later calls the first/last chosen nodes; `reset()` ends it."""
-        assert C == 10, "the HIP kernel is built for the reference's clipping constant C=10"
-        return runtime.decoder_step(self, node_embs, mask, load, greedy=bool(rollout))
+        return runtime.decoder_step(self, node_embs, mask, load, greedy=bool(rollout), clip=float(C))
 
     def reset(self):
         """graph_decoder.py:117-124."""

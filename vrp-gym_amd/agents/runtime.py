@@ -199,8 +199,9 @@ class _Episode:
         self.t = 0
 
 
-def decoder_step(dec, node_embs, mask, load, greedy):
-    """GraphDecoder.forward as ONE decode-only kernel launch (no env)."""
+def decoder_step(dec, node_embs, mask, load, greedy, clip=10.0):
+    """GraphDecoder.forward as ONE decode-only kernel launch (no env).  clip: the C of
+    `u = C tanh(...)` (graph_decoder.py:56,97; the models never pass anything but 10)."""
     dev = _require_cuda(dec)
     lib = hip.lib()
     kind = hip.KIND_IRP if load is not None else hip.KIND_TSP
@@ -241,6 +242,7 @@ def decoder_step(dec, node_embs, mask, load, greedy):
     t = ep.t
     io.actions = actions.data_ptr() - t * B * 8
     io.step_logp = logp.data_ptr() - t * B * 4
+    io.logit_clip = float(clip)
     if noise is not None:
         io.noise = noise.data_ptr() - t * B * N * 4
     w = decoder_struct(dec)

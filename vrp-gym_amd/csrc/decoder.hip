@@ -437,7 +437,7 @@ __global__ __launch_bounds__(64 * WPG, (NPL == 1 ? RT_MINW : 2)) void decode_ste
   for (int i = 0; i < NPL; ++i) {
     u[i] = -INFINITY;
     if (inN[i] && !own_mask[i])
-      u[i] = 10.f * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
+      u[i] = p.clip * tanhf(u_s[wave][lane + 64 * i] + cv[i]);  // graph_decoder.py:97-98
     if (active && p.io.logits && inN[i])
       p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
     if (active && p.io.mask_trace && inN[i])
@@ -604,6 +604,7 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
   p.WvP = d.WvP; p.MP = d.MP;
   p.RT = ws.RT; p.cvec = ws.cvec;
   p.skip_curs = 0;
+  p.clip = io->logit_clip > 0.f ? io->logit_clip : 10.f;
   // tuning aid, read at every call (tools/tile_phase_probe.py changes it between launches)
   const char *dbg = getenv("VRP_TILE_DBG");
   p.dbg = dbg ? atoi(dbg) : 0;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
     }
     PERSIST_WAVE_SYNC();
     float u = -INFINITY;
-    if (inN && !own_mask) u = 10.f * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
+    if (inN && !own_mask) u = p.clip * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
     if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)t * B + b) * N + lane] = (uint8_t)own_mask;
     if (p.io.load_trace && lane == 0) p.io.load_trace[(size_t)t * B + b] = (float)load0;
 

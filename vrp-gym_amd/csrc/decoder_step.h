@@ -15,6 +15,7 @@ struct StepParams {
   const float *Wv, *M;          // (384,128) v_proj rows; (128,384) M = Wkp^T Watt Wo / sqrt(128)
   const float *WvP, *MP;        // the same two in MFMA fragment order (decoder_ws.h)
   const float *RT, *cvec;
+  float clip;                   // C of graph_decoder.py:56,97 (10 unless io.logit_clip says otherwise)
   int dbg;                      // tuning aid (VRP_TILE_DBG): stop the tile kernel after phase dbg
   int stagger;                  // raw-tile kernel: odd workgroups start this many x 64 cycles late
   int skip_curs;                // raw-tile kernel: the next step is the raw-tile kernel's too (the

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, 2) void decode_step_tile_mfma_kernel(StepP
       }
       const float x = reduce_scatter64<64>(pv, lane);
       if (p.dbg == 4) { if (x == 123.f) p.curs[0] = x; continue; }
-      u[i] = (inN[i] && !own_mask[gi][i]) ? 10.f * tanhf(x + cv[gi][i]) : -INFINITY;  // graph_decoder.py:97-98
+      u[i] = (inN[i] && !own_mask[gi][i]) ? p.clip * tanhf(x + cv[gi][i]) : -INFINITY;  // graph_decoder.py:97-98
       if (p.io.logits && inN[i]) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
       if (p.io.mask_trace && inN[i])
         p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] = (uint8_t)own_mask[gi][i];

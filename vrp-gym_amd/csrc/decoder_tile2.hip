@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
     for (int i = 0; i < NPL; ++i) {
       const float x = (lane + 64 * i < NMAX) ? ug[lane + 64 * i] : 0.f;
       if (p.dbg == 4) { if (x == 123.f) p.curs[0] = x; continue; }
-      u[i] = (inN[i] && !own_mask[gi][i]) ? 10.f * tanhf(x + cv[gi][i]) : -INFINITY;  // graph_decoder.py:97-98
+      u[i] = (inN[i] && !own_mask[gi][i]) ? p.clip * tanhf(x + cv[gi][i]) : -INFINITY;  // graph_decoder.py:97-98
       if (p.io.logits && inN[i]) p.io.logits[((size_t)p.t * B + b) * N + lane + 64 * i] = u[i];
       if (p.io.mask_trace && inN[i])
         p.io.mask_trace[((size_t)p.t * B + b) * N + lane + 64 * i] = (uint8_t)own_mask[gi][i];
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(512, 2) void decode_tile_persistent_kernel(TilePers
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
       const float x = (lane + 64 * i < NMAX) ? ug[lane + 64 * i] : 0.f;
-      u[i] = (inN[i] && !vis[i]) ? 10.f * tanhf(x + cv[i]) : -INFINITY;  // graph_decoder.py:97-98
+      u[i] = (inN[i] && !vis[i]) ? p.clip * tanhf(x + cv[i]) : -INFINITY;  // graph_decoder.py:97-98
     }
     auto argmax_nodes = [&](const float (&v)[NPL]) {
       float mx = v[0];

@@ -1524,170 +1524,11 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
   }
 }
 
-// ---- the same GEMM with the epilogue of a pass spread over the NEXT pass's MFMAs ----------
-// Round 4.  What the kernel above loses: a pass ends with every thread storing its five 16-byte
-// pieces of the 80 x 128 block back to back, and a compute unit takes stores at about 7-10 bytes
-// per clock (MI355X_MICROARCH.md: store-issue-bound epilogues): 40 KB = 4-5 k cycles in which no
-// wave issues an MFMA, against 10 k cycles of MFMAs per pass -- 104 us for the 60 us of matrix
-// work of the train-mode in_proj at 81920 x 384 x 128.  Here a pass only parks its accumulators
-// in LDS (Cs); its five pieces (bias / residual / BatchNorm affine / ReLU / gate, 16-byte store)
-// are handled one per k-step group by the `pre` hook of the next pass's MFMA loop, the residual
-// and gate pieces requested one group ahead of their use.  Same arithmetic in the same order:
-// results are bit-identical to gemm_rows_kernel.
-template <int RT16>
-__global__ __launch_bounds__(512) void gemm_rows_pipe_kernel(
-    const float *__restrict__ A, int lda, const float *__restrict__ W_, int ldw,
-    const float *__restrict__ bias_, const float *__restrict__ R, int ldr,
-    const float *__restrict__ norm_, const float *__restrict__ gate, float *__restrict__ C, int ldc,
-    int M, int N, int K, int relu, int ntiles) {
-  constexpr int RTW = 16 * RT16, PF = RTW * 32 / 512;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *const Abuf0 = smem, *const Abuf1 = smem + RTW * EB_LD, *const Cs = smem + 2 * RTW * EB_LD;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i16 = lane & 15, q = lane >> 4;
-  const int ncb = N >> 7, nkc = K >> 7, nst = ncb * nkc;
-  const int prow = tid >> 5, pc4 = (tid & 31) * 4;   // this thread's piece u: row prow + 16 u
-  float4 pa[PF];
-  auto fetchA = [&](int tile, int kc) {
-    const int row0 = tile * RTW;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int r = prow + 16 * u;
-      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < M) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)(row0 + r) * lda + kc * 128 + pc4);
-    }
-  };
-  auto storeA = [&](float *dst) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-      *reinterpret_cast<float4 *>(dst + (prow + 16 * u) * EB_LD + pc4) = pa[u];
-  };
-  // ---- the parked pass ---------------------------------------------------------------------
-  bool pend = false;
-  int p_row0 = 0, p_cb = 0, p_valid = 0;
-  float4 bz, nmean, nmult, nbeta, rcur, gcur;
-  bz = nmean = nbeta = rcur = make_float4(0.f, 0.f, 0.f, 0.f);
-  nmult = gcur = make_float4(1.f, 1.f, 1.f, 1.f);
-  const float *bias = bias_, *norm = norm_;
-  auto piece_request = [&](int u) {   // residual / gate of piece u, one hook ahead of its use
-    const int r = prow + 16 * u;
-    rcur = make_float4(0.f, 0.f, 0.f, 0.f);
-    gcur = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (r < p_valid) {
-      if (R) rcur = *reinterpret_cast<const float4 *>(R + (size_t)(p_row0 + r) * ldr + p_cb * 128 + pc4);
-      if (gate) gcur = *reinterpret_cast<const float4 *>(gate + (size_t)(p_row0 + r) * ldc + p_cb * 128 + pc4);
-    }
-  };
-  auto piece_finish = [&](int u) {
-    const int r = prow + 16 * u;
-    if (r < p_valid) {
-      const float4 a4 = *reinterpret_cast<const float4 *>(Cs + r * EB_LD + pc4);
-      float v[4] = {a4.x, a4.y, a4.z, a4.w};
-      const float rr[4] = {rcur.x, rcur.y, rcur.z, rcur.w};
-      const float gg[4] = {gcur.x, gcur.y, gcur.z, gcur.w};
-      const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
-      const float nm[4] = {nmean.x, nmean.y, nmean.z, nmean.w};
-      const float nu[4] = {nmult.x, nmult.y, nmult.z, nmult.w};
-      const float nb[4] = {nbeta.x, nbeta.y, nbeta.z, nbeta.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += bb[e];
-        if (R) v[e] += rr[e];
-        if (norm) v[e] = (v[e] - nm[e]) * nu[e] + nb[e];
-        if (relu) v[e] = fmaxf(v[e], 0.f);
-        if (gate && !(gg[e] > 0.f)) v[e] = 0.f;
-      }
-      *reinterpret_cast<float4 *>(C + (size_t)(p_row0 + r) * ldc + p_cb * 128 + pc4) =
-          make_float4(v[0], v[1], v[2], v[3]);
-    }
-  };
-  // hook of k-step group g = s / 4 (eight per pass): group 0 fetches the pass constants and
-  // requests piece 0; group g in 1..PF finishes piece g - 1 and requests piece g
-  auto epilogue_hook = [&](int s) {
-    if (!pend) return;
-    const int g = s >> 2;
-    if (g == 0) {
-      const int cq = p_cb * 128 + pc4;
-      bz = nmean = nbeta = make_float4(0.f, 0.f, 0.f, 0.f);
-      nmult = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (bias) bz = *reinterpret_cast<const float4 *>(bias + cq);
-      if (norm) {
-        nmean = *reinterpret_cast<const float4 *>(norm + cq);
-        nmult = *reinterpret_cast<const float4 *>(norm + 128 + cq);
-        nbeta = *reinterpret_cast<const float4 *>(norm + 256 + cq);
-      }
-      piece_request(0);
-    } else if (g <= PF) {
-      piece_finish(g - 1);
-      if (g < PF) piece_request(g);
-    }
-  };
-  static_assert(PF <= 7, "one piece per k-step group of the next pass");
-
-  int tile = blockIdx.x;
-  int cur = 0;
-  float w[32], wn[32];
-  if (tile < ntiles) { fetchA(tile, 0); storeA(Abuf0); }
-  {
-    const float *w0 = W_ + (size_t)(wave * 16 + i16) * ldw + kq8(q);
-#pragma unroll
-    for (int s = 0; s < 32; s += 4) load_w4(w, w0, s);
-  }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    int zero;   // (keeps the tile-invariant weight loads inside the loop, see encoder_block8_kernel)
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    const float *W = W_ + zero;
-    bias = bias_ ? bias_ + zero : nullptr;
-    norm = norm_ ? norm_ + zero : nullptr;
-    const int row0 = tile * RTW, valid = M - row0;
-    const int next_tile = tile + gridDim.x;
-    f32x4v acc[RT16];
-    for (int st = 0; st < nst; ++st) {
-      const int cb = st / nkc, kc = st - cb * nkc;
-      if (kc == 0) {
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      }
-      const bool last_stage = st + 1 == nst;
-      const bool tile_left = next_tile < ntiles;
-      const bool fetch = (nkc > 1) ? (!last_stage || tile_left) : (last_stage && tile_left);
-      if (fetch) fetchA(last_stage ? next_tile : tile, last_stage ? 0 : (kc + 1 == nkc ? 0 : kc + 1));
-      const bool epi = kc + 1 == nkc;
-      {
-        const int sn = last_stage ? 0 : st + 1;
-        const int cbn = sn / nkc, kcn = sn - cbn * nkc;
-        const float *wp = W + (size_t)(cbn * 128 + wave * 16 + i16) * ldw + kcn * 128 + kq8(q);
-        eb8_mma<RT16>(acc, cur ? Abuf1 : Abuf0, w, lane, [&](int s) {
-          load_w4(wn, wp, s);
-          epilogue_hook(s);
-        });
-      }
-      pend = false;   // the parked pass went out under this pass's MFMAs
-      if (fetch) storeA(cur ? Abuf0 : Abuf1);
-      if (epi) {
-        __syncthreads();   // every thread has read its pieces of the previous pass out of Cs
-#pragma unroll
-        for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(rt * 16 + 4 * q + r) * EB_LD + wave * 16 + i16] = acc[rt][r];
-        pend = true;
-        p_row0 = row0; p_cb = cb; p_valid = valid;
-      }
-#pragma unroll
-      for (int s = 0; s < 32; ++s) w[s] = wn[s];
-      if (fetch || epi) __syncthreads();   // next A chunk in place / Cs complete
-      if (fetch) cur ^= 1;
-    }
-  }
-  if (pend) {   // the last pass of this workgroup: nothing left to hide it under
-    epilogue_hook(0);
-#pragma unroll
-    for (int g = 1; g <= PF; ++g) epilogue_hook(4 * g);
-  }
-}
-
+// (Round 4, measured and NOT kept -- DESIGN.md 3.5: the pass epilogue spread over the next pass's
+// k-step groups, 127 vs 117 us at 81920 x 384 x 128; two four-wave workgroups of 48-row tiles per
+// CU instead of one eight-wave workgroup of 80 rows, 187 vs 120 us.  PMC on this kernel: matrix
+// pipe busy 52 % of the cycles, waves parked 27 % -- its eight waves reach the two barriers of a
+// pass in lockstep.)
 int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const float *bias,
                          const float *R, int ldr, const float *norm, const float *gate, float *C,
                          int ldc, int M, int N, int K, int relu, hipStream_t st) {
@@ -1703,22 +1544,6 @@ int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const
     attr_set.mark();
   }
   const int ntiles = (M + RTW - 1) / RTW;
-  static const bool v1 = getenv("VRP_GEMM_ROWS_V1") != nullptr;   // A/B aid: burst epilogue
-  if (!v1) {
-    static VrpAttrOnce attr2;
-    if (!attr2.done()) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_rows_pipe_kernel<RT16>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        vrp_set_error("gemm_rows_pipe: cannot raise dynamic LDS to %zu bytes", lds);
-        return 1;
-      }
-      attr2.mark();
-    }
-    hipLaunchKernelGGL(gemm_rows_pipe_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, A,
-                       lda, W, ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, ntiles);
-    VRP_CHECK_LAUNCH("gemm_rows_pipe");
-    return 0;
-  }
   hipLaunchKernelGGL(gemm_rows_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, A, lda, W,
                      ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, ntiles);
   VRP_CHECK_LAUNCH("gemm_rows");

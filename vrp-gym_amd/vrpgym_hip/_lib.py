@@ -65,7 +65,7 @@ class RolloutIO(C.Structure):
     """struct vrp_rollout_io"""
     _fields_ = [(n, c_vp) for n in ("acc_loss", "acc_logp", "notdone", "actions", "forced",
                                     "noise", "logits", "step_logp", "mask_trace",
-                                    "load_trace")] + [("noise_seed", C.c_uint64)]
+                                    "load_trace")] + [("noise_seed", C.c_uint64), ("logit_clip", C.c_float)]
 
 
 class DecoderGrads(C.Structure):
