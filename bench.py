@@ -431,7 +431,10 @@ def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
                             (projections, attention, feed-forward of 3 layers)
       encoder backward x1   2x a forward (input- and weight-gradient products)
       prologue         x4   per-episode decoder tables: B N 2 (4*384*128 + 2*8*48 N)
-      decode steps          sum over the four rollouts of B T (196 608 + 4 352 N)
+      decode steps          sum over the four rollouts of B T 2*8*N*N: the table formulation the
+                            training batches run (glimpse weights x logit-table rows; the 196 608
+                            flop of per-step weight folds in SURVEY 8d belong to the raw-tile
+                            formulation, which these batch sizes never take)
       decoder backward x1   the T sampled steps re-run un-folded (graph_decoder.py:75-107):
                             forward = B T (2*384*384 [query] + 2*2*8*48 N [scores, values] +
                             2*384*384 [out_proj] + 2*128*384 [_att_output] + 2*128 N [logits])
@@ -440,7 +443,7 @@ def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
     Adam, the t-test and BatchNorm reductions are not matrix work and are left out."""
     enc = B * N * (1180160 + 1536 * N)
     pro = B * N * 2 * (4 * 384 * 128 + 2 * 8 * 48 * N)
-    steps = B * (2 * T_sampled + 2 * T_greedy) * (196608 + 4352 * N)
+    steps = B * (2 * T_sampled + 2 * T_greedy) * (2 * 8 * N * N)
     dec_fwd = (B * T_sampled * (2 * 384 * 384 + 2 * 2 * 8 * 48 * N + 2 * 384 * 384 + 2 * 128 * 384
                                 + 2 * 128 * N) + B * N * 2 * 128 * (384 + 384 + 128))
     parts = {"encoder_forward_x4": 4 * enc, "encoder_backward": 2 * enc, "prologue_x4": 4 * pro,

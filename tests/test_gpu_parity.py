@@ -1343,3 +1343,15 @@ def test_decoder_clipping_constant(C):
     want_lp = lsm.gather(1, got[:, None])[:, 0]
     assert (logp.reshape(-1).cpu() - want_lp).abs().max().item() < 2 * TOL * max(1.0, C / 10.0)
     dec.reset()
+
+
+@pytest.mark.parametrize("kind,B,N,greedy", [
+    (1, 2048, 40, True),     # BASELINE config 3's batch (the rollout its training steps run)
+    (2, 1024, 40, True),     # config 4's per-GPU shard
+    (1, 2048, 100, False),   # config 5's per-GPU shard: sampling, raw-tile + table kernels
+])
+def test_full_size_rollout_against_oracle(kind, B, N, greedy):
+    """The BASELINE configs' per-GPU batches against the oracle itself (not only through
+    size-independent properties): every action, per-step logits and log-probs, cost and
+    accumulated log-prob, with the near-tie rule's allowance of B / 100 graphs."""
+    _compare_rollout(kind, B, N, greedy, 21, 69, 9)
