@@ -181,8 +181,11 @@ def test_encoder_large_against_oracle():
     four key tiles) or behind the GEMM + attention pair (N = 50); N = 113 / 128: seven / eight key
     tiles of the attention kernel that reads q|k|v from global memory."""
     from oracle import policy as opol
+    # (B >= 256 at 64 < N <= 105: encoder_qkv_attn_graph_kernel -- one graph per workgroup pass,
+    # q|k|v in LDS -- with five, six and seven row tiles, ragged last tile, more graphs than CUs)
     for kind, B, N in [(0, 37, 20), (2, 5, 100), (1, 300, 40), (0, 350, 40), (1, 901, 20),
-                       (0, 601, 37), (1, 450, 50), (2, 330, 64), (0, 3, 128), (1, 7, 113)]:
+                       (0, 601, 37), (1, 450, 50), (2, 330, 64), (0, 3, 128), (1, 7, 113),
+                       (1, 257, 65), (0, 300, 80), (2, 260, 81), (1, 520, 100), (0, 256, 105)]:
         agent = _agents()[kind](seed=69)
         sd, _ = opol.init_state_dicts(kind, 69)
         g = torch.Generator().manual_seed(B * N)

@@ -3,9 +3,9 @@
 #   kernel stats of the default bench command, per-shape kernel stats (TSP / VRP 8192x40,
 #   VRP 2048x100 sampling, TSP 512x20), training epochs of configs 3 and 4, and the PMC passes
 #   (FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only) behind roofline.traffic.
-# usage: bash tools/collect_profiles.sh r03
+# usage: bash tools/collect_profiles.sh r04
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -28,4 +28,11 @@ for shp in 0,20,512 0,40,8192 1,40,8192 1,100,2048,0,1; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp40 -o p -- python3 tools/rollout_loop.py 0 40 8192 3 > $OUT/pmc_mfma.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp20 -o p -- python3 tools/rollout_loop.py 0 20 512 10 > $OUT/pmc_mfma20.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_vrp100 -o p -- python3 tools/rollout_loop.py 1 100 2048 3 0 > $OUT/pmc_mfma100.log 2>&1
+# round 4: the tall GEMM of the training path, the raw-tile kernel's phases and
+# the per-CU streaming rate behind DESIGN.md 3.5.1
+VRP_GEMM_VARIANT=rows rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/gemm_rows -o p -- python3 tools/gemm_one.py 81920 384 128 > $OUT/pmc_gemm_rows.log 2>&1
+{ python3 tools/tile_phase_probe.py 1 100 2048 3 1; python3 tools/tile_phase_probe.py 0 40 8192 3 0; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 1 100 2048 3 1; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 0 40 8192 3 0; } 2>/dev/null | grep "us through phase" > $OUT/tile_phases.txt
+[ -x tools/micro/stream_rate ] && tools/micro/stream_rate > $OUT/stream_rate.txt 2>&1
+VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M=" > $OUT/gemm_rows_probe.txt
 ls $OUT

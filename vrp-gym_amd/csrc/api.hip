@@ -72,7 +72,9 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                 "rollout_steps_range: sampling needs io.noise or io.noise_seed");
     const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
                                                 max_steps, flags);
-    return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream);
+    return vrp_launch_persistent_steps(
+        sp, dec_workspace, (hipStream_t)stream,
+        vrp_persistent4_eligible(kind, env->B, env->N, max_steps, flags, io, (hipStream_t)stream));
   }
   for (int t = t_begin; t < t_end; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,

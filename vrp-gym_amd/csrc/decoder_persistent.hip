@@ -337,6 +337,334 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
   }
 }
 
+// ---- the same episode loop with FOUR waves per graph (round 4) -----------------------------
+// At B = 512 the kernel above puts two lone waves on every CU: a wave that has a SIMD to itself
+// issues one vector instruction per ~4 cycles, and a step is ~635 of them (2 us) + the hand-off
+// (PMC).  Here a graph is a 256-thread workgroup, one wave per SIMD:
+//   wave w    glimpse weights of heads 2w, 2w+1 (score rows, scrambled masks, softmax);
+//             the wave-wide shift M is still ONE maximum over all eight heads (exchanged
+//             through LDS): results stay bit-identical to the one-wave and per-step kernels
+//   wave w    the logit-table rows of passes w, w+4 (a pass = eight selectable nodes)
+//   wave 0    polls the eight hand-off words, picks the action, steps the env, publishes
+// Five workgroup barriers per step; everything another wave needs goes through LDS.
+#define P4_BARRIER() __syncthreads()
+__global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams pp) {
+  const StepParams &p = pp.s;
+  __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
+  __shared__ __attribute__((aligned(16))) float u_s[64];
+  __shared__ int sel_s[64];                 // compacted list of selectable nodes of the step
+  __shared__ unsigned long long wrd_s[8];   // the eight other graphs' mask words of the step
+  __shared__ float mx_s[4];
+  __shared__ int ctl_s[4];                  // [0] chosen node, [1] 1 = finished / gave up, [2] nsel,
+                                            // [3] bits of the vehicle load as fp32 (IRP)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (pp.census) {
+    // residency census (vrp_persistent_capacity4): see decode_persistent_kernel
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&pp.census[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int seen = 0;
+      for (int spins = 0; spins < 4000; ++spins) {
+        seen = __hip_atomic_load(&pp.census[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= (int)gridDim.x) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (seen >= (int)gridDim.x)
+        __hip_atomic_fetch_add(&pp.census[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const int N = p.N, B = p.B;
+  const int b = blockIdx.x;
+  const int t0 = p.t;
+  if (p.io.notdone[t0 - 1] == 0) return;  // the batch was done before this launch
+  const int n4 = 2 * N;  // float4 per RT row (8N floats)
+  const int rsl = lane >> 3, part = lane & 7;
+  const bool inN = lane < N;
+  const int ln = inN ? lane : 0;
+  const size_t row = (size_t)b * 8 * N;
+  const int h0 = 2 * wave;   // this wave's two heads
+
+  // ---- per-graph state.  Wave 0: the env row (lane = node); every wave: its heads' constants
+  const uint8_t *mask0 = p.env.mask + (size_t)(t0 & 1) * B * N;
+  int own_mask = mask0[(size_t)b * N + ln];
+  int msk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) msk[j] = mask0[(size_t)((b * 8 + h0 + j) % B) * N + ln];  // QUIRK D3
+  float sld[2], bs[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sld[j] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + (h0 + j) * N + ln] : 0.f;
+    bs[j] = p.base ? p.base[row + (h0 + j) * N + ln] : 0.f;
+  }
+  const float cv = p.cvec[(size_t)b * N + ln];
+  const double2 xy = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln];
+  int vis = inN ? p.env.visited[(size_t)b * N + ln] : 1;
+  const double dem = (p.kind == VRP_KIND_IRP) ? p.env.demand[(size_t)b * N + ln] : 0.0;
+  int cur = p.env.cur[b];
+  const int dep = p.env.depot[b];
+  double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
+  float accl = p.io.acc_loss[b], accp = p.io.acc_logp[b];
+  int last = __builtin_amdgcn_readfirstlane(p.last[b]);
+  float sc[2];  // this step's score rows SL[b][last][h] (requested at the end of the step before)
+  {
+    const float *srow = p.SL + ((size_t)b * N + last) * 8 * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) sc[j] = srow[(h0 + j) * N + ln];
+  }
+  const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
+  const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
+  const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
+  constexpr int NB = 2;  // work items in flight
+  int ta = -1, wb_cur = -1;
+  float ret = 0.f;
+  double wb_load = 1.0;
+  float loadf = (float)load0;   // the softmax's load factor (IRP); later steps: from wave 0
+  // the selectable list of the first step
+  {
+    const bool s_i = inN && !own_mask;
+    const unsigned long long sel = __ballot(s_i);
+    if (wave == 0) {
+      if (s_i) sel_s[__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+      if (lane == 0) { ctl_s[1] = 0; ctl_s[2] = __popcll(sel); }
+    }
+  }
+  P4_BARRIER();
+  int t = t0;
+
+  for (; t < p.max_steps; ++t) {
+    const int nsel = ctl_s[2];
+    const int npass = (nsel + 7) >> 3;
+    // ---- loads that do not depend on other graphs: noise (wave 0), this wave's table rows
+    const float q_noise = (!p.sample || wave != 0) ? 1.f
+                          : p.io.noise ? p.io.noise[((size_t)t * B + b) * N + ln]
+                                       : vrp_exp1_noise(p.io.noise_seed, t, b, ln);
+    // this wave's work items: passes wave, wave + 4 (N <= 63: at most eight passes), chunk-major
+    const int mypass = wave < npass ? ((npass - wave + 3) >> 2) : 0;
+    const int total = mypass * nchunk;
+    float4 rbuf[NB][RT_U];
+    int mrow[NB];
+    auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
+      const int pi = w / nchunk, ch = w - pi * nchunk;
+      const int k = 8 * (wave + 4 * pi) + rsl;
+      const int m = k < nsel ? sel_s[k] : -1;
+      m_out = m;
+      rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
+    };
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      mrow[j] = -1;
+      if (j < total) load_item(rbuf[j], j, mrow[j]);
+    }
+    // ---- the eight other graphs' masks of this step (first step: the byte rows in memory)
+    if (t > t0) {
+      if (wave == 0) {
+        unsigned long long w = PERSIST_VALID;
+        if (lane < 8) {
+          const unsigned long long *src = pp.hist + (size_t)t * B + (b * 8 + lane) % B;
+          int spins = 0;
+          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (!(w & PERSIST_VALID)) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > PERSIST_SPIN_LIMIT) break;
+            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          wrd_s[lane] = w;
+        }
+        if (__any(!(w & PERSIST_VALID))) {
+          // gave up: flag the episode, let everybody who waits for THIS graph go on, leave
+          if (lane == 0) {
+            __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ctl_s[1] = 1;
+          }
+          const unsigned long long word = (__ballot(inN && own_mask) & ~PERSIST_VALID) | PERSIST_VALID;
+          for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
+            __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      P4_BARRIER();
+      if (ctl_s[1]) break;   // uniform over the workgroup
+#pragma unroll
+      for (int j = 0; j < 2; ++j) msk[j] = (int)((wrd_s[h0 + j] >> lane) & 1ull);
+    }
+    // ---- glimpse attention weights of this wave's heads; ONE shift M for all eight heads ----
+    float e[2];
+    {
+      float s[2], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float v = sc[j] + bs[j];
+        if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sld[j], v);
+        v = inN ? v + (float)msk[j] : -INFINITY;
+        s[j] = v;
+        mx = fmaxf(mx, v);
+      }
+      const float mw = wave_max(mx);
+      if (lane == 0) mx_s[wave] = mw;
+      P4_BARRIER();
+      const float M = fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        e[j] = inN ? exp_nonpos(s[j] - M) : 0.f;
+        float sum = wave_sum(e[j]);
+        if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
+          const float hm = wave_max(s[j]);
+          e[j] = inN ? exp_nonpos(s[j] - hm) : 0.f;
+          sum = wave_sum(e[j]);
+        }
+        float r = __builtin_amdgcn_rcpf(sum);
+        r = fmaf(fmaf(-sum, r, 1.f), r, r);
+        if (inN) a_s[(h0 + j) * N + lane] = e[j] * r;
+      }
+    }
+    P4_BARRIER();
+    // ---- u_m = sum_{h,n} a[h][n] * RT[m][h][n] for this wave's selectable rows ------------
+    {
+      const float4 *aw = reinterpret_cast<const float4 *>(a_s) + part;
+      float acc = 0.f;
+      auto consume = [&](const float4 (&r)[RT_U], int w, int m) {
+        const int ch = w % nchunk;
+        acc = rt_dot(acc, r, aw, ch * RT_U, m >= 0 ? cnt : 0);
+        if (ch == nchunk - 1) {
+          acc = group8_sum(acc);
+          if (part == 0 && m >= 0) u_s[m] = acc;
+          acc = 0.f;
+        }
+      };
+      for (int w = 0; w < total; w += NB) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (w + j < total) {
+            consume(rbuf[j], w + j, mrow[j]);
+            if (w + j + NB < total) load_item(rbuf[j], w + j + NB, mrow[j]);
+          }
+        }
+      }
+    }
+    P4_BARRIER();
+    // ---- wave 0: action, the next mask (eight other graphs wait for that word), hand-over ----
+    int idx = 0;
+    float logp = 0.f;
+    double load = 1.0;
+    bool done = false, finish = false;
+    int mk = 0;
+    unsigned long long word = 0ull;
+    if (wave == 0) {
+      float u = -INFINITY;
+      if (inN && !own_mask) u = p.clip * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
+      if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)t * B + b) * N + lane] = (uint8_t)own_mask;
+      if (p.io.load_trace && lane == 0) p.io.load_trace[(size_t)t * B + b] = (float)load0;
+      if (!p.sample) {
+        idx = wave_argmax_lane(u);
+      } else {
+        const float m = wave_max(u);
+        const float se = wave_sum(expf(u - m));
+        const float lse = m + logf(se);
+        const float l = u - lse;
+        const float lm = wave_max(l);
+        const float pe = expf(l - lm);
+        const float ps = wave_sum(pe);
+        const float ratio = inN ? (pe / ps) / q_noise : -1.f;
+        idx = wave_argmax_lane(ratio);
+        logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), idx));
+      }
+      idx = __builtin_amdgcn_readfirstlane(idx);
+      if (lane == idx) vis = 1;  // tsp.py:86
+      if (p.kind == VRP_KIND_IRP) {                               // irp.py:80-86
+        load = load0 - readlane_f64(dem, idx);
+        if (idx == dep) load = 1.0;
+      }
+      done = __all(vis);                                          // before the fix-ups, tsp.py:95
+      if (lane == dep) {
+        if (idx == dep) vis = 1;                                  // tsp.py:141-142
+        else if (p.kind != VRP_KIND_TSP) vis = 0;                 // vrp.py:28-31
+      }
+      if (__all(vis) && lane == dep) vis = 0;                     // tsp.py:145-146
+      mk = vis;
+      if (p.kind == VRP_KIND_IRP && inN && dem - load > 0.0) mk = 1;  // irp.py:151-153
+      word = (__ballot(inN && mk) & ~PERSIST_VALID) | PERSIST_VALID;
+      finish = done && (ta >= 0 || p.kind == VRP_KIND_TSP || idx == dep);
+      if (lane == 0 && !finish)
+        __hip_atomic_store(pp.hist + (size_t)(t + 1) * B + b, word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      // what the other waves need for the next step
+      const bool s_i = inN && !mk;
+      const unsigned long long sel = __ballot(s_i);
+      if (s_i) sel_s[__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+      if (lane == 0) {
+        ctl_s[0] = idx; ctl_s[1] = finish ? 1 : 0; ctl_s[2] = __popcll(sel);
+        ctl_s[3] = __builtin_bit_cast(int, (float)load);
+      }
+    }
+    P4_BARRIER();
+    last = ctl_s[0];
+    const bool leave = ctl_s[1] != 0;   // finished (uniform)
+    loadf = __builtin_bit_cast(float, ctl_s[3]);
+    if (!leave) {
+      // next step's score rows of this wave's heads: requested now, consumed after the hand-off
+      const float *srow = p.SL + ((size_t)b * N + last) * 8 * N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) sc[j] = srow[(h0 + j) * N + ln];
+    }
+    // ---- wave 0 alone: the edge's length (an fp64 square root), accumulators, traces -- while
+    // the other three waves already wait at the next step's first barrier
+    if (wave == 0) {
+      const double dx = readlane_f64(xy.x, cur) - readlane_f64(xy.x, idx);
+      const double dy = readlane_f64(xy.y, cur) - readlane_f64(xy.y, idx);
+      const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+      if (lane == 0) {
+        if (p.io.actions) p.io.actions[(size_t)t * B + b] = idx;
+        if (p.io.step_logp) p.io.step_logp[(size_t)t * B + b] = logp;
+      }
+      if (ta >= 0) {           // this step was the forced return after `done`
+        ret = (float)(-dist);
+        wb_cur = cur;          // where the episode ends if the batch was done at ta
+        wb_load = load0;
+      } else {
+        accl += (float)(-dist);  // fp32 accumulate in step order, tsp_agent:85
+        accp += logp;
+        if (done) ta = t;
+      }
+      own_mask = mk;
+      cur = idx;
+      load0 = load;
+      if (finish) {
+        // the mask is constant from here on: publish it for every remaining step, fill the
+        // traces the way the reference's self-loops on the depot would
+        for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
+          __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        for (int tt = t + 1; tt < p.max_steps; ++tt) {
+          if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)tt * B + b) * N + lane] = (uint8_t)mk;
+          if (lane == 0) {
+            if (p.io.load_trace) p.io.load_trace[(size_t)tt * B + b] = (float)load;
+            if (p.io.actions) p.io.actions[(size_t)tt * B + b] = idx;
+            if (p.io.step_logp) p.io.step_logp[(size_t)tt * B + b] = 0.f;
+          }
+        }
+      }
+    }
+    if (leave) break;
+  }
+  // ---- state back to memory (wave 0 holds it) ------------------------------------------------
+  if (wave == 0) {
+    if (inN) p.env.visited[(size_t)b * N + lane] = (uint8_t)vis;
+    if (lane == 0) {
+      p.env.cur[b] = cur;
+      if (p.kind == VRP_KIND_IRP) p.env.load[b] = load0;
+      p.io.acc_loss[b] = accl;
+      p.io.acc_logp[b] = accp;
+      p.last[b] = cur;
+      pp.ta[b] = ta < 0 ? p.max_steps - 1 : ta;
+      pp.ret[b] = ret;
+      pp.wb_cur[b] = wb_cur;
+      pp.wb_load[b] = wb_load;
+    }
+  }
+}
+
 // T - 1 = max_b ta_b; the way back of a graph counts iff the batch ran on after its ta
 // (otherwise the episode ended with the graph on its last customer: location and load are
 // put back); notdone[t] as the per-step launches would have left it.  One workgroup.
@@ -398,6 +726,8 @@ struct PersistDevice {
   int capacity = -1;             // resident single-wave workgroups, -1 = not measured yet
   int cus = 0;
   int retries = 0;               // censuses thrown away because they looked disturbed
+  int capacity4 = -1;            // resident four-wave workgroups (decode_persistent4_kernel)
+  int retries4 = 0;
   hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
   hipStream_t last_stream = nullptr;  // identity of that launch's stream (compared, never used)
 };
@@ -501,10 +831,69 @@ int vrp_usable_cus() {
   return g_pdev[dev].cus;
 }
 
+// Four-wave workgroups of decode_persistent4_kernel the device keeps resident at once: the same
+// census (every workgroup must see all the others), at most four per compute unit.
+static int persistent4_capacity_of(int dev, hipStream_t capturing_guard) {
+  if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
+  (void)persistent_capacity_of(dev, capturing_guard);   // the usable CUs
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
+  PersistDevice &pd = g_pdev[dev];
+  if (pd.capacity4 >= 0) return pd.capacity4;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
+  int per_cu = 0;
+  if (pd.cus <= 0 || cs != hipStreamCaptureStatusNone ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_persistent4_kernel, 256, 0) !=
+          hipSuccess) { (void)hipGetLastError(); return 0; }
+  per_cu = per_cu > 4 ? 4 : per_cu;
+  int32_t *res = nullptr;
+  hipStream_t st2 = nullptr;
+  if (hipGetSymbolAddress((void **)&res, HIP_SYMBOL(g_residency)) != hipSuccess ||
+      hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  if (capturing_guard) (void)hipStreamSynchronize(capturing_guard);
+  else (void)hipDeviceSynchronize();
+  int measured = 0;
+  for (int k = per_cu; k >= 1 && measured == 0; --k) {
+    int32_t zero2[2] = {0, 0}, got[2] = {0, 0};
+    PersistParams cp = {};
+    cp.census = res;
+    bool ok2 = hipMemcpyAsync(res, zero2, sizeof(zero2), hipMemcpyHostToDevice, st2) == hipSuccess;
+    if (ok2) {
+      hipLaunchKernelGGL(decode_persistent4_kernel, dim3(pd.cus * k), dim3(256), 0, st2, cp);
+      ok2 = hipGetLastError() == hipSuccess;
+    }
+    ok2 = ok2 && hipMemcpyAsync(got, res, sizeof(got), hipMemcpyDeviceToHost, st2) == hipSuccess;
+    ok2 = ok2 && hipStreamSynchronize(st2) == hipSuccess;
+    if (!ok2) { (void)hipGetLastError(); break; }
+    if (got[1] == pd.cus * k) measured = pd.cus * k;
+  }
+  (void)hipStreamDestroy(st2);
+  if (measured < pd.cus * (per_cu - 1) && pd.retries4 < 4) { ++pd.retries4; return measured; }
+  pd.capacity4 = measured;
+  return measured;
+}
+
+// four waves per graph where the batch is small enough for every such workgroup to be resident
+bool vrp_persistent4_eligible(int kind, int B, int N, int max_steps, int flags,
+                              const vrp_rollout_io *io, hipStream_t st) {
+  static const bool off = getenv("VRP_PERSISTENT_ONE_WAVE") != nullptr;   // A/B aid
+  if (off || !vrp_persistent_eligible(kind, B, N, max_steps, flags, io, st)) return false;
+  static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;
+  if (force) return B <= 1024;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return B <= persistent4_capacity_of(dev, st);
+}
+
 extern "C" int vrp_persistent_capacity(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return persistent_capacity_of(dev, nullptr);
+  const int c = persistent_capacity_of(dev, nullptr);
+  (void)persistent4_capacity_of(dev, nullptr);   // measured at the same quiet moment
+  return c;
 }
 
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
@@ -569,7 +958,8 @@ int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStr
 }
 
 // steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
-int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st) {
+int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
+                                bool four_waves) {
   DecWs ws = carve_decws(workspace, sp.B, sp.N);
   PersistParams pp;
   pp.s = sp;
@@ -583,7 +973,8 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
   void *token = nullptr;
   vrp_persistent_serialize_begin(st, &token);
-  hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
+  if (four_waves) hipLaunchKernelGGL(decode_persistent4_kernel, dim3(sp.B), dim3(256), 0, st, pp);
+  else hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
   if (int r = vrp_launch_persistent_finalize(sp, workspace, st)) return r;
   vrp_persistent_serialize_end(st, token);
