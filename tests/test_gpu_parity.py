@@ -1152,6 +1152,21 @@ def test_full_size_properties_configs_4_5(kind, B, N, greedy, train):
     assert (lsm.float() - slp).abs().max().item() < TOL
 
 
+def _persistent_equal(kind, B, steps, ref, got):
+    (r0, e0), (r1, e1) = ref, got
+    T = r0.T
+    assert r1.T == T
+    assert torch.equal(r0.notdone[:steps], r1.notdone[:steps])
+    assert torch.equal(r0.actions[:T], r1.actions[:T])
+    assert torch.equal(r0.step_logp[:T], r1.step_logp[:T])
+    assert torch.equal(r0.mask_trace[:T], r1.mask_trace[:T])
+    if kind == 2:
+        assert torch.equal(r0.load_trace[:T], r1.load_trace[:T])
+    assert torch.equal(r0.acc_loss, r1.acc_loss) and torch.equal(r0.acc_logp, r1.acc_logp)
+    assert torch.equal(e0._visited, e1._visited) and torch.equal(e0._cur, e1._cur)
+    assert torch.equal(e0._load, e1._load)
+
+
 @pytest.mark.parametrize("kind,B,N,greedy,train", [
     (0, 512, 20, True, False), (0, 512, 20, False, True), (1, 300, 33, True, False),
     (1, 2048, 40, False, True), (2, 1024, 40, False, True), (2, 37, 63, True, False),
@@ -1168,16 +1183,30 @@ def test_persistent_steps_equal_per_step_launches(kind, B, N, greedy, train):
     agent.model.train(train)
     steps = runtime.max_steps_for(kind, N)
     noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
+    import vrpgym_hip as hip
     out = []
-    for persistent in (False, True):
-        e = deepcopy(env)
-        a = _agents()[kind](seed=69)
-        a.model.train(train)
-        with torch.no_grad():
-            r = runtime.rollout(a.model, e, greedy, train=train, noise=noise, record=True,
-                                step_trace=True, persistent=persistent)
+    # one launch per step, then the persistent kernel one, two and four waves per graph wide
+    # (VRP_PERSISTENT_WAVES is read at every call; a width that would not be resident falls back
+    # to the one-wave kernel -- all of them must reproduce the per-step results bit for bit)
+    for waves in (None, "1", "2", "4"):
+        if waves is None:
+            os.environ.pop("VRP_PERSISTENT_WAVES", None)
+        else:
+            os.environ["VRP_PERSISTENT_WAVES"] = waves
+        try:
+            e = deepcopy(env)
+            a = _agents()[kind](seed=69)
+            a.model.train(train)
+            with torch.no_grad():
+                r = runtime.rollout(a.model, e, greedy, train=train, noise=noise, record=True,
+                                    step_trace=True, persistent=waves is not None)
+            r.T
+        finally:
+            os.environ.pop("VRP_PERSISTENT_WAVES", None)
         out.append((r, e))
-    (r0, e0), (r1, e1) = out
+    for other in out[2:]:
+        _persistent_equal(kind, B, steps, out[0], other)
+    (r0, e0), (r1, e1) = out[0], out[1]
     T = r0.T
     assert r1.T == T
     assert torch.equal(r0.notdone[:steps], r1.notdone[:steps])

@@ -57,10 +57,13 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                                                 max_steps, flags);
     return vrp_launch_tile_persistent_steps(sp, dec_workspace, (hipStream_t)stream);
   }
-  if (t_end == max_steps && t_end - t_begin >= 2 &&
-      vrp_persistent_eligible(kind, env->B, env->N, max_steps, flags, io, (hipStream_t)stream)) {
+  const int pwaves = (t_end == max_steps && t_end - t_begin >= 2)
+                         ? vrp_persistent_width(kind, env->B, env->N, max_steps, flags, io,
+                                                (hipStream_t)stream) : 0;
+  if (pwaves > 0) {
     // latency-bound regime: step 0 as its own launch (the first-node fold follows it), every
-    // later step inside ONE persistent launch (decoder_persistent.hip)
+    // later step inside ONE persistent launch (decoder_persistent.hip), one, two or four waves
+    // per graph
     if (t_begin == 0) {
       if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
                                   flags, stream)) return r;
@@ -72,9 +75,7 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                 "rollout_steps_range: sampling needs io.noise or io.noise_seed");
     const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
                                                 max_steps, flags);
-    return vrp_launch_persistent_steps(
-        sp, dec_workspace, (hipStream_t)stream,
-        vrp_persistent4_eligible(kind, env->B, env->N, max_steps, flags, io, (hipStream_t)stream));
+    return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream, pwaves);
   }
   for (int t = t_begin; t < t_end; ++t)
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,

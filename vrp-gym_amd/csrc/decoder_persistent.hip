@@ -348,13 +348,17 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
 //   wave 0    polls the eight hand-off words, picks the action, steps the env, publishes
 // Five workgroup barriers per step; everything another wave needs goes through LDS.
 #define P4_BARRIER() __syncthreads()
-__global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams pp) {
+// NW = waves per graph: 4 (heads in pairs; at most four such workgroups per CU) or 2 (heads in
+// fours; for batches that would not be resident four waves wide)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 4) void decode_persistent4_kernel(PersistParams pp) {
+  constexpr int HPW = 8 / NW;   // heads per wave
   const StepParams &p = pp.s;
   __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
   __shared__ __attribute__((aligned(16))) float u_s[64];
   __shared__ int sel_s[64];                 // compacted list of selectable nodes of the step
   __shared__ unsigned long long wrd_s[8];   // the eight other graphs' mask words of the step
-  __shared__ float mx_s[4];
+  __shared__ float mx_s[NW];
   __shared__ int ctl_s[4];                  // [0] chosen node, [1] 1 = finished / gave up, [2] nsel,
                                             // [3] bits of the vehicle load as fp32 (IRP)
 
@@ -384,17 +388,17 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
   const bool inN = lane < N;
   const int ln = inN ? lane : 0;
   const size_t row = (size_t)b * 8 * N;
-  const int h0 = 2 * wave;   // this wave's two heads
+  const int h0 = HPW * wave;   // this wave's heads
 
   // ---- per-graph state.  Wave 0: the env row (lane = node); every wave: its heads' constants
   const uint8_t *mask0 = p.env.mask + (size_t)(t0 & 1) * B * N;
   int own_mask = mask0[(size_t)b * N + ln];
-  int msk[2];
+  int msk[HPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) msk[j] = mask0[(size_t)((b * 8 + h0 + j) % B) * N + ln];  // QUIRK D3
-  float sld[2], bs[2];
+  for (int j = 0; j < HPW; ++j) msk[j] = mask0[(size_t)((b * 8 + h0 + j) % B) * N + ln];  // QUIRK D3
+  float sld[HPW], bs[HPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < HPW; ++j) {
     sld[j] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + (h0 + j) * N + ln] : 0.f;
     bs[j] = p.base ? p.base[row + (h0 + j) * N + ln] : 0.f;
   }
@@ -407,16 +411,18 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
   double load0 = (p.kind == VRP_KIND_IRP) ? p.env.load[b] : 1.0;
   float accl = p.io.acc_loss[b], accp = p.io.acc_logp[b];
   int last = __builtin_amdgcn_readfirstlane(p.last[b]);
-  float sc[2];  // this step's score rows SL[b][last][h] (requested at the end of the step before)
+  float sc[HPW];  // this step's score rows SL[b][last][h] (requested at the end of the step before)
   {
     const float *srow = p.SL + ((size_t)b * N + last) * 8 * N;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) sc[j] = srow[(h0 + j) * N + ln];
+    for (int j = 0; j < HPW; ++j) sc[j] = srow[(h0 + j) * N + ln];
   }
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
-  constexpr int NB = 2;  // work items in flight
+  // work items in flight.  Four waves wide: one (a wave has at most two passes), which keeps the
+  // kernel at 96 registers = five workgroups per CU: B = 1024 resident with a workgroup per CU to spare
+  constexpr int NB = NW == 4 ? 1 : 2;
   int ta = -1, wb_cur = -1;
   float ret = 0.f;
   double wb_load = 1.0;
@@ -440,14 +446,14 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
     const float q_noise = (!p.sample || wave != 0) ? 1.f
                           : p.io.noise ? p.io.noise[((size_t)t * B + b) * N + ln]
                                        : vrp_exp1_noise(p.io.noise_seed, t, b, ln);
-    // this wave's work items: passes wave, wave + 4 (N <= 63: at most eight passes), chunk-major
-    const int mypass = wave < npass ? ((npass - wave + 3) >> 2) : 0;
+    // this wave's work items: passes wave, wave + NW, ... (N <= 63: at most eight), chunk-major
+    const int mypass = wave < npass ? (npass - wave + NW - 1) / NW : 0;
     const int total = mypass * nchunk;
     float4 rbuf[NB][RT_U];
     int mrow[NB];
     auto load_item = [&](float4 (&r)[RT_U], int w, int &m_out) {
       const int pi = w / nchunk, ch = w - pi * nchunk;
-      const int k = 8 * (wave + 4 * pi) + rsl;
+      const int k = 8 * (wave + NW * pi) + rsl;
       const int m = k < nsel ? sel_s[k] : -1;
       m_out = m;
       rt_load(r, rtb + (size_t)(m < 0 ? 0 : m) * n4, ch * RT_U, cnt, m >= 0);
@@ -487,14 +493,14 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
       P4_BARRIER();
       if (ctl_s[1]) break;   // uniform over the workgroup
 #pragma unroll
-      for (int j = 0; j < 2; ++j) msk[j] = (int)((wrd_s[h0 + j] >> lane) & 1ull);
+      for (int j = 0; j < HPW; ++j) msk[j] = (int)((wrd_s[h0 + j] >> lane) & 1ull);
     }
     // ---- glimpse attention weights of this wave's heads; ONE shift M for all eight heads ----
-    float e[2];
+    float e[HPW];
     {
-      float s[2], mx = -INFINITY;
+      float s[HPW], mx = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < HPW; ++j) {
         float v = sc[j] + bs[j];
         if (p.kind == VRP_KIND_IRP) v = fmaf(loadf, sld[j], v);
         v = inN ? v + (float)msk[j] : -INFINITY;
@@ -504,9 +510,11 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
       const float mw = wave_max(mx);
       if (lane == 0) mx_s[wave] = mw;
       P4_BARRIER();
-      const float M = fmaxf(fmaxf(mx_s[0], mx_s[1]), fmaxf(mx_s[2], mx_s[3]));
+      float M = mx_s[0];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int w2 = 1; w2 < NW; ++w2) M = fmaxf(M, mx_s[w2]);
+#pragma unroll
+      for (int j = 0; j < HPW; ++j) {
         e[j] = inN ? exp_nonpos(s[j] - M) : 0.f;
         float sum = wave_sum(e[j]);
         if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(256) void decode_persistent4_kernel(PersistParams p
       // next step's score rows of this wave's heads: requested now, consumed after the hand-off
       const float *srow = p.SL + ((size_t)b * N + last) * 8 * N;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) sc[j] = srow[(h0 + j) * N + ln];
+      for (int j = 0; j < HPW; ++j) sc[j] = srow[(h0 + j) * N + ln];
     }
     // ---- wave 0 alone: the edge's length (an fp64 square root), accumulators, traces -- while
     // the other three waves already wait at the next step's first barrier
@@ -726,8 +734,8 @@ struct PersistDevice {
   int capacity = -1;             // resident single-wave workgroups, -1 = not measured yet
   int cus = 0;
   int retries = 0;               // censuses thrown away because they looked disturbed
-  int capacity4 = -1;            // resident four-wave workgroups (decode_persistent4_kernel)
-  int retries4 = 0;
+  int capacity4 = -1, capacity2 = -1;   // resident workgroups of decode_persistent4_kernel<4> / <2>
+  int retries4 = 0, retries2 = 0;
   hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
   hipStream_t last_stream = nullptr;  // identity of that launch's stream (compared, never used)
 };
@@ -831,21 +839,27 @@ int vrp_usable_cus() {
   return g_pdev[dev].cus;
 }
 
-// Four-wave workgroups of decode_persistent4_kernel the device keeps resident at once: the same
-// census (every workgroup must see all the others), at most four per compute unit.
-static int persistent4_capacity_of(int dev, hipStream_t capturing_guard) {
+// Workgroups of decode_persistent4_kernel<NW> the device keeps resident at once: the same census
+// (every workgroup must see all the others).
+template <int NW>
+static int persistent_wide_capacity_of(int dev, hipStream_t capturing_guard) {
   if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
   (void)persistent_capacity_of(dev, capturing_guard);   // the usable CUs
   std::lock_guard<std::mutex> guard(g_pdev_lock);
   PersistDevice &pd = g_pdev[dev];
-  if (pd.capacity4 >= 0) return pd.capacity4;
+  int &cap = NW == 4 ? pd.capacity4 : pd.capacity2;
+  int &retries = NW == 4 ? pd.retries4 : pd.retries2;
+  if (cap >= 0) return cap;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
   int per_cu = 0;
   if (pd.cus <= 0 || cs != hipStreamCaptureStatusNone ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_persistent4_kernel, 256, 0) !=
-          hipSuccess) { (void)hipGetLastError(); return 0; }
-  per_cu = per_cu > 4 ? 4 : per_cu;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_persistent4_kernel<NW>, 64 * NW,
+                                                   0) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  per_cu = per_cu > 16 ? 16 : per_cu;
   int32_t *res = nullptr;
   hipStream_t st2 = nullptr;
   if (hipGetSymbolAddress((void **)&res, HIP_SYMBOL(g_residency)) != hipSuccess ||
@@ -855,6 +869,7 @@ static int persistent4_capacity_of(int dev, hipStream_t capturing_guard) {
   }
   if (capturing_guard) (void)hipStreamSynchronize(capturing_guard);
   else (void)hipDeviceSynchronize();
+  const int query = per_cu;
   int measured = 0;
   for (int k = per_cu; k >= 1 && measured == 0; --k) {
     int32_t zero2[2] = {0, 0}, got[2] = {0, 0};
@@ -862,7 +877,7 @@ static int persistent4_capacity_of(int dev, hipStream_t capturing_guard) {
     cp.census = res;
     bool ok2 = hipMemcpyAsync(res, zero2, sizeof(zero2), hipMemcpyHostToDevice, st2) == hipSuccess;
     if (ok2) {
-      hipLaunchKernelGGL(decode_persistent4_kernel, dim3(pd.cus * k), dim3(256), 0, st2, cp);
+      hipLaunchKernelGGL(decode_persistent4_kernel<NW>, dim3(pd.cus * k), dim3(64 * NW), 0, st2, cp);
       ok2 = hipGetLastError() == hipSuccess;
     }
     ok2 = ok2 && hipMemcpyAsync(got, res, sizeof(got), hipMemcpyDeviceToHost, st2) == hipSuccess;
@@ -871,28 +886,39 @@ static int persistent4_capacity_of(int dev, hipStream_t capturing_guard) {
     if (got[1] == pd.cus * k) measured = pd.cus * k;
   }
   (void)hipStreamDestroy(st2);
-  if (measured < pd.cus * (per_cu - 1) && pd.retries4 < 4) { ++pd.retries4; return measured; }
-  pd.capacity4 = measured;
+  if (measured < pd.cus * (query - 1) && retries < 4) { ++retries; return measured; }
+  cap = measured;
   return measured;
 }
 
-// four waves per graph where the batch is small enough for every such workgroup to be resident
-bool vrp_persistent4_eligible(int kind, int B, int N, int max_steps, int flags,
-                              const vrp_rollout_io *io, hipStream_t st) {
-  static const bool off = getenv("VRP_PERSISTENT_ONE_WAVE") != nullptr;   // A/B aid
-  if (off || !vrp_persistent_eligible(kind, B, N, max_steps, flags, io, st)) return false;
+// waves per graph of the persistent launch: 4 where every four-wave workgroup of the batch is
+// resident, else 2, else 1 (decode_persistent_kernel)
+int vrp_persistent_width(int kind, int B, int N, int max_steps, int flags, const vrp_rollout_io *io,
+                         hipStream_t st) {
+  if (!vrp_persistent_eligible(kind, B, N, max_steps, flags, io, st)) return 0;
+  const char *forced = getenv("VRP_PERSISTENT_WAVES");   // tests, A/B: "1", "2" or "4" (read per call)
+  if (forced && forced[0] == '1') return 1;
   static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;
-  if (force) return B <= 1024;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return B <= persistent4_capacity_of(dev, st);
+  if (!force && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1; }
+  // One workgroup per CU of slack below the measured capacity: at 128 registers four waves fill a
+  // SIMD's register file exactly, and a grid sized to the last slot (B = 2048 two waves wide:
+  // 8 workgroups on every CU) stopped being resident as soon as another stream's kernels had
+  // fragmented a register file -- tests/test_gpu_persistent_guard.py, two streams: timeouts.
+  const int cus = force ? 0 : vrp_usable_cus();
+  if (!(forced && forced[0] == '2'))
+    if (force ? B <= 768 : B <= persistent_wide_capacity_of<4>(dev, st) - cus) return 4;
+  if (forced && forced[0] == '4') return 1;   // asked for four, not resident: the one-wave kernel
+  if (force ? B <= 1792 : B <= persistent_wide_capacity_of<2>(dev, st) - cus) return 2;
+  return 1;
 }
 
 extern "C" int vrp_persistent_capacity(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   const int c = persistent_capacity_of(dev, nullptr);
-  (void)persistent4_capacity_of(dev, nullptr);   // measured at the same quiet moment
+  (void)persistent_wide_capacity_of<4>(dev, nullptr);   // measured at the same quiet moment
+  (void)persistent_wide_capacity_of<2>(dev, nullptr);
   return c;
 }
 
@@ -959,7 +985,7 @@ int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStr
 
 // steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
-                                bool four_waves) {
+                                int waves) {
   DecWs ws = carve_decws(workspace, sp.B, sp.N);
   PersistParams pp;
   pp.s = sp;
@@ -973,7 +999,8 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
   void *token = nullptr;
   vrp_persistent_serialize_begin(st, &token);
-  if (four_waves) hipLaunchKernelGGL(decode_persistent4_kernel, dim3(sp.B), dim3(256), 0, st, pp);
+  if (waves == 4) hipLaunchKernelGGL(decode_persistent4_kernel<4>, dim3(sp.B), dim3(256), 0, st, pp);
+  else if (waves == 2) hipLaunchKernelGGL(decode_persistent4_kernel<2>, dim3(sp.B), dim3(128), 0, st, pp);
   else hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
   if (int r = vrp_launch_persistent_finalize(sp, workspace, st)) return r;

@@ -74,9 +74,9 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
                              const vrp_rollout_io *io, hipStream_t st);
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
-                                bool four_waves = false);
-bool vrp_persistent4_eligible(int kind, int B, int N, int max_steps, int flags,
-                              const vrp_rollout_io *io, hipStream_t st);
+                                int waves = 1);
+int vrp_persistent_width(int kind, int B, int N, int max_steps, int flags, const vrp_rollout_io *io,
+                         hipStream_t st);
 int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st);
 void vrp_persistent_serialize_begin(hipStream_t st, void **token);
 void vrp_persistent_serialize_end(hipStream_t st, void *token);

@@ -1987,6 +1987,9 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
       ep.hist[(size_t)t * B + g0 + g] = 0ull;
     }
     if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
+    // (round 4, measured and removed: Wq_g g + bq computed here -- one thread per output, the
+    // weight row from L2 -- instead of the 6-us GEMM launch in front of the prologue: 0.284 vs
+    // 0.280 ms per rollout; the kernel's tail is on the critical path of all 256 workgroups)
     if (ep.warm) {
       // workgroups b, b + 8, ... share an XCD: together they touch every 128-byte line once
       const int per_xcd = (gridDim.x + 7) >> 3, slot = blockIdx.x >> 3;
