@@ -355,7 +355,7 @@ int vrp_gemm_nt_gated(const float *A, int lda, const float *W, int ldw, const fl
  * for every input word. */
 int vrp_debug_exp1_from_bits(const uint32_t *bits, float *out, int n, void *stream);
 
-/* First 16 hex digits of the sha256 over the kernel sources (csrc/*.hip, *.h, this header) the
+/* First 16 hex digits of the sha256 over the kernel sources (every .hip and .h under csrc/, this header) the
  * library was built from: ties a measurement kept under profiles/ to the build it was taken on. */
 const char *vrp_source_hash(void);
 

@@ -1228,6 +1228,37 @@ def test_persistent_steps_equal_per_step_launches(kind, B, N, greedy, train):
         assert last_move.min() < last_move.max()
 
 
+@pytest.mark.parametrize("kind,B,N,greedy", [(1, 64, 100, False), (2, 3000, 40, False),
+                                             (1, 3000, 40, True), (2, 16, 30, False)])
+def test_paced_step_loop_equals_fixed_length_loop(kind, B, N, greedy):
+    """vrp_rollout_steps_range stops queueing per-step launches once the device reports the
+    batch finished (a pinned flag word per chunk of eight steps, from step N - 1 on) instead of
+    queueing all 2 (N - 1): everything a caller can read must equal the fixed-length loop's
+    (VRP_NO_THROTTLE=1), including the step count and the per-step done flags."""
+    from agents import runtime
+    env = _envs()[kind](N, B, 1, 21)
+    steps = runtime.max_steps_for(kind, N)
+    noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(5))
+    out = []
+    for off in (True, False):
+        if off:
+            os.environ["VRP_NO_THROTTLE"] = "1"
+        else:
+            os.environ.pop("VRP_NO_THROTTLE", None)
+        try:
+            e = deepcopy(env)
+            a = _agents()[kind](seed=69)
+            with torch.no_grad():
+                r = runtime.rollout(a.model, e, greedy, noise=None if greedy else noise, record=True,
+                                    step_trace=True, persistent=False)
+            r.T
+        finally:
+            os.environ.pop("VRP_NO_THROTTLE", None)
+        out.append((r, e))
+    _persistent_equal(kind, B, steps, out[0], out[1])
+    assert out[0][0].T < steps or greedy   # sampled tours end early: the case the pacing is for
+
+
 def test_training_reaches_the_reference_cost_level(tmp_path):
     """Solution quality, not just throughput: train_models.py's TSP-20 setting (batch 256, seed
     69, Adam 1e-4, rollout baseline with the paired t-test) for 300 of its 851 epochs, then

@@ -31,6 +31,40 @@ __global__ void rollout_init_kernel(float *acc_loss, float *acc_logp, int32_t *n
   if (i < nflags) notdone[i] = 0;
 }
 
+// Host-side pacing of the per-step launch loop (vrp_rollout_steps_range): four pinned flag words
+// and their events per host thread and device.
+#define STEP_CHUNK 8
+struct StepThrottle {
+  int32_t *flags = nullptr;   // hipHostMalloc: [4]
+  hipEvent_t ev[4] = {};
+  int dev = -1;
+};
+static StepThrottle *step_throttle(hipStream_t st) {
+  if (getenv("VRP_NO_THROTTLE")) return nullptr;   // read per call: tests and A/B runs flip it
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VRP_MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
+  static thread_local StepThrottle per_dev[VRP_MAX_DEVICES];
+  StepThrottle &t = per_dev[dev];
+  if (t.dev != dev) {
+    if (hipHostMalloc((void **)&t.flags, 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    for (int i = 0; i < 4; ++i)
+      if (hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+    t.dev = dev;
+  }
+  return &t;
+}
+
 extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                                        const vrp_decoder_weights *dw, const vrp_env *env,
                                        const float *emb, void *dec_workspace,
@@ -77,10 +111,44 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                                                 max_steps, flags);
     return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream, pwaves);
   }
-  for (int t = t_begin; t < t_end; ++t)
+  // One launch per step.  A VRP / IRP episode is over after anything between N - 1 and 2 (N - 1)
+  // steps (tsp.py:95: the batch-wide done flag), and a launch queued behind the end leaves at its
+  // first instruction -- but still costs its 3-4 us (VRP-100 x 2048 sampling: 86 of 198 launches,
+  // 0.35 ms per rollout).  So from step N - 1 on the host stays at most two chunks of STEP_CHUNK
+  // launches ahead of the device: the flag of a chunk's last step comes back through a pinned
+  // word, and the loop stops at the first chunk the device reports finished (at most
+  // 2 STEP_CHUNK - 1 empty launches).  Off while the stream is being captured into a hipGraph
+  // (the fixed-length loop is what a graph needs) and with VRP_NO_THROTTLE set (A/B).
+  StepThrottle *th = nullptr;
+  const int tmin = env->N - 1;
+  if (kind != VRP_KIND_TSP && t_end == max_steps && t_begin <= tmin &&
+      max_steps - tmin >= 2 * STEP_CHUNK && io->notdone && !(flags & VRP_STEP_DECODE_ONLY))
+    th = step_throttle((hipStream_t)stream);
+  int queued = 0;   // checkpoints recorded so far
+  for (int t = t_begin; t < t_end; ++t) {
+    if (th && t >= tmin + 2 * STEP_CHUNK && (t - tmin) % STEP_CHUNK == 0) {
+      // checkpoint i = (t - tmin) / STEP_CHUNK - 2 covers step tmin + STEP_CHUNK (i + 1) - 1
+      const int i = (t - tmin) / STEP_CHUNK - 2;
+      if (i < queued) {
+        if (hipEventSynchronize(th->ev[i % 4]) != hipSuccess) { (void)hipGetLastError(); th = nullptr; }
+        else if (th->flags[i % 4] == 0) break;   // that step found every graph finished
+      }
+    }
     if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, t, max_steps,
                                 flags, stream))
       return r;
+    if (th && t >= tmin && (t - tmin + 1) % STEP_CHUNK == 0) {
+      const int i = queued % 4;
+      if (hipMemcpyAsync(&th->flags[i], io->notdone + t, sizeof(int32_t), hipMemcpyDeviceToHost,
+                         (hipStream_t)stream) != hipSuccess ||
+          hipEventRecord(th->ev[i], (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        th = nullptr;
+      } else {
+        ++queued;
+      }
+    }
+  }
   return 0;
 }
 

@@ -350,8 +350,14 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
 #define P4_BARRIER() __syncthreads()
 // NW = waves per graph: 4 (heads in pairs; at most four such workgroups per CU) or 2 (heads in
 // fours; for batches that would not be resident four waves wide)
+#ifndef P2_WAVES
+#define P2_WAVES 4   // waves per SIMD the two-wave instance is compiled for (A/B: 5 = 96 registers)
+#endif
+#ifndef P2_NB
+#define P2_NB 2      // its table-row work items in flight
+#endif
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 4) void decode_persistent4_kernel(PersistParams pp) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persistent4_kernel(PersistParams pp) {
   constexpr int HPW = 8 / NW;   // heads per wave
   const StepParams &p = pp.s;
   __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 4) void decode_persistent4_k
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
   // work items in flight.  Four waves wide: one (a wave has at most two passes), which keeps the
   // kernel at 96 registers = five workgroups per CU: B = 1024 resident with a workgroup per CU to spare
-  constexpr int NB = NW == 4 ? 1 : 2;
+  constexpr int NB = NW == 4 ? 1 : P2_NB;
   int ta = -1, wb_cur = -1;
   float ret = 0.f;
   double wb_load = 1.0;
@@ -729,7 +735,6 @@ __global__ __launch_bounds__(64) void cu_census_kernel() {
   __builtin_amdgcn_s_sleep(64);  // stay a moment: the dispatcher moves on to the other CUs
 }
 
-#define VRP_MAX_DEVICES 64
 struct PersistDevice {
   int capacity = -1;             // resident single-wave workgroups, -1 = not measured yet
   int cus = 0;

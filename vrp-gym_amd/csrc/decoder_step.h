@@ -4,6 +4,7 @@
 #include "env_device.h"
 #include "decoder_ws.h"
 
+#define VRP_MAX_DEVICES 64   // per-device host-side state (residency census, launch pacing)
 struct StepParams {
   int kind, B, N, t, max_steps, sample, decode_only;
   const float *emb;
