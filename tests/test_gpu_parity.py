@@ -40,6 +40,14 @@ def _agents():
     return {0: agents.TSPAgent, 1: agents.VRPAgent, 2: agents.IRPAgent}
 
 
+def _arch_kw(z):
+    """Agent kwargs of a fixture taken on a non-default architecture (tests/golden/arch*:
+    hidden_dim not a multiple of the kernels' 128-wide slices, other layer counts)."""
+    if "hidden" not in z.files:
+        return {}
+    return dict(hidden_dim=int(z["hidden"]), num_attention_layers=int(z["layers"]))
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _gpu():
     assert torch.cuda.is_available(), "these tests need the MI355X"
@@ -561,6 +569,50 @@ def test_rollout_against_reference(name, path, mode):
                      table_kernel=mode in ("table", "table_wide"))
 
 
+@pytest.mark.parametrize("mode", ["default", "table", "fused"])
+@pytest.mark.parametrize("name,path", _load("archrollout_*.npz"))
+def test_non_default_architecture_against_reference(name, path, mode):
+    """The reference's agent kwargs `hidden_dim` / `num_attention_layers`
+    (graph_tsp_agent.py:96-106, graph_encoder.py:6-39) at values the kernels' 128-wide
+    feed-forward slices do not divide (200, 64, 520, 300) and at 1, 2 and 4 layers: the
+    constructor yields the reference's weights, and the reference's recorded episode is
+    reproduced through the stack kernel / per-layer kernels and every step kernel."""
+    import hashlib
+    z = np.load(path)
+    kind = int(z["kind"])
+    agent = _agents()[kind](seed=69, **_arch_kw(z))
+    h = hashlib.sha256()
+    for k, v in agent.model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().numpy().tobytes())
+    assert h.hexdigest()[:16] == str(z["sd_hash"])
+    _compare_rollout(kind, int(z["B"]), int(z["N"]), bool(z["greedy"]), 69, 69,
+                     int(z["torch_seed"]), ref_actions=z["actions"], ref_loss=z["acc_loss"],
+                     ref_logp=z["acc_logp"], ref_T=int(z["T"]), table_kernel=mode == "table",
+                     fused=mode == "fused", agent=agent)
+
+
+@pytest.mark.parametrize("hidden,layers,B,N", [(200, 2, 600, 40), (72, 5, 300, 80), (520, 1, 64, 20)])
+def test_non_default_architecture_encoder_large(hidden, layers, B, N):
+    """... and through the large-batch encoder kernels (persistent 80-row block kernel behind
+    the fused in_proj + attention kernels, eval mode; GEMM + BatchNorm kernels, train mode)
+    against the oracle."""
+    from oracle import policy as opol
+    import agents
+    agent = agents.VRPAgent(seed=69, hidden_dim=hidden, num_attention_layers=layers)
+    sd = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+    g = torch.Generator().manual_seed(B * N)
+    x = torch.rand(B, N, 2, generator=g)
+    dm = torch.zeros(B, N, dtype=torch.bool)
+    dm[torch.arange(B), torch.randint(0, N, (B,), generator=g)] = True
+    for train in (False, True):
+        agent.model.encoder.train(train)
+        emb = agent.model.encoder(x, dm)
+        want = opol.encoder_forward(sd, x, dm, train=train)
+        err = (emb.cpu() - want).abs().max().item()
+        assert err < 2e-5, (hidden, layers, B, N, train, err)
+
+
 @pytest.mark.parametrize("mode", ["default", "table", "tile"])
 @pytest.mark.parametrize("name,path", _load("trainrollout_*.npz"))
 def test_train_mode_rollout_against_reference(name, path, mode):
@@ -757,7 +809,7 @@ def test_graph_replay_equals_eager():
     assert nb1 - nb0 == 3
 
 
-@pytest.mark.parametrize("name,path", _load("trainstep_*.npz"))
+@pytest.mark.parametrize("name,path", _load("trainstep_*.npz") + _load("archstep_*.npz"))
 def test_training_step_against_reference(name, path):
     """One REINFORCE step (agent.step(env,(False,True)) + backward) on the reference's
     inputs: sampled actions identical (host noise = the reference's CPU stream), loss, T and
@@ -769,9 +821,9 @@ def test_training_step_against_reference(name, path):
     kind, B, N = int(z["kind"]), int(z["B"]), int(z["N"])
     if int(z["env_first"]):
         env = _envs()[kind](N, B, 1, 69)
-        agent = _agents()[kind](seed=69)
+        agent = _agents()[kind](seed=69, **_arch_kw(z))
     else:
-        agent = _agents()[kind](seed=69)
+        agent = _agents()[kind](seed=69, **_arch_kw(z))
         env = _envs()[kind](N, B, 1, 69)
     agent.model.train()
     agent.model.sampling_noise = agent.target_model.sampling_noise = "host"
@@ -807,7 +859,30 @@ def test_training_step_against_reference(name, path):
         assert abs(tot - pins[2]) < 1e-3 * pins[2]
     nb = agent.model.encoder.attention_layers[0].bn1.norm.num_batches_tracked.item()
     assert nb == 1  # exactly one train-mode encoder pass per step, like the reference
+    if "ff0_grad_last" in z.files:
+        # zero-padded feed-forward width: the real part of the padded gradients, element-wise
+        layers = agent.model.encoder.attention_layers
+        for got_g, want_g in ((layers[len(layers) - 1].ff[0].weight.grad, z["ff0_grad_last"]),
+                              (layers[0].ff[2].weight.grad, z["ff2_grad_first"])):
+            assert got_g.shape == want_g.shape
+            err = np.max(np.abs(got_g.cpu().numpy() - want_g))
+            assert err <= 2e-3 * np.max(np.abs(want_g)) + 2e-6 * float(z["grad_total"]), err
     agent.opt.step()
+    if "ff0_grad_last" in z.files:
+        # the shadows follow the optimizer step: a rollout on the updated weights equals the
+        # oracle's on the same state dict
+        from oracle import envs as oenv
+        from oracle import policy as opol
+        from agents import runtime
+        sd = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+        agent.model.eval()
+        e2 = _envs()[kind](N, B, 1, 7)
+        with torch.no_grad():
+            res = runtime.rollout(agent.model, e2, True)
+            ol, olp, T = opol.rollout(sd, oenv.OracleEnv(kind, N, B, 1, 7), True)
+        assert res.T == T
+        assert (res.acc_loss.cpu() - ol).abs().max().item() < 1e-5
+        assert (res.acc_logp.cpu() - olp).abs().max().item() < 1e-5 * max(1, T / 4)
 
 
 def test_train_loop_csv_and_checkpoints(tmp_path):

@@ -111,10 +111,16 @@ def test_decoder_teacher_forced(name, z):
         ep.advance(idx)
 
 
-@pytest.mark.parametrize("name,z", _load("rollout_*.npz"))
+def _arch(z):
+    """hidden_dim / num_attention_layers of a fixture taken on a non-default architecture
+    (tests/golden/arch*: tools/make_golden.py `arch`), {} for the reference's defaults."""
+    return dict(hidden=int(z["hidden"]), layers=int(z["layers"])) if "hidden" in z.files else {}
+
+
+@pytest.mark.parametrize("name,z", _load("rollout_*.npz") + _load("archrollout_*.npz"))
 def test_rollout(name, z):
     kind, B, N, greedy = int(z["kind"]), int(z["B"]), int(z["N"]), bool(z["greedy"])
-    sd, _ = opol.init_state_dicts(kind, 69)
+    sd, _ = opol.init_state_dicts(kind, 69, **_arch(z))
     env = oenv.OracleEnv(kind, N, B, 1, 69)
     torch.manual_seed(int(z["torch_seed"]))
     trace = []
@@ -182,7 +188,7 @@ def test_reference_env_kats():
     assert r[0] == -5
 
 
-@pytest.mark.parametrize("name,z", _load("trainstep_*.npz"))
+@pytest.mark.parametrize("name,z", _load("trainstep_*.npz") + _load("archstep_*.npz"))
 def test_training_step(name, z):
     """One REINFORCE step of the reference (agent.step(env, (False, True)) + backward,
     graph_tsp_agent.py:174-186, 227-255) through the oracle with torch autograd: sampled
@@ -194,9 +200,9 @@ def test_training_step(name, z):
     env_first = int(z["env_first"]) if "env_first" in z.files else 0
     if env_first:
         env = oenv.OracleEnv(kind, N, B, 1, 69)
-        sd, tsd = opol.init_state_dicts(kind, 69)
+        sd, tsd = opol.init_state_dicts(kind, 69, **_arch(z))
     else:
-        sd, tsd = opol.init_state_dicts(kind, 69)
+        sd, tsd = opol.init_state_dicts(kind, 69, **_arch(z))
         env = oenv.OracleEnv(kind, N, B, 1, 69)
     if int(z["torch_seed"]) >= 0:
         torch.manual_seed(int(z["torch_seed"]))

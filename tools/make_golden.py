@@ -543,6 +543,69 @@ def gen_train_step():
                  grad_norms=np.array(list(gn.values())), grad_total=tot, post_adam_sha=post)
 
 
+# ---------------------------------------------------------------- (ix) non-default architecture
+def gen_arch():
+    """The reference run with feed-forward widths that are not multiples of the kernels'
+    128-wide slices and with other layer counts (agent kwargs hidden_dim / num_attention_layers,
+    graph_tsp_agent.py:96-106): one episode (rollout_* format) and one training step
+    (trainstep_* format) per case."""
+    print("[arch]")
+    for kind, hidden, layers, B, N, greedy in [(0, 200, 2, 16, 12, True), (1, 64, 3, 16, 12, False),
+                                               (2, 520, 1, 16, 12, True), (1, 300, 4, 24, 20, True)]:
+        kw = dict(hidden_dim=hidden, num_attention_layers=layers, seed=69)
+        ag = REF_AGENT[kind](**kw)
+        env = REF_ENV[kind](N, B, 1, 69)
+        ag.model.eval()
+        acts = []
+        orig_step = env.step
+
+        def rec_step(a, _o=orig_step, _acts=acts):
+            _acts.append(np.array(a)[:, 0].copy())
+            return _o(a)
+
+        env.step = rec_step
+        torch.manual_seed(77)
+        with torch.no_grad():
+            loss, logp = ag.model(env, greedy)
+        sd, _ = opol.init_state_dicts(kind, 69, hidden=hidden, layers=layers)
+        assert sd_hash(sd) == sd_hash(ag.model.state_dict())
+        oe = oenv.OracleEnv(kind, N, B, 1, 69)
+        torch.manual_seed(77)
+        with torch.no_grad():
+            ol, olp, T = opol.rollout(sd, oe, greedy, forced=np.array(acts))
+        el, ep = (ol - loss).abs().max().item(), (olp - logp).abs().max().item()
+        print(f"   kind={kind} hidden={hidden} layers={layers} B={B} N={N} greedy={greedy}: "
+              f"T={len(acts)} |dloss|={el:.2e} |dlogp|={ep:.2e} sd={sd_hash(sd)}")
+        assert el < 1e-5 and ep < 1e-5 * max(1, len(acts) / 4)
+        tag = f"k{kind}_h{hidden}_l{layers}"
+        save(f"archrollout_{tag}", kind=kind, hidden=hidden, layers=layers, B=B, N=N,
+             greedy=greedy, torch_seed=77, T=len(acts), actions=np.array(acts),
+             acc_loss=loss.numpy(), acc_logp=logp.numpy(), sd_hash=sd_hash(sd))
+        # one training step, as gen_train_step records it
+        ag = REF_AGENT[kind](**kw)
+        env = REF_ENV[kind](N, B, 1, 69)
+        ag.model.train()
+        torch.manual_seed(31)
+        loss_m, loss_b, logp = ag.step(env, (False, True))
+        T = int(env.step_count)
+        tl = (((loss_m - loss_b) * -1) * logp).mean()
+        ag.opt.zero_grad()
+        tl.backward()
+        gn = {k: (p.grad.norm().item() if p.grad is not None else -1.0)
+              for k, p in ag.model.named_parameters()}
+        tot = math_sqrt(sum(v * v for v in gn.values() if v >= 0))
+        ff0 = ag.model.encoder.attention_layers[layers - 1].ff[0].weight.grad.numpy().copy()
+        ff2 = ag.model.encoder.attention_layers[0].ff[2].weight.grad.numpy().copy()
+        ag.opt.step()
+        print(f"      training step: loss={tl.item():.6f} T={T} gradnorm={tot:.5f}")
+        save(f"archstep_{tag}", kind=kind, hidden=hidden, layers=layers, B=B, N=N, torch_seed=31,
+             env_first=0, loss=tl.item(), T=T, loss_m=loss_m.detach().numpy(),
+             loss_b=loss_b.numpy(), logp=logp.detach().numpy(),
+             grad_keys=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values())),
+             grad_total=tot, post_adam_sha=sd_hash(ag.model.state_dict()),
+             ff0_grad_last=ff0, ff2_grad_first=ff2)
+
+
 def math_sqrt(x):
     import math
     return math.sqrt(x)
@@ -551,11 +614,11 @@ def math_sqrt(x):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["kats", "instances", "envtraces", "weights", "encoder",
-                             "decoder", "rollouts", "trainstep", "trainrollouts"]
+                             "decoder", "rollouts", "trainstep", "trainrollouts", "arch"]
     table = {"kats": gen_kats, "instances": gen_instances, "envtraces": gen_env_traces,
              "weights": gen_weight_hashes, "encoder": gen_encoder, "decoder": gen_decoder,
              "rollouts": gen_rollouts, "trainstep": gen_train_step,
-             "trainrollouts": gen_train_rollouts}
+             "trainrollouts": gen_train_rollouts, "arch": gen_arch}
     for w in which:
         table[w]()
     print("done")

@@ -21,10 +21,42 @@ ROLLOUT_LOG = None    # bench.py: a list collecting every RolloutResult (step ac
 
 
 def check_supported_dims(emb_dim, num_heads, hidden_dim, decoder=False):
-    """The kernels are specialised for the reference's architecture (emb 128, 8 heads,
-    hidden a multiple of 128).  Other sizes can be constructed (state_dict
-    compatibility) but not run."""
-    return emb_dim == EMB and num_heads == HEADS and (hidden_dim is None or hidden_dim % 128 == 0)
+    """The kernels are specialised for the reference's embedding width and head count (128, 8);
+    any `hidden_dim` >= 1 and up to eight attention layers run (a feed-forward width that is not
+    a multiple of the kernels' 128-wide slices is zero-padded to the next one, see
+    `_PaddedFF`).  Other sizes can be constructed (state_dict compatibility) but not run."""
+    return emb_dim == EMB and num_heads == HEADS and (hidden_dim is None or hidden_dim >= 1)
+
+
+class _PaddedFF:
+    """Feed-forward weights of one encoder layer, zero-padded from `hidden` to the next multiple
+    of 128 (graph_encoder.py:177-181 allows any width; the kernels walk the hidden dimension in
+    128-wide slices).  Exact, not approximate: a padded hidden unit is relu(0 . y + 0) = 0, adds
+    0 . W2 = +0.0 to every output, and receives a zero gradient.  The shadows are refreshed when
+    the parameters' version counters move (optimizer step, load_state_dict); the backward
+    kernels write padded gradients, of which the real part is copied out."""
+
+    def __init__(self, layer, hp, dev):
+        self.ff0, self.ff2 = layer.ff[0], layer.ff[2]
+        h = self.ff0.weight.shape[0]
+        self.h, self.hp = h, hp
+        self.w0 = torch.zeros((hp, EMB), dtype=torch.float32, device=dev)
+        self.b0 = torch.zeros((hp,), dtype=torch.float32, device=dev)
+        self.w2 = torch.zeros((EMB, hp), dtype=torch.float32, device=dev)
+        self.g_w0 = torch.zeros((hp, EMB), dtype=torch.float32, device=dev)
+        self.g_b0 = torch.zeros((hp,), dtype=torch.float32, device=dev)
+        self.g_w2 = torch.zeros((EMB, hp), dtype=torch.float32, device=dev)
+        self.version = None
+
+    def sync(self):
+        ver = (self.ff0.weight._version, self.ff0.bias._version, self.ff2.weight._version,
+               self.ff0.weight.data_ptr(), self.ff2.weight.data_ptr())
+        if ver != self.version:
+            with torch.no_grad():
+                self.w0[: self.h].copy_(self.ff0.weight)
+                self.b0[: self.h].copy_(self.ff0.bias)
+                self.w2[:, : self.h].copy_(self.ff2.weight)
+            self.version = ver
 
 
 def invalidate(module):
@@ -84,17 +116,19 @@ def workspaces(model, env):
 def encoder_struct(enc):
     hit = _struct_cache.get(enc)
     if hit is not None:
+        for pad in hit[2]:
+            pad.sync()
         return hit[0]
     node_dim, emb, hidden, heads = enc._dims
     if not check_supported_dims(emb, heads, hidden):
         raise NotImplementedError(
-            f"HIP encoder is built for emb_dim=128, num_heads=8, hidden%128==0 "
-            f"(got {emb}, {heads}, {hidden})")
+            f"HIP encoder is built for emb_dim=128, num_heads=8 (got {emb}, {heads})")
+    hp = (hidden + 127) // 128 * 128
     w = hip.EncoderWeights()
-    w.node_dim, w.hidden, w.num_layers = node_dim, hidden, len(enc.attention_layers)
+    w.node_dim, w.hidden, w.num_layers = node_dim, hp, len(enc.attention_layers)
     if w.num_layers > 8:
         raise NotImplementedError("at most 8 attention layers")
-    keep = []
+    keep, padded = [], []
 
     def P(t):
         assert t.dtype in (torch.float32, torch.int64) and t.is_contiguous()
@@ -116,10 +150,23 @@ def encoder_struct(enc):
             setattr(L, tag + "_running_mean", P(bn.running_mean))
             setattr(L, tag + "_running_var", P(bn.running_var))
             setattr(L, tag + "_num_batches_tracked", P(bn.num_batches_tracked))
-        L.ff0_weight, L.ff0_bias = P(layer.ff[0].weight), P(layer.ff[0].bias)
-        L.ff2_weight, L.ff2_bias = P(layer.ff[2].weight), P(layer.ff[2].bias)
-    _struct_cache[enc] = (w, keep)
+        if hp != hidden:
+            pad = _PaddedFF(layer, hp, layer.ff[0].weight.device)
+            pad.sync()
+            padded.append(pad)
+            L.ff0_weight, L.ff0_bias, L.ff2_weight = P(pad.w0), P(pad.b0), P(pad.w2)
+        else:
+            L.ff0_weight, L.ff0_bias = P(layer.ff[0].weight), P(layer.ff[0].bias)
+            L.ff2_weight = P(layer.ff[2].weight)
+        L.ff2_bias = P(layer.ff[2].bias)
+    _struct_cache[enc] = (w, keep, padded)
     return w
+
+
+def padded_ff(enc):
+    """The `_PaddedFF` shadows of an encoder whose hidden_dim is not a multiple of 128 ([] else)."""
+    encoder_struct(enc)
+    return _struct_cache[enc][2]
 
 
 def decoder_struct(dec):
@@ -143,7 +190,7 @@ def decoder_struct(dec):
     w.out_proj_weight, w.out_proj_bias = P(att.out_proj.weight), P(att.out_proj.bias)
     w.kp_weight, w.att_output_weight = P(dec._kp.weight), P(dec._att_output.weight)
     w.context_proj_weight = P(dec._context_proj.weight)
-    _struct_cache[dec] = (w, keep)
+    _struct_cache[dec] = (w, keep, [])
     return w
 
 
@@ -388,6 +435,7 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
         _graphs.pop(key)  # id() reuse after garbage collection
         return _graph_rollout(model, env, greedy, train, tile_kernel, dev)
     decoder_derived(model.decoder, env.KIND)  # in-place refresh if the weights changed
+    encoder_struct(model.encoder)             # likewise the zero-padded feed-forward shadows
     if cap.noise is not None:
         cap.noise.exponential_(1)
     cap.graph.replay()
@@ -626,6 +674,10 @@ def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb, out=None):
              for p in params]
     g = hip.EncoderGrads()
     ptrs = [hip.ptr(t) for t in grads]
+    pads = padded_ff(enc)
+    for l, pad in enumerate(pads):   # ff.0.weight, ff.0.bias, ff.2.weight: padded gradients
+        ptrs[4 + 12 * l + 6], ptrs[4 + 12 * l + 7], ptrs[4 + 12 * l + 8] = (
+            pad.g_w0.data_ptr(), pad.g_b0.data_ptr(), pad.g_w2.data_ptr())
     g.node_embed_weight, g.node_embed_bias, g.depot_embed_weight, g.depot_embed_bias = ptrs[:4]
     names = [n for n, _ in hip._lib.EncoderLayerGrads._fields_]
     for l in range(w.num_layers):
@@ -637,6 +689,10 @@ def encoder_backward(enc, x3, depot_mask_u8, tape, d_emb, out=None):
     hip.check(lib.vrp_encoder_backward(C.byref(w), C.byref(g), B, N, x3.data_ptr(),
                                        hip.ptr(depot_mask_u8), tape.data_ptr(), d_emb.data_ptr(),
                                        ws.data_ptr(), hip.current_stream(dev)))
+    for l, pad in enumerate(pads):
+        grads[4 + 12 * l + 6].copy_(pad.g_w0[: pad.h])
+        grads[4 + 12 * l + 7].copy_(pad.g_b0[: pad.h])
+        grads[4 + 12 * l + 8].copy_(pad.g_w2[:, : pad.h])
     return params, grads
 
 
