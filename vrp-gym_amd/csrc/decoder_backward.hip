@@ -324,6 +324,331 @@ __global__ __launch_bounds__(256) void db_attn_bwd_kernel(int B, int N, int T,
   }
 }
 
+// ------------------------------------------------------------------ glimpse attention on the matrix cores
+// N <= 48 (three 16-node tiles; the training configurations run N = 40): ONE WAVE per (graph,
+// head), no LDS, no barrier -- every product of the forward and of the backward is a chain of
+// v_mfma_f32_16x16x4_f32 over 16-step tiles of the episode.  The VALU kernels above are bound by
+// LDS bandwidth (per step and wave ~50 ds_read_b128 of K_h / V_h rows and broadcast q / dO rows:
+// 1.2 ms of a 18.5 ms VRP-40 x 2048 epoch); here K_h and V_h sit in registers as MFMA operands for
+// the whole episode.  Lane (c, g) = (lane & 15, lane >> 4).  The inner index of every product is
+// permuted the same way for both operands (an MFMA k-step hands lane group g ONE inner index; any
+// bijection works), chosen so that the accumulator layout of one product IS an operand of the
+// next:
+//   "row" fragments   X[16 tile + c][12 g + s],   s = 0..11   three 16-byte loads of a row piece
+//   "col" fragments   X[16 tile + 4 g + i][16 dt + c], i < 4  one dword each
+//   D of a product    D[4 g + i][c]
+// Forward:  S^T(tn)  = K(row) Q(row)^T       -> lane (t = c) holds n = 16 tn + 4 g + i: softmax over
+//                                               n in the lane + two xor steps; a^T IS the B operand of
+//           O^T(dt)  = V(col) a^T            -> lane (t = c) holds d = 16 dt + 4 g + i: 16-byte store.
+// Backward: dA^T(tn) = V(row) dO(row)^T      -> ds^T in the layout of a^T above (a re-read so),
+//           dQ^T(dt) = K(col) ds^T           -> 16-byte stores;
+//           dA(tn)   = dO(row) V(row)^T      -> the same registers, operands swapped: lane (n = c)
+//                                               holds t = 4 g + i, the B operand (inner index t) of
+//           dK^T(dt,tn) += Q(col) ds,  dV^T(dt,tn) += dO(col) a     (a re-read in this layout)
+// accumulated over the episode's tiles in registers: lane (n = c) ends with four consecutive d.
+// Steps beyond T and nodes beyond N are zero operands.  Same mathematics as the VALU kernels,
+// another summation order; deterministic (no atomics).
+typedef float db_f4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ void db_load_row_frag(float (&f)[NT][12], const float *base, int b, int N,
+                                                 int h, int c, int g) {
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int n = 16 * tn + c;
+    const bool on = n < N;
+    const float4 *src = reinterpret_cast<const float4 *>(
+        base + ((size_t)b * N + (on ? n : 0)) * VRP_D + h * VRP_HD + 12 * g);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float4 v = on ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      f[tn][4 * k] = v.x; f[tn][4 * k + 1] = v.y; f[tn][4 * k + 2] = v.z; f[tn][4 * k + 3] = v.w;
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void db_load_col_frag(float (&f)[NT][4][3], const float *base, int b, int N,
+                                                 int h, int c, int g) {
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = 16 * tn + 4 * g + i;
+      const bool on = n < N;
+      const float *src = base + ((size_t)b * N + (on ? n : 0)) * VRP_D + h * VRP_HD + c;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) f[tn][i][dt] = on ? src[16 * dt] : 0.f;
+    }
+}
+// attention weights of step tile tt: lane (t = c) x nodes 16 tn + 4 g + i  (the layout of S^T)
+template <int NT, bool VEC>
+__device__ __forceinline__ void db_load_a_t(float (&a)[NT][4], const float *A, size_t r, bool on_t,
+                                            int h, int N, int g) {
+  const float *row = A + (r * 8 + h) * N;
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int n0 = 16 * tn + 4 * g;
+    if (VEC) {
+      const float4 v = (on_t && n0 < N) ? *reinterpret_cast<const float4 *>(row + n0)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      a[tn][0] = v.x; a[tn][1] = v.y; a[tn][2] = v.z; a[tn][3] = v.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[tn][i] = (on_t && n0 + i < N) ? row[n0 + i] : 0.f;
+    }
+  }
+}
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256, 2) void db_attn_fwd_mfma_kernel(int B, int N, int T,
+                                                                  const float *__restrict__ Q,
+                                                                  const float *__restrict__ Kb,
+                                                                  const float *__restrict__ Vb,
+                                                                  const uint8_t *__restrict__ masks,
+                                                                  float *__restrict__ A,
+                                                                  float *__restrict__ O) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  const int mrow = (b * 8 + h) % B;  // QUIRK D3: head h of graph b reads this graph's mask
+  float KR[NT][12], VC[NT][4][3];
+  db_load_row_frag<NT>(KR, Kb, b, N, h, c, g);
+  db_load_col_frag<NT>(VC, Vb, b, N, h, c, g);
+  for (int t0 = 0; t0 < T; t0 += 16) {
+    const int t = t0 + c;
+    const bool on = t < T;
+    const size_t r = (size_t)(on ? t : 0) * B + b;
+    float QR[12];
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(Q + r * VRP_D + h * VRP_HD + 12 * g);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 v = on ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        QR[4 * k] = v.x; QR[4 * k + 1] = v.y; QR[4 * k + 2] = v.z; QR[4 * k + 3] = v.w;
+      }
+    }
+    float mk[NT][4];
+    {
+      const uint8_t *mr = masks + ((size_t)(on ? t : 0) * B + mrow) * N;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n0 = 16 * tn + 4 * g;
+        if (VEC) {
+          const uint32_t m4 = (n0 < N) ? *reinterpret_cast<const uint32_t *>(mr + n0) : 0u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mk[tn][i] = (float)((m4 >> (8 * i)) & 0xffu);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) mk[tn][i] = (n0 + i < N) ? (float)mr[n0 + i] : 0.f;
+        }
+      }
+    }
+    float s[NT][4], mx = -INFINITY;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(KR[tn][k], QR[k], d, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool nv = 16 * tn + 4 * g + i < N;
+        s[tn][i] = nv ? d[i] * DB_C48 + mk[tn][i] : -INFINITY;
+        mx = fmaxf(mx, s[tn][i]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float es = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s[tn][i] = (16 * tn + 4 * g + i < N) ? expf(s[tn][i] - mx) : 0.f;
+        es += s[tn][i];
+      }
+    es += __shfl_xor(es, 16, 64);
+    es += __shfl_xor(es, 32, 64);
+    float *arow = A + (r * 8 + h) * N;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[tn][i] = s[tn][i] / es;
+      const int n0 = 16 * tn + 4 * g;
+      if (on) {
+        if (VEC) {
+          if (n0 < N) *reinterpret_cast<float4 *>(arow + n0) = make_float4(s[tn][0], s[tn][1], s[tn][2], s[tn][3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (n0 + i < N) arow[n0 + i] = s[tn][i];
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(VC[tn][i][dt], s[tn][i], d, 0, 0, 0);
+      if (on)
+        *reinterpret_cast<float4 *>(O + r * VRP_D + h * VRP_HD + 16 * dt + 4 * g) =
+            make_float4(d[0], d[1], d[2], d[3]);
+    }
+  }
+}
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256, 2) void db_attn_bwd_mfma_kernel(int B, int N, int T,
+                                                                  const float *__restrict__ Q,
+                                                                  const float *__restrict__ Kb,
+                                                                  const float *__restrict__ Vb,
+                                                                  const float *__restrict__ A,
+                                                                  const float *__restrict__ dO,
+                                                                  float *__restrict__ dQ,
+                                                                  float *__restrict__ dK,
+                                                                  float *__restrict__ dV) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  float VR[NT][12], KC[NT][4][3];
+  db_load_row_frag<NT>(VR, Vb, b, N, h, c, g);
+  db_load_col_frag<NT>(KC, Kb, b, N, h, c, g);
+  db_f4 accK[3][NT], accV[3][NT];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      accK[dt][tn] = db_f4{0.f, 0.f, 0.f, 0.f};
+      accV[dt][tn] = db_f4{0.f, 0.f, 0.f, 0.f};
+    }
+  for (int t0 = 0; t0 < T; t0 += 16) {
+    // ---- this tile's rows, in both layouts ------------------------------------------------
+    const int t1 = t0 + c;
+    const bool on1 = t1 < T;
+    const size_t r1 = (size_t)(on1 ? t1 : 0) * B + b;
+    float DR[12];   // dO[t = c][12 g + s]
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(dO + r1 * VRP_D + h * VRP_HD + 12 * g);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float4 v = on1 ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        DR[4 * k] = v.x; DR[4 * k + 1] = v.y; DR[4 * k + 2] = v.z; DR[4 * k + 3] = v.w;
+      }
+    }
+    float a1[NT][4];
+    db_load_a_t<NT, VEC>(a1, A, r1, on1, h, N, g);
+    float QC[4][3], DC[4][3], a2[NT][4];   // Q / dO [t = 4 g + i][16 dt + c];  a[t = 4 g + i][n = c]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t2 = t0 + 4 * g + i;
+      const bool on2 = t2 < T;
+      const size_t r2 = (size_t)(on2 ? t2 : 0) * B + b;
+      const float *qs = Q + r2 * VRP_D + h * VRP_HD + c, *ds = dO + r2 * VRP_D + h * VRP_HD + c;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        QC[i][dt] = on2 ? qs[16 * dt] : 0.f;
+        DC[i][dt] = on2 ? ds[16 * dt] : 0.f;
+      }
+      const float *ar = A + (r2 * 8 + h) * N;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) a2[tn][i] = (on2 && 16 * tn + c < N) ? ar[16 * tn + c] : 0.f;
+    }
+    // ---- dA^T = V dO^T, ds^T = a (dA - <a, dA>), dQ^T = K ds^T ------------------------------
+    float ds1[NT][4], part = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(VR[tn][k], DR[k], d, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ds1[tn][i] = d[i]; part = fmaf(a1[tn][i], d[i], part); }
+    }
+    part += __shfl_xor(part, 16, 64);
+    const float dot = part + __shfl_xor(part, 32, 64);   // <a_t, dA_t> of step t = c, in every group
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ds1[tn][i] = a1[tn][i] * (ds1[tn][i] - dot);
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(KC[tn][i][dt], ds1[tn][i], d, 0, 0, 0);
+      if (on1)
+        *reinterpret_cast<float4 *>(dQ + r1 * VRP_D + h * VRP_HD + 16 * dt + 4 * g) =
+            make_float4(d[0] * DB_C48, d[1] * DB_C48, d[2] * DB_C48, d[3] * DB_C48);
+    }
+    // ---- dA = dO V^T (lane = node), ds, dK^T += Q^T ds, dV^T += dO^T a ----------------------
+    float dot2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dot2[i] = __shfl(dot, 4 * g + i, 64);   // step t = 4 g + i
+    float ds2[NT][4];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) d = __builtin_amdgcn_mfma_f32_16x16x4f32(DR[k], VR[tn][k], d, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ds2[tn][i] = a2[tn][i] * (d[i] - dot2[i]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          accK[dt][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(QC[i][dt], ds2[tn][i], accK[dt][tn], 0, 0, 0);
+          accV[dt][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(DC[i][dt], a2[tn][i], accV[dt][tn], 0, 0, 0);
+        }
+  }
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int n = 16 * tn + c;
+    if (n < N) {
+      const size_t o = ((size_t)b * N + n) * VRP_D + h * VRP_HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const db_f4 k4 = accK[dt][tn], v4 = accV[dt][tn];
+        *reinterpret_cast<float4 *>(dK + o + 16 * dt) =
+            make_float4(k4[0] * DB_C48, k4[1] * DB_C48, k4[2] * DB_C48, k4[3] * DB_C48);
+        *reinterpret_cast<float4 *>(dV + o + 16 * dt) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+      }
+    }
+  }
+}
+
+// N <= 48: the matrix-core kernels (A/B: VRP_DB_ATTN_VALU=1 keeps the VALU ones)
+static bool db_attn_mfma_applies(int N) {
+  static const bool off = getenv("VRP_DB_ATTN_VALU") != nullptr;
+  return !off && N <= 48;
+}
+template <int NT, bool VEC>
+static void db_launch_attn_fwd_mfma(int B, int N, int T, const float *Q, const float *Kb, const float *Vb,
+                                    const uint8_t *masks, float *A, float *O, hipStream_t st) {
+  hipLaunchKernelGGL((db_attn_fwd_mfma_kernel<NT, VEC>), dim3(B, 2), dim3(256), 0, st, B, N, T, Q, Kb,
+                     Vb, masks, A, O);
+}
+template <int NT, bool VEC>
+static void db_launch_attn_bwd_mfma(int B, int N, int T, const float *Q, const float *Kb, const float *Vb,
+                                    const float *A, const float *dO, float *dQ, float *dK, float *dV,
+                                    hipStream_t st) {
+  hipLaunchKernelGGL((db_attn_bwd_mfma_kernel<NT, VEC>), dim3(B, 2), dim3(256), 0, st, B, N, T, Q, Kb,
+                     Vb, A, dO, dQ, dK, dV);
+}
+#define DB_ATTN_DISPATCH(FN, ...)                                        \
+  do {                                                                   \
+    const int nt_ = (N + 15) / 16;                                       \
+    const bool vec_ = (N & 3) == 0;                                      \
+    if (nt_ == 1) { if (vec_) FN<1, true>(__VA_ARGS__); else FN<1, false>(__VA_ARGS__); }      \
+    else if (nt_ == 2) { if (vec_) FN<2, true>(__VA_ARGS__); else FN<2, false>(__VA_ARGS__); } \
+    else { if (vec_) FN<3, true>(__VA_ARGS__); else FN<3, false>(__VA_ARGS__); }               \
+  } while (0)
+
 // ------------------------------------------------------------------ pointer logits + log-softmax
 // One workgroup per graph, KP_b (N x 128) in LDS.  Forward u = 10 tanh(Q2.KP_n/sqrt(128)),
 // own mask -> -inf, log p = u - logsumexp(u) (graph_decoder.py:96-100, graph_tsp_agent.py:86);
@@ -593,7 +918,10 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   }
   if (int r = vrp_launch_gemm_nt(s.ctx, 384, w->q_proj_weight, 384, bias, nullptr, 0, s.Q, 384, R,
                                  384, 384, 0, st)) return r;
-  {
+  if (db_attn_mfma_applies(N)) {
+    DB_ATTN_DISPATCH(db_launch_attn_fwd_mfma, B, N, T, s.Q, s.Kb, s.Vb, masks, s.A, s.O, st);
+    VRP_CHECK_LAUNCH("db_attn_fwd_mfma");
+  } else {
     const size_t lds = sizeof(float) * ((size_t)N * DBK_LD + N * 48 + 4 * 48 + 4 * 64 * npl);
     if (npl == 1) {
       if (db_raise_lds(db_attn_fwd_kernel<1>, lds, "db_attn_fwd")) return 1;
@@ -638,7 +966,10 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
   if (int r = vrp_launch_transpose(w->out_proj_weight, 384, 384, 384, s.WT, st)) return r;
   if (int r = vrp_launch_gemm_nt(s.dO2, 384, s.WT, 384, nullptr, nullptr, 0, s.dO, 384, R, 384, 384,
                                  0, st)) return r;
-  {
+  if (db_attn_mfma_applies(N)) {
+    DB_ATTN_DISPATCH(db_launch_attn_bwd_mfma, B, N, T, s.Q, s.Kb, s.Vb, s.A, s.dO, s.dQ, s.dKb, s.dVb, st);
+    VRP_CHECK_LAUNCH("db_attn_bwd_mfma");
+  } else {
     const size_t lds = sizeof(float) * ((size_t)3 * N * DBK_LD + 4 * 64 * npl + 4 * 96);
     if (npl == 1) {
       if (db_raise_lds(db_attn_bwd_kernel<1>, lds, "db_attn_bwd")) return 1;
