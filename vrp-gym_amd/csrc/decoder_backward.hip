@@ -791,6 +791,180 @@ __global__ __launch_bounds__(256) void db_logit_kernel(int B, int N, int T,
   }
 }
 
+// The same step on the matrix cores (N <= 48): one wave per graph, KP_b (N x 128) in LDS, 16-step
+// tiles.  Z^T(tn) = KP Q2^T puts step t on the lane (c) and nodes 16 tn + 4 g + i in its registers:
+// tanh, mask, log-softmax and dz are in-lane plus two xor steps, and dz^T IS the B operand of
+// dQ2^T(dt) = KP^T dz^T (A operand: one dword of KP_s per MFMA).  dz goes through a 16 x 48 LDS
+// tile once to put the node on the lane (t = 4 g + i in the registers): the B operand of
+// dKP^T(dt, tn) += Q2^T dz, accumulated over the episode in registers (96 of them).
+#define DBZ_LD 49
+template <int NT, bool VEC>
+__global__ __launch_bounds__(64) void db_logit_mfma_kernel(int B, int N, int T,
+                                                           const float *__restrict__ Q2,
+                                                           const float *__restrict__ KP,
+                                                           const uint8_t *__restrict__ masks,
+                                                           const int64_t *__restrict__ actions,
+                                                           const float *__restrict__ d_logp,
+                                                           float *__restrict__ dQ2,
+                                                           float *__restrict__ dKP,
+                                                           float *__restrict__ step_logp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *KP_s = smem;                       // [16 NT][132], rows >= N zero
+  float *dz_s = KP_s + 16 * NT * DBL_LD;    // [16][DBZ_LD]
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  for (int idx = lane; idx < 16 * NT * 32; idx += 64) {
+    const int n = idx >> 5, k4 = idx & 31;
+    const float4 v = n < N ? reinterpret_cast<const float4 *>(KP + ((size_t)b * N + n) * DB_E)[k4]
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4 *>(KP_s + n * DBL_LD + 4 * k4) = v;
+  }
+  db_f4 acc[8][NT];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) acc[dt][tn] = db_f4{0.f, 0.f, 0.f, 0.f};
+  const float wgt = d_logp[b];
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 16) {
+    const int t1 = t0 + c;
+    const bool on1 = t1 < T;
+    const size_t r1 = (size_t)(on1 ? t1 : 0) * B + b;
+    float QR[32];   // Q2[t = c][32 g + s]
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(Q2 + r1 * DB_E + 32 * g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 v = on1 ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        QR[4 * k] = v.x; QR[4 * k + 1] = v.y; QR[4 * k + 2] = v.z; QR[4 * k + 3] = v.w;
+      }
+    }
+    float QC[4][8];  // Q2[t = 4 g + i][16 dt + c]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t2 = t0 + 4 * g + i;
+      const bool on2 = t2 < T;
+      const float *src = Q2 + ((size_t)(on2 ? t2 : 0) * B + b) * DB_E + c;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) QC[i][dt] = on2 ? src[16 * dt] : 0.f;
+    }
+    const int act = (int)actions[r1];
+    bool open[NT][4];   // selectable: inside the graph and not masked (graph_decoder.py:98)
+    {
+      const uint8_t *mr = masks + r1 * N;
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn) {
+        const int n0 = 16 * tn + 4 * g;
+        if (VEC) {
+          const uint32_t m4 = (n0 < N) ? *reinterpret_cast<const uint32_t *>(mr + n0) : 0xffffffffu;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) open[tn][i] = ((m4 >> (8 * i)) & 0xffu) == 0;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) open[tn][i] = (n0 + i < N) && mr[n0 + i] == 0;
+        }
+      }
+    }
+    // ---- Z^T, u = 10 tanh(z / sqrt(128)), log-softmax over the open nodes ----------------------
+    float u[NT][4], th[NT][4], mx = -INFINITY;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+      const float *kr = KP_s + (16 * tn + c) * DBL_LD + 32 * g;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float4 a = *reinterpret_cast<const float4 *>(kr + 4 * k);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, QR[4 * k], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, QR[4 * k + 1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, QR[4 * k + 2], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, QR[4 * k + 3], d, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        th[tn][i] = open[tn][i] ? tanhf(d[i] * DB_C128) : 0.f;
+        u[tn][i] = open[tn][i] ? 10.f * th[tn][i] : -INFINITY;
+        mx = fmaxf(mx, u[tn][i]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) se += expf(u[tn][i] - mx);
+    se += __shfl_xor(se, 16, 64);
+    se += __shfl_xor(se, 32, 64);
+    const float lse = mx + logf(se);
+    float dz[NT][4], lp = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = 16 * tn + 4 * g + i;
+        const float pn = expf(u[tn][i] - lse);   // 0 for closed nodes
+        const float du = wgt * ((n == act ? 1.f : 0.f) - pn);
+        dz[tn][i] = (open[tn][i] && on1) ? du * 10.f * (1.f - th[tn][i] * th[tn][i]) * DB_C128 : 0.f;
+        if (n == act) lp += u[tn][i] - lse;
+      }
+    lp += __shfl_xor(lp, 16, 64);
+    lp += __shfl_xor(lp, 32, 64);
+    if (step_logp && on1 && g == 0) step_logp[r1] = lp;
+    // ---- dQ2^T = KP^T dz^T ----------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      db_f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(KP_s[(16 * tn + 4 * g + i) * DBL_LD + 16 * dt + c],
+                                                   dz[tn][i], d, 0, 0, 0);
+      if (on1)
+        *reinterpret_cast<float4 *>(dQ2 + r1 * DB_E + 16 * dt + 4 * g) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    // ---- dz with the node on the lane, dKP^T += Q2^T dz -----------------------------------
+    __syncthreads();   // (one wave: orders the previous tile's reads of dz_s before these writes)
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dz_s[c * DBZ_LD + 16 * tn + 4 * g + i] = dz[tn][i];
+    __syncthreads();
+    float dz2[NT][4];
+#pragma unroll
+    for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dz2[tn][i] = dz_s[(4 * g + i) * DBZ_LD + 16 * tn + c];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[dt][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(QC[i][dt], dz2[tn][i], acc[dt][tn], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tn = 0; tn < NT; ++tn) {
+    const int n = 16 * tn + c;
+    if (n < N) {
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const db_f4 v = acc[dt][tn];
+        *reinterpret_cast<float4 *>(dKP + ((size_t)b * N + n) * DB_E + 16 * dt + 4 * g) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+template <int NT, bool VEC>
+static void db_launch_logit_mfma(int B, int N, int T, const float *Q2, const float *KP,
+                                 const uint8_t *masks, const int64_t *actions, const float *d_logp,
+                                 float *dQ2, float *dKP, float *step_logp, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((size_t)16 * NT * DBL_LD + 16 * DBZ_LD);
+  hipLaunchKernelGGL((db_logit_mfma_kernel<NT, VEC>), dim3(B), dim3(64), lds, st, B, N, T, Q2, KP, masks,
+                     actions, d_logp, dQ2, dKP, step_logp);
+}
+
 // ------------------------------------------------------------------ context rows -> d_emb
 // D (T*B,384) = gradient of the context rows ([dg | dfirst | dlast], IRP: [dg | dlast | ..]).
 // One workgroup per graph, thread = embedding column, steps visited in order:
@@ -940,7 +1114,11 @@ extern "C" int vrp_decoder_backward(int kind, const vrp_decoder_weights *w,
                                  128, R, 128, 384, 0, st)) return r;
 
   // ---- backward ------------------------------------------------------------------------
-  {
+  if (db_attn_mfma_applies(N)) {
+    DB_ATTN_DISPATCH(db_launch_logit_mfma, B, N, T, s.Q2, s.KPb, masks, actions, d_logp, s.dQ2, s.dKPb,
+                     step_logp, st);
+    VRP_CHECK_LAUNCH("db_logit_mfma");
+  } else {
     const size_t lds = sizeof(float) * ((size_t)2 * N * DBL_LD + 4 * 128 + 4 * 64 * npl);
     if (npl == 1) {
       if (db_raise_lds(db_logit_kernel<1>, lds, "db_logit")) return 1;
