@@ -457,8 +457,154 @@ __global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float 
   }
 }
 
+// The same backward on the matrix cores for N <= 48 (three 16-node tiles): one wave per (graph,
+// head), every operand in registers, no LDS.  Lane (c, g) = (lane & 15, lane >> 4); "row" fragments
+// X[16 t + c][4 g .. 4 g + 3] (one 16-byte load; an MFMA k-step s hands group g the head column
+// 4 g + s on both sides) and "col" fragments X[16 t + 4 g + i][c].
+//   lane = query:  S^T(tj,ti) = K Q^T and dP^T = V dO^T put query i = c on the lane with keys
+//                  16 tj + 4 g + r in its registers: row max, sum and D_i are in-lane + two xor steps,
+//                  and ds^T is the B operand of dQ^T = K(col) ds^T  (16-byte stores);
+//   lane = key:    the same registers with the operands swapped give S and dP with key j = c on the
+//                  lane and queries 16 ti + 4 g + r in the registers (their statistics come over by
+//                  ds_bpermute), the B operands of dK^T = Q(col) ds and dV^T = dO(col) P.
+// 252 MFMAs per (graph, head) at N = 40 against ~3 N^2 x 50 VALU operations on 40 of 64 lanes:
+// 247 -> 70 us per layer at 2048 x 40.
+typedef float ab_f4 __attribute__((ext_vector_type(4)));
+#define AB_MFMA4(D, A, Bv)                                                \
+  D = __builtin_amdgcn_mfma_f32_16x16x4f32((A).x, (Bv).x, D, 0, 0, 0);    \
+  D = __builtin_amdgcn_mfma_f32_16x16x4f32((A).y, (Bv).y, D, 0, 0, 0);    \
+  D = __builtin_amdgcn_mfma_f32_16x16x4f32((A).z, (Bv).z, D, 0, 0, 0);    \
+  D = __builtin_amdgcn_mfma_f32_16x16x4f32((A).w, (Bv).w, D, 0, 0, 0)
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void encoder_attention_bwd_mfma_kernel(
+    const float *__restrict__ qkv, const float *__restrict__ dO, float *__restrict__ dqkv, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  const float *base = qkv + (size_t)b * N * 384 + h * 16;
+  const float *gbase = dO + (size_t)b * N * 128 + h * 16;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 QR[NT], KR[NT], VR[NT], GR[NT];
+  float KC[NT][4], QC[NT][4], GC[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = 16 * t + c;
+    const bool on = n < N;
+    const float *r = base + (size_t)(on ? n : 0) * 384 + 4 * g;
+    const float4 q4 = on ? *reinterpret_cast<const float4 *>(r) : zero4;
+    QR[t] = make_float4(q4.x * 0.25f, q4.y * 0.25f, q4.z * 0.25f, q4.w * 0.25f);   // 1/sqrt(16)
+    KR[t] = on ? *reinterpret_cast<const float4 *>(r + 128) : zero4;
+    VR[t] = on ? *reinterpret_cast<const float4 *>(r + 256) : zero4;
+    GR[t] = on ? *reinterpret_cast<const float4 *>(gbase + (size_t)n * 128 + 4 * g) : zero4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = 16 * t + 4 * g + i;
+      const bool om = m < N;
+      const float *rc = base + (size_t)(om ? m : 0) * 384 + c;
+      QC[t][i] = om ? rc[0] * 0.25f : 0.f;
+      KC[t][i] = om ? rc[128] : 0.f;
+      GC[t][i] = om ? gbase[(size_t)m * 128 + c] : 0.f;
+    }
+  }
+  // ---- lane = query i = 16 ti + c ------------------------------------------------------------
+  float st_m[NT], st_inv[NT], st_D[NT];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) {
+    ab_f4 p[NT], dp[NT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) {
+      ab_f4 d = {0.f, 0.f, 0.f, 0.f};
+      AB_MFMA4(d, KR[tj], QR[ti]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * tj + 4 * g + r >= N) d[r] = -INFINITY;
+        mx = fmaxf(mx, d[r]);
+      }
+      p[tj] = d;
+      ab_f4 e = {0.f, 0.f, 0.f, 0.f};
+      AB_MFMA4(e, VR[tj], GR[ti]);
+      dp[tj] = e;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f, Dacc = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(p[tj][r] - mx);   // 0 beyond N
+        p[tj][r] = e;
+        l += e;
+        Dacc = fmaf(e, dp[tj][r], Dacc);
+      }
+    l += __shfl_xor(l, 16, 64);       Dacc += __shfl_xor(Dacc, 16, 64);
+    l += __shfl_xor(l, 32, 64);       Dacc += __shfl_xor(Dacc, 32, 64);
+    const float inv = 1.f / l, Di = Dacc * inv;   // sum_j P_ij dP_ij
+    st_m[ti] = mx; st_inv[ti] = inv; st_D[ti] = Di;
+    ab_f4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ds = p[tj][r] * inv * (dp[tj][r] - Di);
+        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(KC[tj][r], ds, dq, 0, 0, 0);
+      }
+    const int i = 16 * ti + c;
+    if (i < N)
+      *reinterpret_cast<float4 *>(dqkv + ((size_t)b * N + i) * 384 + h * 16 + 4 * g) =
+          make_float4(dq[0] * 0.25f, dq[1] * 0.25f, dq[2] * 0.25f, dq[3] * 0.25f);
+  }
+  // ---- lane = key j = 16 tj + c; statistics of query 16 ti + 4 g + r from lane 4 g + r ----------
+  float s2m[NT][4], s2i[NT][4], s2D[NT][4];
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s2m[ti][r] = __shfl(st_m[ti], 4 * g + r, 64);
+      s2i[ti][r] = __shfl(st_inv[ti], 4 * g + r, 64);
+      s2D[ti][r] = __shfl(st_D[ti], 4 * g + r, 64);
+    }
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj) {
+    const int j = 16 * tj + c;
+    ab_f4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      ab_f4 sv = {0.f, 0.f, 0.f, 0.f}, dpv = {0.f, 0.f, 0.f, 0.f};
+      AB_MFMA4(sv, QR[ti], KR[tj]);
+      AB_MFMA4(dpv, GR[ti], VR[tj]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = (16 * ti + 4 * g + r < N) && (j < N);
+        const float pv = on ? expf(sv[r] - s2m[ti][r]) * s2i[ti][r] : 0.f;
+        const float ds = pv * (dpv[r] - s2D[ti][r]);
+        dv = __builtin_amdgcn_mfma_f32_16x16x4f32(GC[ti][r], pv, dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_16x16x4f32(QC[ti][r], ds, dk, 0, 0, 0);
+      }
+    }
+    if (j < N) {
+      float *dst = dqkv + ((size_t)b * N + j) * 384 + h * 16 + 4 * g;
+      *reinterpret_cast<float4 *>(dst + 128) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+      *reinterpret_cast<float4 *>(dst + 256) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+  }
+}
+
 int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
                              hipStream_t st) {
+  static const bool valu = getenv("VRP_ATTN_BWD_VALU") != nullptr;   // A/B aid
+  if (N <= 48 && !valu) {
+    if (N <= 16)
+      hipLaunchKernelGGL(encoder_attention_bwd_mfma_kernel<1>, dim3(B, 2), dim3(256), 0, st, qkv, dO, dqkv, N);
+    else if (N <= 32)
+      hipLaunchKernelGGL(encoder_attention_bwd_mfma_kernel<2>, dim3(B, 2), dim3(256), 0, st, qkv, dO, dqkv, N);
+    else
+      hipLaunchKernelGGL(encoder_attention_bwd_mfma_kernel<3>, dim3(B, 2), dim3(256), 0, st, qkv, dO, dqkv, N);
+    VRP_CHECK_LAUNCH("encoder_attention_bwd_mfma");
+    return 0;
+  }
   const size_t lds = (size_t)4 * ((N * 67 + 3) & ~3) * sizeof(float);
   static VrpAttrOnce attr_set;
   if (!attr_set.done() && lds > 64 * 1024) {
