@@ -453,7 +453,8 @@ def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
 
 def gemm_kernel_roofline(device, M=81920, N=384, K=128, reps=20):
     """The training path's most frequent tall GEMM (the train-mode in_proj of VRP-40 x 2048:
-    M = B N rows, bias only; vrp_gemm_nt -> gemm_rows_kernel) timed with HIP events."""
+    M = B N rows, bias only; vrp_gemm_nt -> gemm_rows_wide_kernel: all of W in registers) timed
+    with HIP events."""
     import vrpgym_hip as hip
     lib = hip.lib()
     A = torch.randn(M, K, device=device)
@@ -475,7 +476,7 @@ def gemm_kernel_roofline(device, M=81920, N=384, K=128, reps=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     tf = 2.0 * M * N * K / us / 1e6
-    return {"kernel": "gemm_rows_kernel<5>", "shape": [M, N, K], "avg_launch_us": round(us, 2),
+    return {"kernel": "gemm_rows_wide_kernel<3, false>", "shape": [M, N, K], "avg_launch_us": round(us, 2),
             "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
             "hbm_bytes": 4 * (M * K + M * N + N * K),

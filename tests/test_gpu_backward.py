@@ -152,6 +152,54 @@ def test_encoder_backward_against_oracle_autograd(kind, B, N):
     assert nb == 1
 
 
+def test_encoder_backward_wide_gemm_paths():
+    """hidden_dim = 384 at 20800 rows: the feed-forward products take the W-resident tall GEMM
+    (gemm_rows_wide_kernel: N = 384, K = 128), forward with ReLU and backward with the ReLU gate;
+    in_proj takes it in every train-mode pass of that size.  Against the oracle's autograd."""
+    import agents
+    from agents import runtime
+    from oracle import policy as opol
+    B, N = 520, 40
+    agent = agents.VRPAgent(seed=69, hidden_dim=384, num_attention_layers=2)
+    enc = agent.model.encoder
+    enc.train()
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, N, 3, generator=g)
+    x[:, :, 2] = 0
+    dm = torch.zeros(B, N, dtype=torch.bool)
+    dm[torch.arange(B), torch.randint(0, N, (B,), generator=g)] = True
+    G = torch.randn(B, N, 128, generator=g)
+    sd0 = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
+
+    def oracle_grads(dtype):
+        psd = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone())
+               for k, v in sd0.items()}
+        psd = {k: v.requires_grad_(v.is_floating_point() and "running" not in k) for k, v in psd.items()}
+        o = opol.encoder_forward(psd, x[:, :, :2].to(dtype), dm, train=True)
+        (o * G.to(dtype)).sum().backward()
+        return o.detach(), psd
+    oemb, psd = oracle_grads(torch.float32)
+    _, psd64 = oracle_grads(torch.float64)
+    x3 = x.cuda().contiguous()
+    dmu = dm.to(torch.uint8).cuda().contiguous()
+    emb, tape = runtime.encoder_forward_tape(enc, x3, dmu, update_running=True)
+    assert (emb.cpu() - oemb).abs().max().item() < 2e-5
+    params, grads = runtime.encoder_backward(enc, x3, dmu, tape, G.cuda())
+    names = {id(p): n for n, p in enc.named_parameters()}
+    wants = [None if p is None else psd64["encoder." + names[id(p)]].grad for p in params]
+    floor = 1e-5 * float(np.max([w.abs().max().item() for w in wants if w is not None]))
+    report = []
+    for p, gr, want in zip(params, grads, wants):
+        if p is None:
+            continue
+        nz = (psd["encoder." + names[id(p)]].grad.double() - want).abs().max().item()
+        err = (gr.cpu().double() - want).abs().max().item()
+        tol = 2e-4 * want.abs().max().item() + max(floor, 2e-5) + 4.0 * nz
+        report.append((err / tol, names[id(p)], err, want.abs().max().item()))
+    report.sort(reverse=True)
+    assert report[0][0] < 1.0, report[:5]
+
+
 def _decoder_oracle_grads(kind, dtype, sd, emb, acts, masks, loads, wgt):
     """Autograd through the CPU oracle's DecoderEpisode, teacher-forced on the recorded
     actions / masks / loads: gradient of sum_b w_b sum_t log p(a_t)."""

@@ -34,5 +34,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCL
 VRP_GEMM_VARIANT=rows rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/gemm_rows -o p -- python3 tools/gemm_one.py 81920 384 128 > $OUT/pmc_gemm_rows.log 2>&1
 { python3 tools/tile_phase_probe.py 1 100 2048 3 1; python3 tools/tile_phase_probe.py 0 40 8192 3 0; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 1 100 2048 3 1; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 0 40 8192 3 0; } 2>/dev/null | grep "us through phase" > $OUT/tile_phases.txt
 [ -x tools/micro/stream_rate ] && tools/micro/stream_rate > $OUT/stream_rate.txt 2>&1
-VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M=" > $OUT/gemm_rows_probe.txt
+{ echo "== bias + residual + ReLU (gemm_rows_kernel)"; VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only (N = 384 / 256, K = 128: gemm_rows_wide_kernel)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only, VRP_GEMM_ROWS_NARROW=1 (gemm_rows_kernel everywhere)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_ROWS_NARROW=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; } > $OUT/gemm_rows_probe.txt
 ls $OUT

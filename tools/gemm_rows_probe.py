@@ -25,7 +25,8 @@ plain = bool(os.environ.get("GEMM_PROBE_PLAIN"))   # bias only: no residual, no 
 shapes = [(204800, 384, 128), (81920, 384, 128), (81920, 128, 128), (81920, 512, 128), (81920, 128, 512),
           (81920, 384, 384), (40960, 384, 128), (40960, 512, 128), (40960, 128, 512),
           (204800, 1536, 128), (327680, 384, 128), (327680, 512, 128), (327680, 128, 512),
-          (20479, 128, 128), (30003, 256, 256)]
+          (20479, 128, 128), (30003, 256, 256),
+          (50001, 384, 128), (30003, 256, 128), (102400, 384, 128)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for M, N, K in shapes:
     A = torch.randn(M, K, device="cuda", generator=g)

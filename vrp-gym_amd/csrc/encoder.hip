@@ -1529,9 +1529,170 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
 // CU instead of one eight-wave workgroup of 80 rows, 187 vs 120 us.  PMC on this kernel: matrix
 // pipe busy 52 % of the cycles, waves parked 27 % -- its eight waves reach the two barriers of a
 // pass in lockstep.)
+// ---- N = 128 NCT, K = 128 (the train-mode in_proj, the decoder backward's K / V projections and
+// dO2: 81920..102400 x 384 x 128): ALL of W stays in registers -- a wave owns columns
+// ct 128 + 16 wave + i16 of every 128-column block ct, NCT x 32 fragment registers loaded once per
+// workgroup -- and a tile is ONE MFMA phase: an A fragment read from LDS feeds NCT column tiles (a
+// third of gemm_rows_kernel's LDS reads), no weight traffic, no barrier inside the phase.  The
+// column blocks then leave through two alternating 80 x 128 LDS images (whole rows, 16-byte
+// pieces): ONE barrier per block instead of two, and the waves drift apart between them.  The next
+// tile's rows travel in registers under the MFMA phase and are stored behind the first barrier of
+// the epilogue (every wave has left the phase by then).
+template <int NCT, bool GATE>
+__global__ __launch_bounds__(512) void gemm_rows_wide_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ W, int ldw,
+    const float *__restrict__ bias, const float *__restrict__ gate, float *__restrict__ C, int ldc,
+    int M, int relu, int ntiles) {
+  constexpr int RT16 = 5, RTW = 80, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *const Abuf = smem, *const Cs0 = smem + RTW * EB_LD, *const Cs1 = smem + 2 * RTW * EB_LD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  float4 pa[PF];
+  auto fetchA = [&](int tile) {
+    const int row0 = tile * RTW;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < M) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)(row0 + r) * lda + c4);
+    }
+  };
+  auto storeA = [&]() {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(Abuf + r * EB_LD + c4) = pa[u];
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) { fetchA(tile); storeA(); }
+  float w[NCT][32];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const float *w0 = W + (size_t)(ct * 128 + wave * 16 + i16) * ldw + kq8(q);
+#pragma unroll
+    for (int s = 0; s < 32; s += 4) load_w4(w[ct], w0, s);
+  }
+  __syncthreads();
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * RTW, valid = M - row0;
+    const int next_tile = tile + gridDim.x;
+    const bool more = next_tile < ntiles;
+    if (more) fetchA(next_tile);
+    f32x4v acc[NCT][RT16];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) acc[ct][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    {
+      const float *ap = Abuf + i16 * EB_LD + kq8(q);
+      float4 a[2][RT16];
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) a[0][rt] = *reinterpret_cast<const float4 *>(ap + rt * 16 * EB_LD);
+#pragma unroll
+      for (int s = 0; s < 32; s += 4) {
+        const int cur = (s >> 2) & 1;
+        if (s + 4 < 32) {
+#pragma unroll
+          for (int rt = 0; rt < RT16; ++rt)
+            a[cur ^ 1][rt] = *reinterpret_cast<const float4 *>(ap + rt * 16 * EB_LD + ks8(s + 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+          for (int rt = 0; rt < RT16; ++rt) {
+            const float av = k4 == 0 ? a[cur][rt].x : k4 == 1 ? a[cur][rt].y : k4 == 2 ? a[cur][rt].z : a[cur][rt].w;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+              acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[ct][s + k4], acc[ct][rt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      float *Cs = par ? Cs1 : Cs0;
+      par ^= 1;
+      float4 gv[GATE ? PF : 1];
+      if (GATE) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+          gv[GATE ? u : 0] = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (r < valid)
+            gv[GATE ? u : 0] = *reinterpret_cast<const float4 *>(gate + (size_t)(row0 + r) * ldc + ct * 128 + c4);
+        }
+      }
+      const int cq = ct * 128 + (tid & 31) * 4;
+      const float4 bz = bias ? *reinterpret_cast<const float4 *>(bias + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(rt * 16 + 4 * q + r) * EB_LD + wave * 16 + i16] = acc[ct][rt][r];
+      __syncthreads();
+      if (ct == 0 && more) storeA();   // every wave has left the MFMA phase
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+        if (r < valid) {
+          const float4 a4 = *reinterpret_cast<const float4 *>(Cs + r * EB_LD + c4);
+          float v[4] = {a4.x + bz.x, a4.y + bz.y, a4.z + bz.z, a4.w + bz.w};
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (GATE) {
+            const float gg[4] = {gv[GATE ? u : 0].x, gv[GATE ? u : 0].y, gv[GATE ? u : 0].z, gv[GATE ? u : 0].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!(gg[e] > 0.f)) v[e] = 0.f;
+          }
+          *reinterpret_cast<float4 *>(C + (size_t)(row0 + r) * ldc + ct * 128 + c4) =
+              make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    if (NCT == 1) __syncthreads();
+  }
+}
+
+template <int NCT, bool GATE>
+static int launch_gemm_rows_wide(const float *A, int lda, const float *W, int ldw, const float *bias,
+                                 const float *gate, float *C, int ldc, int M, int relu, hipStream_t st) {
+  constexpr int RTW = 80;
+  const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_rows_wide_kernel<NCT, GATE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("gemm_rows_wide: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set.mark();
+  }
+  const int ntiles = (M + RTW - 1) / RTW;
+  hipLaunchKernelGGL((gemm_rows_wide_kernel<NCT, GATE>), dim3(min(ntiles, 256)), dim3(512), lds, st, A,
+                     lda, W, ldw, bias, gate, C, ldc, M, relu, ntiles);
+  VRP_CHECK_LAUNCH("gemm_rows_wide");
+  return 0;
+}
+
 int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const float *bias,
                          const float *R, int ldr, const float *norm, const float *gate, float *C,
                          int ldc, int M, int N, int K, int relu, hipStream_t st) {
+  static const bool narrow = getenv("VRP_GEMM_ROWS_NARROW") != nullptr;   // A/B aid
+  if (!narrow && K == 128 && !R && !norm) {
+    if (N == 384)
+      return gate ? launch_gemm_rows_wide<3, true>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st)
+                  : launch_gemm_rows_wide<3, false>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st);
+    if (N == 256)
+      return gate ? launch_gemm_rows_wide<2, true>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st)
+                  : launch_gemm_rows_wide<2, false>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st);
+  }
   constexpr int RT16 = 5, RTW = 80;
   const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
   static VrpAttrOnce attr_set;
