@@ -129,6 +129,41 @@ def test_agent_weight_init_matches_reference():
             assert k1 == k2 and torch.equal(v1, v2)
 
 
+def test_non_default_architecture_weights_and_padded_shadows():
+    """Agent kwargs hidden_dim / num_attention_layers (graph_tsp_agent.py:96-106): the constructor
+    yields the reference's weights (hash from tests/golden/arch*), and the weight struct handed to
+    the kernels carries zero-padded shadows of the feed-forward weights (next multiple of 128)
+    that follow the parameters' version counters."""
+    import agents
+    from agents import runtime
+    for path in sorted(glob.glob(os.path.join(G, "archrollout_*.npz"))):
+        z = np.load(path)
+        kind, hidden, layers = int(z["kind"]), int(z["hidden"]), int(z["layers"])
+        cls = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
+        a = cls(seed=69, hidden_dim=hidden, num_attention_layers=layers)
+        h = hashlib.sha256()
+        for k, v in a.model.state_dict().items():
+            h.update(k.encode())
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+        assert h.hexdigest()[:16] == str(z["sd_hash"]), path
+        enc = a.model.encoder
+        w = runtime.encoder_struct(enc)
+        hp = (hidden + 127) // 128 * 128
+        assert w.hidden == hp and w.num_layers == layers
+        pads = runtime.padded_ff(enc)
+        assert len(pads) == (layers if hp != hidden else 0)
+        for layer, pad in zip(enc.attention_layers, pads):
+            assert pad.w0.shape == (hp, 128) and pad.w2.shape == (128, hp) and pad.b0.shape == (hp,)
+            assert torch.equal(pad.w0[:hidden], layer.ff[0].weight) and not pad.w0[hidden:].any()
+            assert torch.equal(pad.w2[:, :hidden], layer.ff[2].weight) and not pad.w2[:, hidden:].any()
+            assert torch.equal(pad.b0[:hidden], layer.ff[0].bias) and not pad.b0[hidden:].any()
+            with torch.no_grad():
+                layer.ff[0].weight.add_(1.0)      # an optimizer step moves the version counter
+        runtime.encoder_struct(enc)               # ... and the next use refreshes the shadows
+        for layer, pad in zip(enc.attention_layers, pads):
+            assert torch.equal(pad.w0[:hidden], layer.ff[0].weight) and not pad.w0[hidden:].any()
+
+
 def test_c_abi_exports_every_declared_symbol():
     """The shared library loads and exports every function include/vrpgym_hip.h
     declares (no compute call: there is no GPU here)."""
