@@ -1,2 +1,4 @@
-export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_backward.py -q -m gpu -x -k "wide" 2>&1 | tail -5
+mkdir -p gpurun_out/r04
+python3 bench.py > gpurun_out/r04/bench.json 2> gpurun_out/r04/bench.err
+tail -c 300 gpurun_out/r04/bench.json
+timeout 900 python -m pytest tests/test_bench_multirank.py -q -m gpu -x 2>&1 | tail -3
