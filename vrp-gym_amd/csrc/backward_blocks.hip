@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TN_MINWG 4
 #endif
 #ifndef TN_TARGET
-#define TN_TARGET 1024   // workgroups per launch (tiles x row splits): four per CU
+#define TN_TARGET 512    // workgroups per launch (tiles x row splits): two per CU (round 4: 1024 wrote twice the slabs)
 #endif
 __global__ __launch_bounds__(256, TN_MINWG) void gemm_tn_kernel(const float *__restrict__ X, int ldx,
                                                          const float *__restrict__ Y, int ldy,
@@ -116,20 +116,35 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   C[i] = s;
 }
 
-// Splits over rows: enough workgroups to fill the chip (~2 per CU) while a split keeps at
-// least 64 rows; the partial tiles (slabs) are summed in split order.
+// Splits over rows: about TN_TARGET workgroups per launch (tiles x splits: two per CU; a one-tile
+// product one per CU) while a split keeps at least 64 rows; the partial tiles (slabs) are summed in
+// split order.  Measured (tools/gemm_tn_probe.py, 81920 rows; until round 4: 1024 workgroups, at
+// most 128 splits -- a 128 x 128 product on half the CUs, a 384 x 128 one with two workgroups on
+// half of them and one on the others):
+//   384 x 128   120.7 us -> 97.7      128 x 128   67.6 -> 46.7      128 x 384 (102400 rows)  135.0 -> 114.2
+//   512 x 128 / 128 x 512  116.6 -> 117.9 (unchanged: 512 workgroups before and after)
+// 256 / 384 / 1024 workgroups for the multi-tile shapes: 103 / 112 / 108 us at 384 x 128 (fewer leave
+// latency exposed, more write more slabs: 67 MB at 1024).
+#ifndef TN_MAXSPLIT
+#define TN_MAXSPLIT 256
+#endif
 static int tn_splits(int R, int N1, int N2) {
   const int tiles = (N1 / 128) * (N2 / 128);
-  int nsplit = (TN_TARGET + tiles - 1) / tiles;
+  int nsplit = TN_TARGET / tiles;   // (floor: tiles x splits never exceeds TN_TARGET slabs)
   const int max_by_rows = (R + 63) / 64;
   if (nsplit > max_by_rows) nsplit = max_by_rows;
-  if (nsplit > 128) nsplit = 128;
+  if (nsplit > TN_MAXSPLIT) nsplit = TN_MAXSPLIT;
   if (nsplit < 1) nsplit = 1;
   return nsplit;
 }
 
+// An upper bound for EVERY product with at most these many tiles: callers size one workspace for
+// their largest shape and run smaller ones in it (tiles x splits <= max(TN_TARGET, tiles) slabs of
+// 128 x 128 floats).
 extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2) {
-  return (int64_t)tn_splits(R, N1, N2) * N1 * N2 * sizeof(float);
+  (void)R;
+  const int tiles = (N1 / 128) * (N2 / 128);
+  return (int64_t)(tiles > TN_TARGET ? tiles : TN_TARGET) * 128 * 128 * sizeof(float);
 }
 
 int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *C, int R, int N1,
