@@ -35,4 +35,5 @@ VRP_GEMM_VARIANT=rows rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCL
 { python3 tools/tile_phase_probe.py 1 100 2048 3 1; python3 tools/tile_phase_probe.py 0 40 8192 3 0; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 1 100 2048 3 1; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 0 40 8192 3 0; } 2>/dev/null | grep "us through phase" > $OUT/tile_phases.txt
 [ -x tools/micro/stream_rate ] && tools/micro/stream_rate > $OUT/stream_rate.txt 2>&1
 { echo "== bias + residual + ReLU (gemm_rows_kernel)"; VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only (N = 384 / 256, K = 128: gemm_rows_wide_kernel)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only, VRP_GEMM_ROWS_NARROW=1 (gemm_rows_kernel everywhere)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_ROWS_NARROW=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; } > $OUT/gemm_rows_probe.txt
+python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R=" > $OUT/gemm_tn_probe.txt
 ls $OUT
