@@ -90,6 +90,9 @@ typedef struct vrp_encoder_layer {
 
 typedef struct vrp_encoder_weights {
   int32_t node_dim, depot_dim, hidden, num_layers;     /* 2|3, 2|0, 512, <=8 */
+  int32_t heads, reserved_;  /* encoder heads: 8 (0 = 8; every fused kernel), or 4 / 16 (head width
+                              * 32 / 8: plain GEMM + per-(graph, head) VALU attention kernels, forward
+                              * and backward; graph_encoder.py:170-172) */
   const float *node_embed_weight, *node_embed_bias;    /* (128,node_dim) */
   const float *depot_embed_weight, *depot_embed_bias;  /* (128,2) or NULL */
   vrp_encoder_layer layer[8];

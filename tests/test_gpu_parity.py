@@ -45,7 +45,10 @@ def _arch_kw(z):
     hidden_dim not a multiple of the kernels' 128-wide slices, other layer counts)."""
     if "hidden" not in z.files:
         return {}
-    return dict(hidden_dim=int(z["hidden"]), num_attention_layers=int(z["layers"]))
+    kw = dict(hidden_dim=int(z["hidden"]), num_attention_layers=int(z["layers"]))
+    if "heads" in z.files:
+        kw["num_heads"] = int(z["heads"])
+    return kw
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -382,10 +385,11 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     model.train(train)
     env = _envs()[kind](N, B, 1, env_seed)
     oe = oenv.OracleEnv(kind, N, B, 1, env_seed)
+    heads = agent.model.encoder._dims[3]   # encoder heads (8 unless the fixture says otherwise)
     trace = []
     torch.manual_seed(torch_seed)
     with torch.no_grad():
-        ol, olp, oT = opol.rollout(sd, deepcopy(oe), greedy, train=train, trace=trace)
+        ol, olp, oT = opol.rollout(sd, deepcopy(oe), greedy, train=train, trace=trace, heads=heads)
     oacts = np.array([t["idx"].numpy() for t in trace])
     torch.manual_seed(torch_seed)
     with torch.no_grad():
@@ -413,7 +417,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         torch.manual_seed(torch_seed)   # same noise stream: one (B,N) draw per step
         with torch.no_grad():
             ol, olp, oT2 = opol.rollout(sd, deepcopy(oe), greedy, train=train,
-                                        trace=forced_trace, forced=acts)
+                                        trace=forced_trace, forced=acts, heads=heads)
         assert oT2 == T
     div_ref = diverged(ref_actions) if ref_actions is not None else {}
     # Along the HIP action path the oracle must agree with every HIP choice up to a near
@@ -430,7 +434,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         torch.manual_seed(torch_seed)
         with torch.no_grad():
             _, olp64, oT64 = opol.rollout(opol.as_double(sd), deepcopy(oe), greedy, train=True,
-                                          trace=trace64, forced=acts)
+                                          trace=trace64, forced=acts, heads=heads)
         assert oT64 == T
         U64 = torch.stack([st["u"] for st in trace64])
         LP64 = torch.stack([st["logp"] for st in trace64])
@@ -572,9 +576,10 @@ def test_rollout_against_reference(name, path, mode):
 @pytest.mark.parametrize("mode", ["default", "table", "fused"])
 @pytest.mark.parametrize("name,path", _load("archrollout_*.npz"))
 def test_non_default_architecture_against_reference(name, path, mode):
-    """The reference's agent kwargs `hidden_dim` / `num_attention_layers`
+    """The reference's agent kwargs `hidden_dim` / `num_attention_layers` / `num_heads`
     (graph_tsp_agent.py:96-106, graph_encoder.py:6-39) at values the kernels' 128-wide
-    feed-forward slices do not divide (200, 64, 520, 300) and at 1, 2 and 4 layers: the
+    feed-forward slices do not divide (200, 64, 520, 300), at 1, 2 and 4 layers, and with four
+    and sixteen encoder heads (GEMM + per-head attention kernels instead of the fused ones): the
     constructor yields the reference's weights, and the reference's recorded episode is
     reproduced through the stack kernel / per-layer kernels and every step kernel."""
     import hashlib
@@ -592,14 +597,16 @@ def test_non_default_architecture_against_reference(name, path, mode):
                      fused=mode == "fused", agent=agent)
 
 
-@pytest.mark.parametrize("hidden,layers,B,N", [(200, 2, 600, 40), (72, 5, 300, 80), (520, 1, 64, 20)])
-def test_non_default_architecture_encoder_large(hidden, layers, B, N):
+@pytest.mark.parametrize("hidden,layers,B,N,heads", [(200, 2, 600, 40, 8), (72, 5, 300, 80, 8),
+                                                     (520, 1, 64, 20, 8), (512, 3, 600, 40, 4),
+                                                     (256, 2, 300, 100, 16), (200, 2, 40, 128, 4)])
+def test_non_default_architecture_encoder_large(hidden, layers, B, N, heads):
     """... and through the large-batch encoder kernels (persistent 80-row block kernel behind
     the fused in_proj + attention kernels, eval mode; GEMM + BatchNorm kernels, train mode)
     against the oracle."""
     from oracle import policy as opol
     import agents
-    agent = agents.VRPAgent(seed=69, hidden_dim=hidden, num_attention_layers=layers)
+    agent = agents.VRPAgent(seed=69, hidden_dim=hidden, num_attention_layers=layers, num_heads=heads)
     sd = {k: v.detach().cpu().clone() for k, v in agent.model.state_dict().items()}
     g = torch.Generator().manual_seed(B * N)
     x = torch.rand(B, N, 2, generator=g)
@@ -608,9 +615,9 @@ def test_non_default_architecture_encoder_large(hidden, layers, B, N):
     for train in (False, True):
         agent.model.encoder.train(train)
         emb = agent.model.encoder(x, dm)
-        want = opol.encoder_forward(sd, x, dm, train=train)
+        want = opol.encoder_forward(sd, x, dm, train=train, heads=heads)
         err = (emb.cpu() - want).abs().max().item()
-        assert err < 2e-5, (hidden, layers, B, N, train, err)
+        assert err < 2e-5, (hidden, layers, B, N, heads, train, err)
 
 
 @pytest.mark.parametrize("mode", ["default", "table", "tile"])
@@ -879,7 +886,8 @@ def test_training_step_against_reference(name, path):
         e2 = _envs()[kind](N, B, 1, 7)
         with torch.no_grad():
             res = runtime.rollout(agent.model, e2, True)
-            ol, olp, T = opol.rollout(sd, oenv.OracleEnv(kind, N, B, 1, 7), True)
+            ol, olp, T = opol.rollout(sd, oenv.OracleEnv(kind, N, B, 1, 7), True,
+                                      heads=agent.model.encoder._dims[3])
         assert res.T == T
         assert (res.acc_loss.cpu() - ol).abs().max().item() < 1e-5
         assert (res.acc_logp.cpu() - olp).abs().max().item() < 1e-5 * max(1, T / 4)

@@ -140,7 +140,8 @@ def test_non_default_architecture_weights_and_padded_shadows():
         z = np.load(path)
         kind, hidden, layers = int(z["kind"]), int(z["hidden"]), int(z["layers"])
         cls = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[kind]
-        a = cls(seed=69, hidden_dim=hidden, num_attention_layers=layers)
+        heads = int(z["heads"]) if "heads" in z.files else 8
+        a = cls(seed=69, hidden_dim=hidden, num_attention_layers=layers, num_heads=heads)
         h = hashlib.sha256()
         for k, v in a.model.state_dict().items():
             h.update(k.encode())
@@ -149,7 +150,7 @@ def test_non_default_architecture_weights_and_padded_shadows():
         enc = a.model.encoder
         w = runtime.encoder_struct(enc)
         hp = (hidden + 127) // 128 * 128
-        assert w.hidden == hp and w.num_layers == layers
+        assert w.hidden == hp and w.num_layers == layers and w.heads == heads
         pads = runtime.padded_ff(enc)
         assert len(pads) == (layers if hp != hidden else 0)
         for layer, pad in zip(enc.attention_layers, pads):
@@ -174,7 +175,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert lib.vrp_abi_version() == 5
+    assert lib.vrp_abi_version() == 6
     assert len(lib.vrp_source_hash()) == 16
     assert lib.vrp_decoder_derived_bytes() > 0
     assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
@@ -185,7 +186,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(vrpgym_hip.DecoderWeights) == 11 * 8
     assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 12 * 8   # + logit_clip (float, padded)
     assert ctypes.sizeof(vrpgym_hip.DecoderGrads) == 11 * 8
-    assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 16 + 4 * 8 + 8 * 18 * 8
+    assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 24 + 4 * 8 + 8 * 18 * 8   # + heads, reserved_
 
 
 def test_product_fails_loudly_without_gpu():
@@ -284,7 +285,7 @@ assert vrpgym_hip.library_path().endswith("_asan.so")
 header = open(os.path.join(%(root)r, "include", "vrpgym_hip.h")).read()
 for n in sorted(set(re.findall(r"\b(vrp_[a-z_0-9]+)\s*\(", header))):
     assert hasattr(lib, n), n
-assert lib.vrp_abi_version() == 5 and lib.vrp_decoder_derived_bytes() > 0
+assert lib.vrp_abi_version() == 6 and lib.vrp_decoder_derived_bytes() > 0
 for B, N in ((1, 2), (512, 20), (8192, 40), (2048, 100), (5, 128)):
     assert lib.vrp_encoder_workspace_bytes(B, N, 512) > 0
     for kind in (0, 1, 2):

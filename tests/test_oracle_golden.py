@@ -114,7 +114,14 @@ def test_decoder_teacher_forced(name, z):
 def _arch(z):
     """hidden_dim / num_attention_layers of a fixture taken on a non-default architecture
     (tests/golden/arch*: tools/make_golden.py `arch`), {} for the reference's defaults."""
-    return dict(hidden=int(z["hidden"]), layers=int(z["layers"])) if "hidden" in z.files else {}
+    if "hidden" not in z.files:
+        return {}
+    return dict(hidden=int(z["hidden"]), layers=int(z["layers"]),
+                heads=int(z["heads"]) if "heads" in z.files else 8)
+
+
+def _heads(z):
+    return int(z["heads"]) if "heads" in z.files else 8
 
 
 @pytest.mark.parametrize("name,z", _load("rollout_*.npz") + _load("archrollout_*.npz"))
@@ -125,7 +132,7 @@ def test_rollout(name, z):
     torch.manual_seed(int(z["torch_seed"]))
     trace = []
     with torch.no_grad():
-        loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, trace=trace)
+        loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, trace=trace, heads=_heads(z))
     acts = np.array([t["idx"].numpy() for t in trace])
     exempt = np.zeros(B, bool)
     if acts.shape != z["actions"].shape or not np.array_equal(acts, z["actions"]):
@@ -138,7 +145,7 @@ def test_rollout(name, z):
                     break
         torch.manual_seed(int(z["torch_seed"]))
         with torch.no_grad():
-            loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, forced=z["actions"])
+            loss, logp, T = opol.rollout(sd, deepcopy(env), greedy, forced=z["actions"], heads=_heads(z))
     assert T == int(z["T"])
     assert np.max(np.abs(loss.numpy() - z["acc_loss"])) < 1e-5
     # accumulated log-prob: fp32 sum of T terms, 1 ulp at |sum| ~ 380 (N = 100) is 3e-5; the
@@ -212,9 +219,9 @@ def test_training_step(name, z):
     env.reset()                                        # graph_tsp_agent.py:246
     env_b = deepcopy(env)
     noise = lambda t, u: torch.empty(u.shape).exponential_(1)   # Categorical.sample's draw
-    loss_m, logp, T = opol.rollout(sd, env, False, train=True, noise_fn=noise)
+    loss_m, logp, T = opol.rollout(sd, env, False, train=True, noise_fn=noise, heads=_heads(z))
     with torch.no_grad():                              # QUIRK :253: baseline sampled too
-        loss_b, _, _ = opol.rollout(tsd, env_b, False, train=False, noise_fn=noise)
+        loss_b, _, _ = opol.rollout(tsd, env_b, False, train=False, noise_fn=noise, heads=_heads(z))
     assert T == int(z["T"])
     assert np.max(np.abs(loss_m.detach().numpy() - z["loss_m"])) < 1e-5
     assert np.max(np.abs(loss_b.numpy() - z["loss_b"])) < 1e-5

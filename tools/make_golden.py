@@ -550,9 +550,14 @@ def gen_arch():
     graph_tsp_agent.py:96-106): one episode (rollout_* format) and one training step
     (trainstep_* format) per case."""
     print("[arch]")
-    for kind, hidden, layers, B, N, greedy in [(0, 200, 2, 16, 12, True), (1, 64, 3, 16, 12, False),
-                                               (2, 520, 1, 16, 12, True), (1, 300, 4, 24, 20, True)]:
-        kw = dict(hidden_dim=hidden, num_attention_layers=layers, seed=69)
+    for kind, hidden, layers, B, N, greedy, heads in [
+            (0, 200, 2, 16, 12, True, 8), (1, 64, 3, 16, 12, False, 8), (2, 520, 1, 16, 12, True, 8),
+            (1, 300, 4, 24, 20, True, 8),
+            # encoder head counts other than eight (num_heads; the decoder keeps its eight,
+            # graph_tsp_agent.py:53-55)
+            (0, 512, 3, 16, 12, True, 4), (1, 512, 3, 24, 20, False, 16), (2, 200, 2, 16, 12, True, 16),
+            (1, 384, 2, 16, 50, False, 4)]:
+        kw = dict(hidden_dim=hidden, num_attention_layers=layers, num_heads=heads, seed=69)
         ag = REF_AGENT[kind](**kw)
         env = REF_ENV[kind](N, B, 1, 69)
         ag.model.eval()
@@ -567,18 +572,18 @@ def gen_arch():
         torch.manual_seed(77)
         with torch.no_grad():
             loss, logp = ag.model(env, greedy)
-        sd, _ = opol.init_state_dicts(kind, 69, hidden=hidden, layers=layers)
+        sd, _ = opol.init_state_dicts(kind, 69, hidden=hidden, layers=layers, heads=heads)
         assert sd_hash(sd) == sd_hash(ag.model.state_dict())
         oe = oenv.OracleEnv(kind, N, B, 1, 69)
         torch.manual_seed(77)
         with torch.no_grad():
-            ol, olp, T = opol.rollout(sd, oe, greedy, forced=np.array(acts))
+            ol, olp, T = opol.rollout(sd, oe, greedy, forced=np.array(acts), heads=heads)
         el, ep = (ol - loss).abs().max().item(), (olp - logp).abs().max().item()
-        print(f"   kind={kind} hidden={hidden} layers={layers} B={B} N={N} greedy={greedy}: "
+        print(f"   kind={kind} hidden={hidden} layers={layers} heads={heads} B={B} N={N} greedy={greedy}: "
               f"T={len(acts)} |dloss|={el:.2e} |dlogp|={ep:.2e} sd={sd_hash(sd)}")
         assert el < 1e-5 and ep < 1e-5 * max(1, len(acts) / 4)
-        tag = f"k{kind}_h{hidden}_l{layers}"
-        save(f"archrollout_{tag}", kind=kind, hidden=hidden, layers=layers, B=B, N=N,
+        tag = f"k{kind}_h{hidden}_l{layers}" + (f"_heads{heads}" if heads != 8 else "")
+        save(f"archrollout_{tag}", kind=kind, hidden=hidden, layers=layers, heads=heads, B=B, N=N,
              greedy=greedy, torch_seed=77, T=len(acts), actions=np.array(acts),
              acc_loss=loss.numpy(), acc_logp=logp.numpy(), sd_hash=sd_hash(sd))
         # one training step, as gen_train_step records it
@@ -598,7 +603,7 @@ def gen_arch():
         ff2 = ag.model.encoder.attention_layers[0].ff[2].weight.grad.numpy().copy()
         ag.opt.step()
         print(f"      training step: loss={tl.item():.6f} T={T} gradnorm={tot:.5f}")
-        save(f"archstep_{tag}", kind=kind, hidden=hidden, layers=layers, B=B, N=N, torch_seed=31,
+        save(f"archstep_{tag}", kind=kind, hidden=hidden, layers=layers, heads=heads, B=B, N=N, torch_seed=31,
              env_first=0, loss=tl.item(), T=T, loss_m=loss_m.detach().numpy(),
              loss_b=loss_b.numpy(), logp=logp.detach().numpy(),
              grad_keys=np.array(list(gn.keys())), grad_norms=np.array(list(gn.values())),

@@ -21,11 +21,16 @@ ROLLOUT_LOG = None    # bench.py: a list collecting every RolloutResult (step ac
 
 
 def check_supported_dims(emb_dim, num_heads, hidden_dim, decoder=False):
-    """The kernels are specialised for the reference's embedding width and head count (128, 8);
-    any `hidden_dim` >= 1 and up to eight attention layers run (a feed-forward width that is not
-    a multiple of the kernels' 128-wide slices is zero-padded to the next one, see
-    `_PaddedFF`).  Other sizes can be constructed (state_dict compatibility) but not run."""
-    return emb_dim == EMB and num_heads == HEADS and (hidden_dim is None or hidden_dim >= 1)
+    """The kernels are specialised for the reference's embedding width (128) and, in the decoder,
+    its eight heads (fixed by the reference too: graph_tsp_agent.py:53-55).  The encoder runs 8
+    heads on every fused kernel and 4 or 16 heads (head width 32 / 8) on a plain GEMM + per-head
+    attention path, forward and backward; any `hidden_dim` >= 1 and up to eight attention layers
+    run (a feed-forward width that is not a multiple of the kernels' 128-wide slices is
+    zero-padded to the next one, see `_PaddedFF`).  Other sizes can be constructed (state_dict
+    compatibility) but not run."""
+    if decoder:
+        return emb_dim == EMB and num_heads == HEADS
+    return emb_dim == EMB and num_heads in (4, 8, 16) and (hidden_dim is None or hidden_dim >= 1)
 
 
 class _PaddedFF:
@@ -122,10 +127,11 @@ def encoder_struct(enc):
     node_dim, emb, hidden, heads = enc._dims
     if not check_supported_dims(emb, heads, hidden):
         raise NotImplementedError(
-            f"HIP encoder is built for emb_dim=128, num_heads=8 (got {emb}, {heads})")
+            f"HIP encoder is built for emb_dim=128 and 4, 8 or 16 heads (got {emb}, {heads})")
     hp = (hidden + 127) // 128 * 128
     w = hip.EncoderWeights()
     w.node_dim, w.hidden, w.num_layers = node_dim, hp, len(enc.attention_layers)
+    w.heads = heads
     if w.num_layers > 8:
         raise NotImplementedError("at most 8 attention layers")
     keep, padded = [], []

@@ -367,105 +367,116 @@ __device__ __forceinline__ void ld16(float (&v)[16], const float *p) {
     v[d] = t.x; v[d + 1] = t.y; v[d + 2] = t.z; v[d + 3] = t.w;
   }
 }
+template <int D>
+__device__ __forceinline__ void ldD(float (&v)[D], const float *p) {
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p + d);
+    v[d] = t.x; v[d + 1] = t.y; v[d + 2] = t.z; v[d + 3] = t.w;
+  }
+}
 
-__global__ __launch_bounds__(256) void encoder_attention_bwd_kernel(const float *__restrict__ qkv,
+template <int D, int W>
+__global__ __launch_bounds__(64 * W) void encoder_attention_bwd_kernel(const float *__restrict__ qkv,
                                                                     const float *__restrict__ dO,
                                                                     float *__restrict__ dqkv,
                                                                     int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+  const int b = blockIdx.x, h = blockIdx.y * W + wave;
+  const float scale = D == 16 ? 0.25f : (D == 32 ? 0.17677669529663687f : 0.35355339059327373f);
   // per wave: Q,K,V,dO (N x 16 each), row max / inverse sum / D (N each)
-  float *Qs = smem + (size_t)wave * ((N * 67 + 3) & ~3);  // 16-byte aligned rows of 16 floats
-  float *Ks = Qs + N * 16, *Vs = Ks + N * 16, *Gs = Vs + N * 16;
-  float *mx = Gs + N * 16, *isum = mx + N, *Dv = isum + N;
+  float *Qs = smem + (size_t)wave * ((N * (4 * D + 3) + 3) & ~3);  // 16-byte aligned rows of D floats
+  float *Ks = Qs + N * D, *Vs = Ks + N * D, *Gs = Vs + N * D;
+  float *mx = Gs + N * D, *isum = mx + N, *Dv = isum + N;
   const float *base = qkv + (size_t)b * N * 384;
   const float *gbase = dO + (size_t)b * N * 128;
-  for (int idx = lane; idx < N * 4; idx += 64) {
-    const int j = idx >> 2, q4 = (idx & 3) * 4;
-    *reinterpret_cast<float4 *>(Qs + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + h * 16 + q4);
-    *reinterpret_cast<float4 *>(Ks + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * 16 + q4);
-    *reinterpret_cast<float4 *>(Vs + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * 16 + q4);
-    *reinterpret_cast<float4 *>(Gs + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(gbase + (size_t)j * 128 + h * 16 + q4);
+  constexpr int D4 = D / 4;
+  for (int idx = lane; idx < N * D4; idx += 64) {
+    const int j = idx / D4, q4 = (idx % D4) * 4;
+    *reinterpret_cast<float4 *>(Qs + j * D + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + h * D + q4);
+    *reinterpret_cast<float4 *>(Ks + j * D + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * D + q4);
+    *reinterpret_cast<float4 *>(Vs + j * D + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * D + q4);
+    *reinterpret_cast<float4 *>(Gs + j * D + q4) =
+        *reinterpret_cast<const float4 *>(gbase + (size_t)j * 128 + h * D + q4);
   }
   __syncthreads();
   // ---- pass A: lane = i
   for (int i = lane; i < N; i += 64) {
-    float q[16], g[16];
+    float q[D], g[D];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) { q[d] = Qs[i * 16 + d] * 0.25f; g[d] = Gs[i * 16 + d]; }  // own row
+    for (int d = 0; d < D; ++d) { q[d] = Qs[i * D + d] * scale; g[d] = Gs[i * D + d]; }  // own row
     float m = -INFINITY;
     for (int j = 0; j < N; ++j) {
-      float kk[16];
-      ld16(kk, Ks + j * 16);
+      float kk[D];
+      ldD<D>(kk, Ks + j * D);
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) s = fmaf(q[d], kk[d], s);
+      for (int d = 0; d < D; ++d) s = fmaf(q[d], kk[d], s);
       m = fmaxf(m, s);
     }
     float l = 0.f, Dacc = 0.f;
     for (int j = 0; j < N; ++j) {
-      float kk[16], vv[16];
-      ld16(kk, Ks + j * 16);
-      ld16(vv, Vs + j * 16);
+      float kk[D], vv[D];
+      ldD<D>(kk, Ks + j * D);
+      ldD<D>(vv, Vs + j * D);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
+      for (int d = 0; d < D; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
       const float p = expf(s - m);
       l += p;
       Dacc = fmaf(p, dp, Dacc);
     }
     const float inv = 1.f / l;
     const float Di = Dacc * inv;  // sum_j P_ij dP_ij
-    float dq[16];
+    float dq[D];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) dq[d] = 0.f;
+    for (int d = 0; d < D; ++d) dq[d] = 0.f;
     for (int j = 0; j < N; ++j) {
-      float kk[16], vv[16];
-      ld16(kk, Ks + j * 16);
-      ld16(vv, Vs + j * 16);
+      float kk[D], vv[D];
+      ldD<D>(kk, Ks + j * D);
+      ldD<D>(vv, Vs + j * D);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
+      for (int d = 0; d < D; ++d) { s = fmaf(q[d], kk[d], s); dp = fmaf(g[d], vv[d], dp); }
       const float ds = expf(s - m) * inv * (dp - Di);
 #pragma unroll
-      for (int d = 0; d < 16; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
+      for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, kk[d], dq[d]);
     }
     mx[i] = m; isum[i] = inv; Dv[i] = Di;
-    float *dst = dqkv + ((size_t)b * N + i) * 384 + h * 16;
+    float *dst = dqkv + ((size_t)b * N + i) * 384 + h * D;
 #pragma unroll
-    for (int d = 0; d < 16; d += 4)
-      *reinterpret_cast<float4 *>(dst + d) = make_float4(dq[d] * 0.25f, dq[d + 1] * 0.25f,
-                                                         dq[d + 2] * 0.25f, dq[d + 3] * 0.25f);
+    for (int d = 0; d < D; d += 4)
+      *reinterpret_cast<float4 *>(dst + d) = make_float4(dq[d] * scale, dq[d + 1] * scale,
+                                                         dq[d + 2] * scale, dq[d + 3] * scale);
   }
   __syncthreads();
   // ---- pass B: lane = j
   for (int j = lane; j < N; j += 64) {
-    float k[16], v[16], dk[16], dv[16];
+    float k[D], v[D], dk[D], dv[D];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) { k[d] = Ks[j * 16 + d]; v[d] = Vs[j * 16 + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int d = 0; d < D; ++d) { k[d] = Ks[j * D + d]; v[d] = Vs[j * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
     for (int i = 0; i < N; ++i) {
-      float qq[16], gg[16];
-      ld16(qq, Qs + i * 16);
-      ld16(gg, Gs + i * 16);
+      float qq[D], gg[D];
+      ldD<D>(qq, Qs + i * D);
+      ldD<D>(gg, Gs + i * D);
       float s = 0.f, dp = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) { s = fmaf(qq[d] * 0.25f, k[d], s); dp = fmaf(gg[d], v[d], dp); }
+      for (int d = 0; d < D; ++d) { s = fmaf(qq[d] * scale, k[d], s); dp = fmaf(gg[d], v[d], dp); }
       const float p = expf(s - mx[i]) * isum[i];
       const float ds = p * (dp - Dv[i]);
 #pragma unroll
-      for (int d = 0; d < 16; ++d) {
+      for (int d = 0; d < D; ++d) {
         dv[d] = fmaf(p, gg[d], dv[d]);
-        dk[d] = fmaf(ds, qq[d] * 0.25f, dk[d]);
+        dk[d] = fmaf(ds, qq[d] * scale, dk[d]);
       }
     }
-    float *dst = dqkv + ((size_t)b * N + j) * 384 + h * 16;
+    float *dst = dqkv + ((size_t)b * N + j) * 384 + h * D;
 #pragma unroll
-    for (int d = 0; d < 16; d += 4) {
+    for (int d = 0; d < D; d += 4) {
       *reinterpret_cast<float4 *>(dst + 128 + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
       *reinterpret_cast<float4 *>(dst + 256 + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
     }
@@ -607,8 +618,32 @@ __global__ __launch_bounds__(256, 2) void encoder_attention_bwd_mfma_kernel(
   }
 }
 
+template <int D, int W>
+static int launch_attention_bwd_valu(const float *qkv, const float *dO, float *dqkv, int B, int N,
+                                     hipStream_t st) {
+  const size_t lds = (size_t)W * ((N * (4 * D + 3) + 3) & ~3) * sizeof(float);
+  VRP_REQUIRE(lds <= 160 * 1024, "attention_bwd: N=%d too large for head width %d", N, D);
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_bwd_kernel<D, W>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      vrp_set_error("attention_bwd: cannot raise dynamic LDS");
+      return 1;
+    }
+    attr_set.mark();
+  }
+  hipLaunchKernelGGL((encoder_attention_bwd_kernel<D, W>), dim3(B, (128 / D) / W), dim3(64 * W), lds, st,
+                     qkv, dO, dqkv, N);
+  VRP_CHECK_LAUNCH("encoder_attention_bwd");
+  return 0;
+}
+
+// heads: 8 (the reference's default: matrix-core kernel for N <= 48, VALU above), 4 or 16 (VALU;
+// four heads of width 32 run two waves per workgroup: Q, K, V, dO of a wave are 131 N floats of LDS)
 int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
-                             hipStream_t st) {
+                             hipStream_t st, int heads) {
+  if (heads == 4) return launch_attention_bwd_valu<32, 2>(qkv, dO, dqkv, B, N, st);
+  if (heads == 16) return launch_attention_bwd_valu<8, 4>(qkv, dO, dqkv, B, N, st);
   static const bool valu = getenv("VRP_ATTN_BWD_VALU") != nullptr;   // A/B aid
   if (N <= 48 && !valu) {
     if (N <= 16)
@@ -620,22 +655,10 @@ int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int
     VRP_CHECK_LAUNCH("encoder_attention_bwd_mfma");
     return 0;
   }
-  const size_t lds = (size_t)4 * ((N * 67 + 3) & ~3) * sizeof(float);
-  static VrpAttrOnce attr_set;
-  if (!attr_set.done() && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      vrp_set_error("attention_bwd: cannot raise dynamic LDS");
-      return 1;
-    }
-    attr_set.mark();
-  }
-  hipLaunchKernelGGL(encoder_attention_bwd_kernel, dim3(B, 2), dim3(256), lds, st, qkv, dO, dqkv, N);
-  VRP_CHECK_LAUNCH("encoder_attention_bwd");
-  return 0;
+  return launch_attention_bwd_valu<16, 4>(qkv, dO, dqkv, B, N, st);
 }
 
 extern "C" int vrp_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
                                  void *stream) {
-  return vrp_launch_attention_bwd(qkv, dO, dqkv, B, N, (hipStream_t)stream);
+  return vrp_launch_attention_bwd(qkv, dO, dqkv, B, N, (hipStream_t)stream, 8);
 }

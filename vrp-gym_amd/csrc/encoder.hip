@@ -25,7 +25,7 @@ int vrp_launch_bn_bwd(const float *dy, const float *z, const float *stats, const
                       int R, float *dz, float *dgamma, float *dbeta, int accumulate, void *ws,
                       hipStream_t st);
 int vrp_launch_attention_bwd(const float *qkv, const float *dO, float *dqkv, int B, int N,
-                             hipStream_t st);
+                             hipStream_t st, int heads = 8);
 extern "C" int64_t vrp_gemm_tn_workspace_bytes(int R, int N1, int N2);
 extern "C" int64_t vrp_bn_bwd_workspace_bytes(void);
 
@@ -57,58 +57,88 @@ __global__ __launch_bounds__(256) void embed_kernel(const float *__restrict__ x,
 // V_h (N x 16 each) sit in LDS and are read as broadcasts.  One pass over the keys with a
 // running maximum (flash-style); equal to torch's softmax up to fp32 rounding.
 // graph_encoder.py:170-172,196.
+// D = head width: 16 (eight heads; the A/B arm of the matrix-core kernels) or 32 / 8 (four / sixteen
+// heads, graph_encoder.py:170-172 with a non-default num_heads: this kernel is their only path).
+template <int D>
 __global__ __launch_bounds__(256) void encoder_attention_kernel(const float *__restrict__ qkv,
                                                                 float *__restrict__ out, int N) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
-  float *Ks = smem + (size_t)wave * N * 32;
-  float *Vs = Ks + N * 16;
+  const float scale = D == 16 ? 0.25f : (D == 32 ? 0.17677669529663687f : 0.35355339059327373f);
+  float *Ks = smem + (size_t)wave * N * 2 * D;
+  float *Vs = Ks + N * D;
   const float *base = qkv + (size_t)b * N * 384;
-  for (int idx = lane; idx < N * 4; idx += 64) {
-    const int j = idx >> 2, q4 = (idx & 3) * 4;
-    *reinterpret_cast<float4 *>(Ks + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * 16 + q4);
-    *reinterpret_cast<float4 *>(Vs + j * 16 + q4) =
-        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * 16 + q4);
+  for (int idx = lane; idx < N * (D / 4); idx += 64) {
+    const int j = idx / (D / 4), q4 = (idx % (D / 4)) * 4;
+    *reinterpret_cast<float4 *>(Ks + j * D + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 128 + h * D + q4);
+    *reinterpret_cast<float4 *>(Vs + j * D + q4) =
+        *reinterpret_cast<const float4 *>(base + (size_t)j * 384 + 256 + h * D + q4);
   }
   __syncthreads();
   for (int i = lane; i < N; i += 64) {
-    float q[16];
+    float q[D];
 #pragma unroll
-    for (int d = 0; d < 16; d += 4) {
-      float4 t = *reinterpret_cast<const float4 *>(base + (size_t)i * 384 + h * 16 + d);
-      q[d] = t.x * 0.25f; q[d + 1] = t.y * 0.25f; q[d + 2] = t.z * 0.25f; q[d + 3] = t.w * 0.25f;
+    for (int d = 0; d < D; d += 4) {
+      float4 t = *reinterpret_cast<const float4 *>(base + (size_t)i * 384 + h * D + d);
+      q[d] = t.x * scale; q[d + 1] = t.y * scale; q[d + 2] = t.z * scale; q[d + 3] = t.w * scale;
     }
     // single pass over the keys with a running maximum (scores are computed once); the
     // accumulators are rescaled only when the maximum moves
-    float m = -INFINITY, l = 0.f, o[16];
+    float m = -INFINITY, l = 0.f, o[D];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) o[d] = 0.f;
+    for (int d = 0; d < D; ++d) o[d] = 0.f;
     for (int j = 0; j < N; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) s = fmaf(q[d], Ks[j * 16 + d], s);
+      for (int d = 0; d < D; ++d) s = fmaf(q[d], Ks[j * D + d], s);
       if (s > m) {
         const float corr = expf(m - s);  // exp(-inf) = 0 on the first key
         l *= corr;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] *= corr;
+        for (int d = 0; d < D; ++d) o[d] *= corr;
         m = s;
       }
       const float p = expf(s - m);
       l += p;
 #pragma unroll
-      for (int d = 0; d < 16; ++d) o[d] = fmaf(p, Vs[j * 16 + d], o[d]);
+      for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[j * D + d], o[d]);
     }
     const float inv = 1.f / l;
-    float *dst = out + ((size_t)b * N + i) * VRP_EMB + h * 16;
+    float *dst = out + ((size_t)b * N + i) * VRP_EMB + h * D;
 #pragma unroll
-    for (int d = 0; d < 16; d += 4)
+    for (int d = 0; d < D; d += 4)
       *reinterpret_cast<float4 *>(dst + d) =
           make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
   }
 }
+// heads = 128 / D waves per graph, four per workgroup; LDS: K_h | V_h of every wave
+static int launch_attention_valu(const float *qkv, float *att, int B, int N, int heads, hipStream_t st) {
+  const size_t lds = (size_t)4 * N * 2 * (128 / heads) * sizeof(float);
+  VRP_REQUIRE(lds <= 160 * 1024, "encoder attention: N=%d too large for %d heads", N, heads);
+#define VRP_ATT_VALU(D_)                                                                          \
+  do {                                                                                            \
+    static VrpAttrOnce attr_set;                                                                  \
+    if (!attr_set.done() && lds > 64 * 1024) {                                                    \
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_attention_kernel<D_>),      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { \
+        vrp_set_error("encoder_attention: cannot raise dynamic LDS");                             \
+        return 1;                                                                                 \
+      }                                                                                           \
+      attr_set.mark();                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL(encoder_attention_kernel<D_>, dim3(B, heads / 4), dim3(256), lds, st, qkv, att, N); \
+  } while (0)
+  if (heads == 8) VRP_ATT_VALU(16);
+  else if (heads == 4) VRP_ATT_VALU(32);
+  else VRP_ATT_VALU(8);
+#undef VRP_ATT_VALU
+  VRP_CHECK_LAUNCH("encoder_attention");
+  return 0;
+}
+// encoder heads of a weight struct (0 = the reference's default)
+static inline int enc_heads(const vrp_encoder_weights *w) { return w->heads ? w->heads : 8; }
 
 // ---- small batches (B*N <= 16384, N <= 64): in_proj + attention of one graph in ONE launch ----
 // At ~10 k rows the QKV GEMM and the attention kernel are two launch-latency-bound launches
@@ -2219,7 +2249,7 @@ static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, co
 // small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
 static bool encoder_stack_applies(const vrp_encoder_weights *w, int train, int B, int N) {
   static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
-  return !train && !stack_off && N <= 48 && w->hidden % 128 == 0 && w->num_layers <= 8 &&
+  return !train && !stack_off && enc_heads(w) == 8 && N <= 48 && w->hidden % 128 == 0 && w->num_layers <= 8 &&
          (B + 48 / N - 1) / (48 / N) <= 512;
 }
 
@@ -2296,6 +2326,8 @@ static int encoder_check(const vrp_encoder_weights *w, int B, int N) {
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder: bad shape B=%d N=%d", B, N);
   VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8, "encoder: num_layers=%d", w->num_layers);
   VRP_REQUIRE(w->hidden % 128 == 0, "encoder: hidden=%d must be a multiple of 128", w->hidden);
+  VRP_REQUIRE(enc_heads(w) == 8 || enc_heads(w) == 4 || enc_heads(w) == 16,
+              "encoder: heads=%d (4, 8 or 16)", w->heads);
   VRP_REQUIRE(w->node_dim >= 1 && w->node_dim <= 3, "encoder: node_dim=%d", w->node_dim);
   return 0;
 }
@@ -2383,7 +2415,10 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
   for (int l = 0; l < w->num_layers; ++l) {
     const vrp_encoder_layer &L = w->layer[l];
     // out = bn1(x + MHA(x))
-    static const char *qa_off = getenv("VRP_UNFUSED_QKV");  // A/B aid
+    static const char *qa_env = getenv("VRP_UNFUSED_QKV");  // A/B aid
+    const int heads = enc_heads(w);
+    // (four or sixteen heads: every fused kernel is built for eight -- GEMM + VALU attention)
+    const bool qa_off = qa_env != nullptr || heads != 8;
     if (N <= 64 && R <= 16 * 1024 && !qa_off) {
       // small batches: in_proj + attention of a graph in one launch
       int r;
@@ -2395,19 +2430,17 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       // large batches, eval mode: in_proj + attention of 80 / N whole graphs per workgroup
       // (only when the graphs fill at least three quarters of the five row tiles)
       if (int r = launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
-    } else if (qkv_attn_graph_applies(train, B, N)) {
+    } else if (heads == 8 && qkv_attn_graph_applies(train, B, N)) {
       // 64 < N <= 102, eval mode: in_proj + attention of one graph per workgroup pass, q|k|v in LDS
       if (int r = launch_qkv_attn_graph(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
     } else {
       if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
                                      ws.qkv, 384, R, 384, 128, 0, st)) return r;
       static const char *valu_att = getenv("VRP_ATTENTION_VALU");  // A/B aid
-      if (!valu_att) {
+      if (!valu_att && heads == 8) {
         if (int r = launch_attention_mfma(ws.qkv, ws.att, B, N, st)) return r;
       } else {
-        const size_t lds = (size_t)4 * N * 32 * sizeof(float);
-        hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, ws.qkv, ws.att, N);
-        VRP_CHECK_LAUNCH("encoder_attention");
+        if (int r = launch_attention_valu(ws.qkv, ws.att, B, N, heads, st)) return r;
       }
     }
     static const char *unfused = getenv("VRP_ENCODER_UNFUSED");  // A/B aid
@@ -2562,6 +2595,7 @@ extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int
                                         int update_running, void *stream) {
   VRP_REQUIRE(w && x && emb && tape, "encoder_tape: NULL argument");
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder_tape: bad shape B=%d N=%d", B, N);
+  VRP_REQUIRE(enc_heads(w) == 8 || enc_heads(w) == 4 || enc_heads(w) == 16, "encoder: heads=%d", w->heads);
   VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8 && w->hidden % 128 == 0,
               "encoder_tape: unsupported architecture");
   hipStream_t st = (hipStream_t)stream;
@@ -2578,12 +2612,10 @@ extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int
     if (int r = vrp_launch_gemm_nt(T.X, 128, P.in_proj_weight, 128, P.in_proj_bias, nullptr, 0,
                                    T.QKV, 384, R, 384, 128, 0, st)) return r;
     static const char *valu_att = getenv("VRP_ATTENTION_VALU");  // A/B aid
-    if (!valu_att) {
+    if (!valu_att && enc_heads(w) == 8) {
       if (int r = launch_attention_mfma(T.QKV, T.ATT, B, N, st)) return r;
     } else {
-      const size_t lds = (size_t)4 * N * 32 * sizeof(float);
-      hipLaunchKernelGGL(encoder_attention_kernel, dim3(B, 2), dim3(256), lds, st, T.QKV, T.ATT, N);
-      VRP_CHECK_LAUNCH("encoder_attention");
+      if (int r = launch_attention_valu(T.QKV, T.ATT, B, N, enc_heads(w), st)) return r;
     }
     if (int r = vrp_launch_gemm_nt(T.ATT, 128, P.out_proj_weight, 128, P.out_proj_bias, T.X, 128,
                                    T.Z1, 128, R, 128, 128, 0, st)) return r;
@@ -2721,7 +2753,7 @@ extern "C" int vrp_encoder_backward(const vrp_encoder_weights *w, const vrp_enco
     if (int r = vrp_launch_transpose(P.out_proj_weight, 128, 128, 128, s.WT, st)) return r;
     if (int r = vrp_launch_gemm_nt(s.gB, 128, s.WT, 128, nullptr, nullptr, 0, s.gC, 128, R, 128,
                                    128, 0, st)) return r;                        // gC = dATT
-    if (int r = vrp_launch_attention_bwd(T.QKV, s.gC, s.gQKV, B, N, st)) return r;
+    if (int r = vrp_launch_attention_bwd(T.QKV, s.gC, s.gQKV, B, N, st, enc_heads(w))) return r;
     if (int r = vrp_launch_colsum(s.gQKV, 384, R, 384, G.in_proj_bias, 0, s.csws, st)) return r;
     if (int r = vrp_launch_gemm_tn(s.gQKV, 384, T.X, 128, G.in_proj_weight, R, 384, 128, 0, s.slab,
                                    st)) return r;                                // dWin (384,128)

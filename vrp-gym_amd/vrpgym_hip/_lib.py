@@ -32,7 +32,7 @@ class EncoderLayer(C.Structure):
 class EncoderWeights(C.Structure):
     """struct vrp_encoder_weights"""
     _fields_ = [("node_dim", C.c_int32), ("depot_dim", C.c_int32), ("hidden", C.c_int32),
-                ("num_layers", C.c_int32),
+                ("num_layers", C.c_int32), ("heads", C.c_int32), ("reserved_", C.c_int32),
                 ("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
                 ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
                 ("layer", EncoderLayer * 8)]
