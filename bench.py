@@ -647,6 +647,11 @@ def main():
             # the whole device, serialised only within a process) would not all be resident --
             # one launch per step instead.  Never the case with one process per GPU.
             os.environ["VRP_NO_PERSISTENT"] = "1"
+        elif world == 2:
+            # two processes on ONE GPU: one wave per graph (2 x 1024 such workgroups are resident
+            # together; two four-wave grids sized against the whole device each are not, and
+            # nothing serialises the launches of two PROCESSES)
+            os.environ["VRP_PERSISTENT_WAVES"] = "1"
     if world > 1 and not one_gpu and torch.cuda.device_count() < world:
         # (the parent counted in sysfs; a rank sees what the runtime really offers)
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
