@@ -73,24 +73,6 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
   VRP_REQUIRE(0 <= t_begin && t_begin <= t_end && t_end <= max_steps,
               "rollout_steps_range: [%d,%d) outside [0,%d]", t_begin, t_end, max_steps);
   VRP_REQUIRE(derived && env && emb && dec_workspace && io, "rollout_steps_range: NULL argument");
-  if (t_end == max_steps && t_end - t_begin >= 2 &&
-      vrp_tile_persistent_eligible(kind, env->B, env->N, max_steps, flags, io)) {
-    // 64 < N <= 100, at most one 8-graph workgroup per compute unit: step 0 as its own launch
-    // (the first-node fold follows it), every later step inside ONE launch that keeps the
-    // embedding tiles in registers (decoder_tile2.hip)
-    if (t_begin == 0) {
-      if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
-                                  flags, stream)) return r;
-      t_begin = 1;
-    }
-    VRP_REQUIRE(env->kind == kind && io->acc_loss && io->acc_logp && io->notdone,
-                "rollout_steps_range: bad env/io");
-    VRP_REQUIRE(!(flags & VRP_STEP_SAMPLE) || io->noise || io->noise_seed,
-                "rollout_steps_range: sampling needs io.noise or io.noise_seed");
-    const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
-                                                max_steps, flags);
-    return vrp_launch_tile_persistent_steps(sp, dec_workspace, (hipStream_t)stream);
-  }
   const int pwaves = (t_end == max_steps && t_end - t_begin >= 2)
                          ? vrp_persistent_width(kind, env->B, env->N, max_steps, flags, io,
                                                 (hipStream_t)stream) : 0;

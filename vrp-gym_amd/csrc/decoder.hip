@@ -684,7 +684,6 @@ static bool hybrid_shape(int kind, int B, int N) {
 extern "C" const char *vrp_step_kernel_name(int kind, int B, int N, int flags) {
   vrp_rollout_io none = {};
   if (vrp_persistent_eligible(kind, B, N, 2, flags, &none, nullptr)) return "decode_persistent_kernel";
-  if (vrp_tile_persistent_eligible(kind, B, N, 2, flags, &none)) return "decode_tile_persistent_kernel<100>";
   const bool v2 = !tile_v1_forced() && vrp_tile2_supported(N);
   const char *tile = v2 ? (kind == VRP_KIND_IRP
                                ? (N <= 40 ? "decode_step_tile_zmfma_kernel<40, 2, true>" : "decode_step_tile_zmfma_kernel<100, 1, true>")

@@ -600,561 +600,11 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
 }
 
 
-// =================================================================================================
-// The tile RESIDENT for a whole episode (round 4): steps t0 .. T-1 of a TSP / VRP episode in ONE
-// launch, for batches that put at most one 8-graph workgroup on every compute unit (B <= 8 x CUs:
-// configs[4]'s per-GPU shard, VRP-100 x 2048, is exactly that).  A wave keeps its graph's (N,128)
-// tile in registers (+ the last k-steps in LDS) ACROSS steps: the per-step kernel above spends 20
-// of its 36 us re-reading 105 MB of embeddings that have not changed since the encoder wrote them.
-// Round 3 tried this with the lane = two columns layout and lost to spills (450 registers of tile
-// + 200 of working set per wave pair); the operand-order layout's working set (glimpse sums on the
-// matrix cores, 16-lane logit reduction) fits next to the 184 tile registers.
-// What a kernel boundary per step used to provide comes from decoder_persistent.hip's protocol:
-//   * QUIRK D3 (graph_decoder.py:93-94): head h of graph b adds the mask row of graph
-//     (8b + h) mod B.  A graph publishes its mask for step t + 1 as two 8-byte words (63 nodes
-//     each, bit 63 = valid), agent-scope stores; a reader polls the sixteen words it needs.
-//   * the batch-wide `done` (tsp.py:95): per-graph ta / way-back bookkeeping and
-//     persistent_finalize_kernel, unchanged.
-// A finished graph's wave keeps arriving at the three workgroup barriers of a step (the weight
-// folds are a workgroup affair) until all eight graphs of its workgroup have finished.
-// Requires every workgroup of the grid to be resident: one per CU (137 KB of LDS), grid <= the
-// usable CUs the census found; spins are bounded, a wave that gives up poisons the episode (NaN)
-// exactly as decode_persistent_kernel does.
-struct TilePersistParams {
-  StepParams s;               // s.t = first step of the launch (>= 1)
-  unsigned long long *hist;   // (2 (max_steps + 1), B): words w = 0, 1 of step t at row 2 t + w
-  int32_t *ta;
-  float *ret;
-  int32_t *wb_cur;
-  double *wb_load;
-  int32_t *err;
-};
-#define TP_VALID (1ull << 63)
-#ifndef TP_KL
-#define TP_KL 3   // k-steps of the tile kept in LDS (2 KB per graph each): 176 tile registers
-#endif
-#define TP_SPIN_LIMIT (1 << 20)
-
-template <int NMAX>
-__global__ __launch_bounds__(512, 2) void decode_tile_persistent_kernel(TilePersistParams pp) {
-  const StepParams &p = pp.s;
-  constexpr int NW = 8, GPB = 8, ROWS = 8;
-  constexpr int KS = NMAX / 4, NPL = (NMAX + 63) / 64;
-  constexpr int KL = TP_KL, KR = KS - KL;   // k-steps in LDS / in registers
-  static_assert(NMAX % 4 == 0 && NMAX > 64 && NMAX <= 124, "two nodes per lane, two words per mask");
-  const int t0 = p.t;
-  if (p.io.notdone[t0 - 1] == 0) return;  // the batch was done before this launch
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *a_s = smem;                      // [GPB][NMAX*8]
-  float *zs = a_s + GPB * NMAX * 8;       // [ROWS][T2_ZG]
-  float *os = zs + ROWS * T2_ZG;          // [ROWS][T2_OS]
-  float *ws = os + ROWS * T2_OS;          // [ROWS][T2_WS]
-  float *us = ws + ROWS * T2_WS;          // [GPB][T2_US]
-  float4 *tl = reinterpret_cast<float4 *>(us + GPB * T2_US);   // [GPB][KL][2][64]
-  int *fin_s = reinterpret_cast<int *>(tl + (size_t)GPB * KL * 128);  // [8] graph finished
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int N = p.N, B = p.B;
-  const int i16 = lane & 15, q = lane >> 4;
-  const int g = wave;
-  const int braw = blockIdx.x * GPB + wave;
-  const bool active = braw < B;
-  const int b = __builtin_amdgcn_readfirstlane(active ? braw : B - 1);
-  bool inN[NPL];
-  int ln[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) { inN[i] = lane + 64 * i < N; ln[i] = inN[i] ? lane + 64 * i : 0; }
-
-  // ---- once per episode: the tile, the graph's env row ----------------------------------------
-  float4 T[KR][2];
-  float4 *tlg = tl + (size_t)g * KL * 128 + lane;
-  {
-    const __amdgpu_buffer_rsrc_t tile_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.emb + (size_t)b * N * VRP_EMB), 0, N * VRP_EMB * 4, 0x00020000);
-    const int tile_voff = q * (VRP_EMB * 4) + i16 * 16;
-    auto tile_load = [&](int j, int hf) {
-      const t2_v4f v = __builtin_bit_cast(t2_v4f, __builtin_amdgcn_raw_buffer_load_b128(
-          tile_rsrc, tile_voff + 256 * hf, j * (4 * VRP_EMB * 4), T2_TILE_AUX));
-      return make_float4(v[0], v[1], v[2], v[3]);
-    };
-#pragma unroll
-    for (int j = 0; j < KL; ++j)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) tlg[(2 * j + hf) * 64] = tile_load(KR + j, hf);
-#pragma unroll
-    for (int j = 0; j < KR; ++j)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) T[j][hf] = tile_load(j, hf);
-  }
-  const uint8_t *mask0 = p.env.mask + (size_t)(t0 & 1) * B * N;
-  // (TSP / VRP: after generate_mask's fix-ups the mask column IS the visited row, tsp.py:131-148,
-  // vrp.py:13-37 -- one loop-carried register per node slot)
-  int vis[NPL];
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) vis[i] = inN[i] ? mask0[(size_t)b * N + ln[i]] : 1;
-  int cur = p.env.cur[b];
-  const int dep = p.env.depot[b];
-  int last = __builtin_amdgcn_readfirstlane(p.last[b]);
-  float accl = p.io.acc_loss[b], accp = p.io.acc_logp[b];
-  int ta = -1, wb_cur = -1;
-  float ret = 0.f;
-  bool fin = !active;   // (a graph beyond B: nothing to do, but its wave joins the barriers)
-  if (lane == 0) fin_s[wave] = fin ? 1 : 0;
-  const size_t row = (size_t)b * 8 * N;
-
-  for (int t = t0; t < p.max_steps; ++t) {
-    // Every address below is re-derived from an offset the compiler cannot see through: hoisted
-    // out of the step loop, the ~100 loop-invariant 64-bit addresses of a step (score / base rows
-    // per head, weight fragments, LDS rows) would sit in registers next to the tile and spill
-    // (first cut: 265 spilled registers).
-    int zero;
-    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
-    const float *SLp = p.SL + zero, *basep = p.base ? p.base + zero : nullptr;
-    const float *cvecp = p.cvec + zero, *WvPp = p.WvP + zero, *MPp = p.MP + zero;
-    const float *bvp = p.bv + zero, *mbp = p.mb + zero;
-    const float *noisep = p.io.noise ? p.io.noise + zero : nullptr;
-    const double *posp = p.env.pos + zero;
-    unsigned long long *histp = pp.hist + zero;
-    float *a_sl = a_s + zero, *zsl = zs + zero, *osl = os + zero, *wsl = ws + zero, *usl = us + zero;
-    float4 *tlgl = tlg + zero;
-    const int lnz0 = ln[0] + zero, lnz1 = ln[NPL - 1] + zero;
-    const int lnz[2] = {lnz0, lnz1};
-    if (!fin) {
-      // ---- score row of this step + the eight other graphs' masks ---------------------------
-      const float *srow = SLp + ((size_t)b * N + last) * 8 * N;
-      float sv[NPL][8], bv_[NPL][8];
-#pragma unroll
-      for (int i = 0; i < NPL; ++i)
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          sv[i][h] = srow[h * N + lnz[i]];
-          bv_[i][h] = basep ? basep[row + h * N + lnz[i]] : 0.f;
-        }
-      int mo[NPL][8];
-      if (t == t0) {   // first step of the launch: the byte rows the previous launch wrote
-#pragma unroll
-        for (int i = 0; i < NPL; ++i)
-#pragma unroll
-          for (int h = 0; h < 8; ++h) mo[i][h] = mask0[(size_t)((b * 8 + h) % B) * N + ln[i]];
-      } else {
-        // lanes 0..15: word (lane & 1) of graph (8b + (lane >> 1)) mod B
-        unsigned long long w = TP_VALID;
-        if (lane < 16) {
-          const unsigned long long *src =
-              histp + ((size_t)2 * t + (lane & 1)) * B + (b * 8 + (lane >> 1)) % B;
-          int spins = 0;
-          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while (!(w & TP_VALID)) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > TP_SPIN_LIMIT) break;
-            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        if (__any(!(w & TP_VALID))) {
-          // gave up (the grid is not fully resident, or a graph it depends on gave up): flag the
-          // episode, let everybody who waits for THIS graph go on, leave the step loop
-          if (lane == 0) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long b0 = __ballot(inN[0] && vis[0]);
-          const unsigned long long b1 = __ballot(inN[NPL - 1] && vis[NPL - 1]);
-          const unsigned long long w0 = (b0 & ~TP_VALID) | TP_VALID;
-          const unsigned long long w1 = (((b0 >> 63) | (b1 << 1)) & ~TP_VALID) | TP_VALID;
-          for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64) {
-            __hip_atomic_store(histp + ((size_t)2 * tt) * B + b, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(histp + ((size_t)2 * tt + 1) * B + b, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          fin = true;
-        } else {
-          const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
-#pragma unroll
-          for (int h = 0; h < 8; ++h) {
-            const unsigned long long w0 =
-                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 2 * h) << 32) |
-                (unsigned)__builtin_amdgcn_readlane((int)lo, 2 * h);
-            const unsigned long long w1 =
-                ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 2 * h + 1) << 32) |
-                (unsigned)__builtin_amdgcn_readlane((int)lo, 2 * h + 1);
-            // node n: word n / 63, bit n % 63.  Slot 0 = node lane, slot 1 = node lane + 64
-            mo[0][h] = lane < 63 ? (int)((w0 >> lane) & 1ull) : (int)(w1 & 1ull);
-            if (NPL > 1) mo[NPL - 1][h] = (int)((w1 >> ((lane + 1) & 63)) & 1ull);
-          }
-        }
-      }
-      if (!fin) {
-        // ---- glimpse attention weights (lane = n), one wave-wide shift for all eight heads ---
-        float sm[NPL][8], mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < NPL; ++i)
-#pragma unroll
-          for (int h = 0; h < 8; ++h) {
-            const float v = inN[i] ? sv[i][h] + bv_[i][h] + (float)mo[i][h] : -INFINITY;
-            sm[i][h] = v;
-            mx = fmaxf(mx, v);
-          }
-        const float M = wave_max(mx);
-        float *ag = a_sl + (size_t)g * NMAX * 8;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          float ev[NPL], es = 0.f;
-#pragma unroll
-          for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(sm[i][h] - M) : 0.f; es += ev[i]; }
-          float sum = wave_sum(es);
-          if (!(sum > 1e-30f)) {  // wave-uniform, practically never: per-head maximum
-            float hm = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) hm = fmaxf(hm, sm[i][h]);
-            hm = wave_max(hm);
-            es = 0.f;
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) { ev[i] = inN[i] ? exp_nonpos(sm[i][h] - hm) : 0.f; es += ev[i]; }
-            sum = wave_sum(es);
-          }
-          float r = __builtin_amdgcn_rcpf(sum);
-          r = fmaf(fmaf(-sum, r, 1.f), r, r);
-#pragma unroll
-          for (int i = 0; i < NPL; ++i)
-            if (lane + 64 * i < NMAX) ag[(lane + 64 * i) * 8 + h] = ev[i] * r;  // 0 beyond N
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): a_s of this graph is this wave's own
-        __builtin_amdgcn_wave_barrier();
-        // ---- z_h = sum_n a[h][n] e_n on the matrix cores, from the resident tile -------------
-        f32x4 zacc[2][4];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-          for (int el = 0; el < 4; ++el) zacc[hf][el] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *ap = a_sl + (size_t)g * NMAX * 8 + q * 8 + (i16 & 7);
-        float an = ap[0];
-#pragma unroll
-        for (int j = 0; j < KS; ++j) {
-          const float ac = an;
-          if (j + 1 < KS) an = ap[(j + 1) * 32];
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const float4 tt4 = j < KR ? T[j < KR ? j : 0][hf] : tlgl[(2 * (j - KR) + hf) * 64];
-            zacc[hf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, tt4.x, zacc[hf][0], 0, 0, 0);
-            zacc[hf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, tt4.y, zacc[hf][1], 0, 0, 0);
-            zacc[hf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, tt4.z, zacc[hf][2], 0, 0, 0);
-            zacc[hf][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, tt4.w, zacc[hf][3], 0, 0, 0);
-          }
-        }
-        if (q < 2) {
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              *reinterpret_cast<float4 *>(zsl + g * T2_ZG + (4 * q + i) * 128 + 64 * hf + 4 * i16) =
-                  make_float4(zacc[hf][0][i], zacc[hf][1][i], zacc[hf][2][i], zacc[hf][3][i]);
-        }
-      }
-    }
-    if (lane == 0 && fin) fin_s[wave] = 1;
-    __syncthreads();
-    {  // every graph of the workgroup finished: the workgroup leaves (uniform over the waves)
-      int all = 1;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) all &= fin_s[w8];
-      if (all) break;
-    }
-
-    // ---- the two weight folds, all eight waves (a finished graph's row is dead weight) --------
-    constexpr int PF = T2_PF, PF2 = T2_PF2;
-    const int koff = 4 * q;
-    float4 mw[PF2];
-    {
-      const int h = wave;
-      const float4 *wbase = reinterpret_cast<const float4 *>(WvPp) + (size_t)h * 24 * 64 + lane;
-      float4 wq[PF][3];
-#pragma unroll
-      for (int j = 0; j < PF; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) wq[j][c] = wbase[(3 * j + c) * 64];
-      f32x4 acc[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float bb = bvp[h * VRP_HD + 16 * c + i16];
-        acc[c] = f32x4{bb, bb, bb, bb};
-      }
-      const float *arow = zsl + (i16 & (ROWS - 1)) * T2_ZG + h * 128 + koff;
-#pragma unroll
-      for (int k4 = 0; k4 < 8; ++k4) {
-        const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
-        const float av[4] = {a.x, a.y, a.z, a.w};
-        float4 w[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          w[c] = wq[k4 % PF][c];
-          if (k4 + PF < 8) wq[k4 % PF][c] = wbase[(3 * (k4 + PF) + c) * 64];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], w[c].x, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], w[c].y, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], w[c].z, acc[c], 0, 0, 0);
-          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], w[c].w, acc[c], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4)
-          if (4 * q + r4 < ROWS) osl[(4 * q + r4) * T2_OS + h * VRP_HD + 16 * c + i16] = acc[c][r4];
-    }
-    const float4 *mrow = reinterpret_cast<const float4 *>(MPp) + (size_t)wave * 24 * 64 + lane;
-#pragma unroll
-    for (int j = 0; j < PF2; ++j) mw[j] = mrow[j * 64];
-    __syncthreads();
-    {
-      const int ct = wave;
-      const float mbv = mbp[ct * 16 + i16];
-      f32x4 acc0 = {mbv, mbv, mbv, mbv}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float *arow = osl + (i16 & (ROWS - 1)) * T2_OS + koff;
-#pragma unroll
-      for (int k4 = 0; k4 < 24; ++k4) {
-        const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * k4);
-        const float4 w = mw[k4 % PF2];
-        if (k4 + PF2 < 24) mw[k4 % PF2] = mrow[(k4 + PF2) * 64];
-        f32x4 &acc = (k4 & 1) ? acc1 : acc0;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-        if (4 * q + r4 < ROWS) wsl[(4 * q + r4) * T2_WS + ct * 16 + i16] = acc0[r4] + acc1[r4];
-    }
-    __syncthreads();
-    if (fin) continue;
-
-    // ---- pointer logits, action, env step ------------------------------------------------------
-    const float4 w0 = *reinterpret_cast<const float4 *>(wsl + g * T2_WS + 4 * i16);
-    const float4 w1 = *reinterpret_cast<const float4 *>(wsl + g * T2_WS + 64 + 4 * i16);
-    float *ug = usl + g * T2_US;
-    float cv[NPL], q_noise[NPL];
-    double2 xy[NPL];
-#pragma unroll
-    for (int k = 0; k < (KS + 15) / 16; ++k) {
-      float pv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int j = 16 * k + i;
-        if (j < KS) {
-          const float4 t0v = j < KR ? T[j < KR ? j : 0][0] : tlgl[(2 * (j - KR)) * 64];
-          const float4 t1v = j < KR ? T[j < KR ? j : 0][1] : tlgl[(2 * (j - KR) + 1) * 64];
-          float sacc = t0v.x * w0.x;
-          sacc = fmaf(t0v.y, w0.y, sacc); sacc = fmaf(t0v.z, w0.z, sacc); sacc = fmaf(t0v.w, w0.w, sacc);
-          sacc = fmaf(t1v.x, w1.x, sacc); sacc = fmaf(t1v.y, w1.y, sacc); sacc = fmaf(t1v.z, w1.z, sacc);
-          pv[i] = fmaf(t1v.w, w1.w, sacc);
-        } else {
-          pv[i] = 0.f;
-        }
-      }
-      const float tot = row_reduce_scatter16(pv, i16);
-      if (16 * k + i16 < KS) ug[4 * (16 * k + i16) + q] = tot;
-      if (k == 0) {   // the constant rows of the graph: L2-resident, requested under the second batch
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-          cv[i] = cvecp[(size_t)b * N + lnz[i]];
-          xy[i] = reinterpret_cast<const double2 *>(posp)[(size_t)b * N + lnz[i]];
-          q_noise[i] = !p.sample ? 1.f
-                       : noisep ? noisep[((size_t)t * B + b) * N + lnz[i]]
-                                    : vrp_exp1_noise(p.io.noise_seed, t, b, ln[i]);
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    float u[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const float x = (lane + 64 * i < NMAX) ? ug[lane + 64 * i] : 0.f;
-      u[i] = (inN[i] && !vis[i]) ? p.clip * tanhf(x + cv[i]) : -INFINITY;  // graph_decoder.py:97-98
-    }
-    auto argmax_nodes = [&](const float (&v)[NPL]) {
-      float mx = v[0];
-#pragma unroll
-      for (int i = 1; i < NPL; ++i) mx = fmaxf(mx, v[i]);
-      const float m = wave_max(mx);
-      int res = 0;
-      bool found = false;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const unsigned long long hit = __ballot(v[i] == m);
-        if (!found && hit) { res = 64 * i + __ffsll((long long)hit) - 1; found = true; }
-      }
-      return res;
-    };
-    int idx;
-    float logp = 0.f;
-    if (!p.sample) {
-      idx = argmax_nodes(u);
-    } else {
-      float mx = u[0];
-#pragma unroll
-      for (int i = 1; i < NPL; ++i) mx = fmaxf(mx, u[i]);
-      const float m = wave_max(mx);
-      float se = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) se += expf(u[i] - m);
-      se = wave_sum(se);
-      const float lse = m + logf(se);
-      float l[NPL], lmx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) { l[i] = u[i] - lse; lmx = fmaxf(lmx, l[i]); }
-      const float lm = wave_max(lmx);
-      float pe[NPL], ps = 0.f;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) { pe[i] = expf(l[i] - lm); ps += pe[i]; }
-      ps = wave_sum(ps);
-      float ratio[NPL];
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) ratio[i] = inN[i] ? (pe[i] / ps) / q_noise[i] : -1.f;
-      idx = argmax_nodes(ratio);
-      const float lsel = (NPL > 1 && idx >= 64) ? l[NPL - 1] : l[0];
-      logp = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lsel),
-                                                                 idx & 63));
-    }
-    idx = __builtin_amdgcn_readfirstlane(idx);
-    // ---- env.step on registers (same operation order as env_device.h) ---------------------
-    auto node_f64 = [&](const double (&v)[NPL], int n) {
-      return (NPL > 1 && n >= 64) ? readlane_f64(v[NPL - 1], n - 64) : readlane_f64(v[0], n);
-    };
-    double px[NPL], py[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) { px[i] = xy[i].x; py[i] = xy[i].y; }
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) if (lane + 64 * i == idx) vis[i] = 1;  // tsp.py:86
-    const double dx = node_f64(px, cur) - node_f64(px, idx);
-    const double dy = node_f64(py, cur) - node_f64(py, idx);
-    const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
-    auto all_visited = [&]() {
-      int ok = 1;
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) ok &= vis[i];
-      return __all(ok);
-    };
-    const bool done = all_visited();                              // before the fix-ups, tsp.py:95
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      if (lane + 64 * i == dep) {
-        if (idx == dep) vis[i] = 1;                               // tsp.py:141-142
-        else if (p.kind != VRP_KIND_TSP) vis[i] = 0;              // vrp.py:28-31
-      }
-    }
-    if (all_visited()) {                                          // tsp.py:145-146
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) if (lane + 64 * i == dep) vis[i] = 0;
-    }
-    const unsigned long long b0 = __ballot(inN[0] && vis[0]);
-    const unsigned long long b1 = __ballot(inN[NPL - 1] && vis[NPL - 1]);
-    const unsigned long long word0 = (b0 & ~TP_VALID) | TP_VALID;
-    const unsigned long long word1 = (((b0 >> 63) | (b1 << 1)) & ~TP_VALID) | TP_VALID;
-    const bool way_back = ta >= 0;  // this step is the forced return after `done`
-    const bool finish = done && (way_back || p.kind == VRP_KIND_TSP || idx == dep);
-    if (lane == 0) {
-      if (p.io.actions) p.io.actions[(size_t)t * B + b] = idx;
-      if (p.io.step_logp) p.io.step_logp[(size_t)t * B + b] = logp;
-      if (!finish) {
-        __hip_atomic_store(histp + ((size_t)2 * (t + 1)) * B + b, word0, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(histp + ((size_t)2 * (t + 1) + 1) * B + b, word1, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (way_back) {
-      ret = (float)(-dist);
-      wb_cur = cur;        // where the episode ends if the batch was done at ta
-    } else {
-      accl += (float)(-dist);  // fp32 accumulate in step order, tsp_agent:85
-      accp += logp;
-      if (done) ta = t;
-    }
-    cur = idx;
-    last = idx;
-    if (finish) {
-      // the mask is constant from here on: publish it for every remaining step, fill the traces
-      // the way the reference's self-loops on the depot would
-      for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64) {
-        __hip_atomic_store(histp + ((size_t)2 * tt) * B + b, word0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(histp + ((size_t)2 * tt + 1) * B + b, word1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0)
-        for (int tt = t + 1; tt < p.max_steps; ++tt) {
-          if (p.io.actions) p.io.actions[(size_t)tt * B + b] = idx;
-          if (p.io.step_logp) p.io.step_logp[(size_t)tt * B + b] = 0.f;
-        }
-      fin = true;
-    }
-  }
-  // ---- state back to memory ---------------------------------------------------------------
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < NPL; ++i)
-      if (inN[i]) p.env.visited[(size_t)b * N + lane + 64 * i] = (uint8_t)vis[i];
-    if (lane == 0) {
-      p.env.cur[b] = cur;
-      p.io.acc_loss[b] = accl;
-      p.io.acc_logp[b] = accp;
-      p.last[b] = last;
-      pp.ta[b] = ta < 0 ? p.max_steps - 1 : ta;
-      pp.ret[b] = ret;
-      pp.wb_cur[b] = wb_cur;
-      pp.wb_load[b] = 1.0;
-    }
-  }
-}
-
-// steps sp.t .. max_steps-1 (sp.t >= 1) of a TSP / VRP episode with the tile resident
-bool vrp_tile_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
-                                  const vrp_rollout_io *io) {
-  // OPT-IN (VRP_TILE_PERSISTENT=1): measured at VRP-100 x 2048 sampling it runs every step in
-  // 31.7 us (3.52 ms for the 111 steps of an episode) against 31.5 us for the per-step schedule
-  // (36 us raw-tile steps early, ~9-20 us table steps late): without the 20 us load phase a step
-  // still costs the exposed glimpse sums (6 us), the two weight folds (8.4 us), logits and env
-  // (5 us), the score-row round trip and the wait for the slowest of eight other graphs -- and
-  // inside the step loop hipcc spills 92 of the registers the per-step kernel keeps.
-  static const bool on = getenv("VRP_TILE_PERSISTENT") != nullptr &&
-                         getenv("VRP_NO_PERSISTENT") == nullptr && !tile_v1_forced();
-  if (!on || kind == VRP_KIND_IRP || N <= 64 || N > 100 || max_steps < 2) return false;
-  if (io->logits || io->forced || io->mask_trace || io->load_trace) return false;
-  if (flags & (VRP_STEP_TILE_KERNEL | VRP_STEP_THROUGHPUT_KERNEL | VRP_STEP_DECODE_ONLY |
-               VRP_STEP_TABLE_KERNEL | VRP_STEP_NO_PERSISTENT)) return false;
-  if (2 * (max_steps + 1) > hist_rows(N)) return false;
-  static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;
-  const int cus = force ? 1 << 20 : vrp_usable_cus();
-  return (B + 7) / 8 <= cus;   // one 8-graph workgroup per compute unit, all resident
-}
-
-int vrp_launch_tile_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st) {
-  constexpr int NMAX = 100, GPB = 8, KL = TP_KL;
-  DecWs wsd = carve_decws(workspace, sp.B, sp.N);
-  TilePersistParams pp;
-  pp.s = sp;
-  pp.hist = wsd.hist;
-  pp.ta = wsd.ta; pp.ret = wsd.ret; pp.wb_cur = wsd.wb_cur; pp.wb_load = wsd.wb_load;
-  pp.err = wsd.err;
-  const size_t lds = sizeof(float) * ((size_t)GPB * NMAX * 8 + GPB * (T2_ZG + T2_OS + T2_WS) +
-                                      (size_t)GPB * T2_US + (size_t)GPB * KL * 512) + 64;
-  static VrpAttrOnce attr_set;
-  if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&decode_tile_persistent_kernel<NMAX>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      vrp_set_error("decode_tile_persistent: cannot raise dynamic LDS to %zu bytes", lds);
-      return 1;
-    }
-    attr_set.mark();
-  }
-  void *token = nullptr;
-  vrp_persistent_serialize_begin(st, &token);
-  hipLaunchKernelGGL(decode_tile_persistent_kernel<NMAX>, dim3((sp.B + GPB - 1) / GPB), dim3(512),
-                     lds, st, pp);
-  VRP_CHECK_LAUNCH("decode_tile_persistent");
-  if (int r = vrp_launch_persistent_finalize(sp, workspace, st)) return r;
-  vrp_persistent_serialize_end(st, token);
-  return 0;
-}
+// (Round 4, measured and removed: the tile RESIDENT for a whole episode -- steps 1..T-1 of VRP-100 x
+// 2048 in ONE launch, the tile in registers across steps, masks exchanged as hand-off words as in
+// decoder_persistent.hip: 3.52 ms for 111 steps = 31.7 us per step against 31.5 for the per-step
+// schedule; hipcc spilled 92 registers inside the step loop.  DESIGN.md 3.5.1; the kernel is in the
+// history of this file, commit 2458ff7.)
 
 template <int NMAX, int GPW, bool IRP>
 static int launch_tile2(const StepParams &p, hipStream_t st) {
