@@ -236,7 +236,16 @@ int vrp_rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived,
 /* Name of the kernel(s) the encoder phase launches for this shape (profiles, bench line). */
 const char *vrp_encoder_kernel_name(const vrp_encoder_weights *w, int train, int B, int N);
 
-/* Only the T-step decode+env loop of vrp_rollout (emb and prologue already done). */
+/* Only the T-step decode+env loop of vrp_rollout (emb and prologue already done).
+ * Host-side behaviour of the loop (vrp_rollout, vrp_rollout_steps, and a _range call that runs
+ * to max_steps): where it issues one launch per step, a VRP / IRP call paces itself by the
+ * device's done flag from step N - 1 on -- a chunk of eight launches, then hipEventSynchronize on
+ * the chunk before the previous one, whose last step's flag came back through a pinned word --
+ * and stops at the first finished chunk instead of queueing all 2 (N - 1) launches (a launch
+ * behind the end leaves at its first instruction, but still costs its 3-4 us).  The call
+ * therefore returns once the batch has (nearly) finished.  Not while the stream is being
+ * captured into a hipGraph, not with VRP_NO_THROTTLE set (read per call), never for TSP
+ * (always N - 1 steps) and never where the steps run as one persistent launch. */
 int vrp_rollout_steps(int kind, const void *derived, const vrp_decoder_weights *dw,
                       const vrp_env *env, const float *emb, void *dec_workspace,
                       const vrp_rollout_io *io, int max_steps, int flags, void *stream);
