@@ -10,9 +10,9 @@ rows [512 r, 512 (r+1)) of ONE seed-ordered instance stream of 512 x N graphs
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-`--gpus N` with N > 1 launches the N ranks itself (a `python -m torch.distributed.run`
-child process, started before this process touches the GPU) unless it already runs under
-torchrun (RANK/WORLD_SIZE set).  Workloads:
+`--gpus N` with N > 1 launches the N ranks itself (child processes with torchrun's environment
+variables, started before this process touches the GPU; they die with the launcher) unless it
+already runs under torchrun (RANK/WORLD_SIZE set).  Workloads:
 
     tsp20_b512         BASELINE configs[1], greedy rollout (default: the metric's config)
     tsp40_b8192        north-star shape, greedy rollout
@@ -96,9 +96,25 @@ def visible_gpu_count():
     return n
 
 
+def _die_with_parent():
+    """preexec_fn of a rank: SIGKILL it when this launcher exits, however that happens (a test
+    harness that SIGKILLs the launcher on a timeout must not leave ranks on the GPU)."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL(None).prctl(1, signal.SIGKILL, 0, 0, 0)   # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
 def spawn_ranks(a, argv):
-    """--gpus N outside torchrun: start the N ranks as a CHILD process group and relay its
-    exit code.  Nothing in this process touches the GPU runtime: the GPUs are counted in sysfs."""
+    """--gpus N outside torchrun: start the N ranks as CHILD processes (env-var rendezvous:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, what torchrun would set) and
+    relay the first failure.  Nothing in this process touches the GPU runtime: the GPUs are
+    counted in sysfs.  The ranks stay in this process's group and session and carry
+    PR_SET_PDEATHSIG: SIGTERM / SIGINT are forwarded, the first rank to fail takes the others
+    down, and no rank survives the launcher."""
+    import signal
     ndev = visible_gpu_count()
     env = dict(os.environ)
     if ndev < a.gpus and env.get("VRPGYM_BENCH_ONE_GPU") != "1":
@@ -109,10 +125,51 @@ def spawn_ranks(a, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-           f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port",
-           str(port), os.path.abspath(__file__)] + argv
-    sys.exit(subprocess.run(cmd, env=env).returncode)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(a.gpus),
+               LOCAL_WORLD_SIZE=str(a.gpus))
+    env.setdefault("OMP_NUM_THREADS", "1")      # torchrun's default for its workers
+    procs = []
+    for r in range(a.gpus):
+        renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=renv,
+                                      preexec_fn=_die_with_parent))
+
+    def stop(sig=signal.SIGTERM):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    q.send_signal(sig)
+                except ProcessLookupError:
+                    pass
+
+    def on_signal(signum, _frame):
+        stop(signal.SIGTERM)
+        deadline = time.time() + 5
+        while time.time() < deadline and any(q.poll() is None for q in procs):
+            time.sleep(0.05)
+        stop(signal.SIGKILL)
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for q in list(live):
+            code = q.poll()
+            if code is None:
+                continue
+            live.remove(q)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                # one rank failed: the others would wait in a collective forever
+                stop(signal.SIGTERM)
+                deadline = time.time() + 10
+                while time.time() < deadline and any(x.poll() is None for x in procs):
+                    time.sleep(0.05)
+                stop(signal.SIGKILL)
+    sys.exit(rc)
 
 
 # ---------------------------------------------------------------------- helpers
@@ -642,16 +699,8 @@ def main():
     one_gpu = os.environ.get("VRPGYM_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0
-        if world > 2:
-            # more than two processes on ONE GPU: their persistent step grids (each sized against
-            # the whole device, serialised only within a process) would not all be resident --
-            # one launch per step instead.  Never the case with one process per GPU.
-            os.environ["VRP_NO_PERSISTENT"] = "1"
-        elif world == 2:
-            # two processes on ONE GPU: one wave per graph (2 x 1024 such workgroups are resident
-            # together; two four-wave grids sized against the whole device each are not, and
-            # nothing serialises the launches of two PROCESSES)
-            os.environ["VRP_PERSISTENT_WAVES"] = "1"
+        # (ranks that share a GPU need no special care: the library's lease word lets one of them
+        # use the persistent step grid at a time, the others run one launch per step)
     if world > 1 and not one_gpu and torch.cuda.device_count() < world:
         # (the parent counted in sysfs; a rank sees what the runtime really offers)
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")

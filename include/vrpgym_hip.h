@@ -14,8 +14,9 @@
  *     synchronises, and is safe to capture into a hipGraph;
  *   - return value 0 = ok, non-zero = error; vrp_last_error() returns a
  *     thread-local description of the last failure;
- *   - process-wide state: none that results depend on (the measured residency of the
- *     persistent kernel per device and the stream of its last launch are cached under a lock);
+ *   - process-wide state: none that results depend on (per device, under a lock: the measured
+ *     residency of the persistent kernel, the stream of its last launch, a pinned counter of
+ *     episodes that fell back, and the mapping of the cross-process lease word);
  *   - kind: 0 = TSP, 1 = VRP, 2 = IRP  (gym_vrp/envs/{tsp,vrp,irp}.py).
  */
 #ifndef VRPGYM_HIP_H
@@ -26,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* Version of this header's struct layouts and entry points: vrp_abi_version() of a matching
+ * library returns it; the shipped binding (vrpgym_hip/_lib.py: ABI_VERSION) refuses any other. */
+#define VRP_ABI_VERSION 7
 
 #define VRP_KIND_TSP 0
 #define VRP_KIND_VRP 1
@@ -201,6 +206,18 @@ int vrp_decode_step(int kind, const void *derived, const vrp_decoder_weights *w,
  * comes out more than one workgroup per CU under the occupancy query was disturbed by other work
  * and is not cached: the next call measures again. */
 int vrp_persistent_capacity(void);
+
+/* The persistent launch is an optimisation that cannot fail an episode: a wave waits at most
+ * 20 ms for another graph's mask word (VRP_PERSISTENT_SPIN_MS overrides, tests); if one gives up
+ * -- the grid was not resident, e.g. another process' kernels held the compute units -- the
+ * whole grid leaves within that time and the one-workgroup kernel launched behind it reruns the
+ * steps from the saved start state with the per-step kernel's arithmetic: same actions, same
+ * accumulators, bit for bit, no host round trip.  This call returns how many episodes of the
+ * current device took that route in this process (after one, the library stays off the persistent
+ * path for 100 ms, doubling up to 10 s while they keep coming).  Processes that share a device
+ * additionally take turns through a lease word in /dev/shm (500 ms; VRP_PERSISTENT_LEASE=0
+ * disables): a process that does not hold it runs one launch per step. */
+int vrp_persistent_failures(void);
 
 /* Name of the kernel vrp_decode_step launches for this shape and these flags (what a
  * rocprofv3 kernel trace will show). */

@@ -16,6 +16,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# Parity evidence first, process-spawning infrastructure tests last: under `pytest -x` a hang or
+# failure of a multi-process bench test must not hide the kernel-vs-oracle tests (round 4 lost
+# 247 of 249 GPU tests that way).  Within the multi-rank file the real-RCCL tests lead (they
+# only run where two GPUs exist -- the first contact of that backend should not wait for the
+# gloo-on-one-GPU variants).
+_FILE_ORDER = ["test_oracle_golden.py", "test_host_logic.py", "test_gpu_parity.py",
+               "test_gpu_backward.py", "test_gpu_persistent_guard.py",
+               "test_gpu_rccl_single_rank.py", "test_bench_multirank.py"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.basename(str(item.fspath))
+        rank = _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 2
+        rccl_first = 0 if "over_rccl" in item.name else 1
+        return (rank, rccl_first)
+    items.sort(key=key)   # stable: the order inside a file is otherwise kept
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -4,20 +4,23 @@ paired t-test, average_buffers).  On a one-GPU box the ranks share cuda:0 and th
 collectives run over gloo (VRPGYM_BENCH_ONE_GPU=1, flagged in the JSON line)."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _proc  # noqa: E402
 
 
-def _bench(args, extra_env=None, timeout=900):
-    env = dict(os.environ)
+def _bench(args, extra_env=None, timeout=_proc.SUBPROCESS_TIMEOUT, env=None):
+    """bench.py in a process group of its own that cannot outlive the test (tests/_proc.py; the
+    launcher inside bench.py gives its ranks the same property)."""
+    if env is None:
+        env = dict(os.environ)
     env.update(extra_env or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, timeout=timeout)
     if p.returncode != 0:
         # the tail of a torchrun failure is its summary table; keep the whole stream where a
         # gpurun call brings it back, and put the lines that name the cause in front
@@ -47,8 +50,7 @@ def test_bench_refuses_more_ranks_than_gpus():
         pytest.skip("two GPUs visible")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}
     env.pop("VRPGYM_BENCH_ONE_GPU", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, timeout=120)
     assert p.returncode != 0
     assert "--gpus 2" in p.stderr and "{" not in p.stdout
 
@@ -96,7 +98,7 @@ def test_bench_eight_ranks_one_gpu(workload):
     (the rendezvous, sharding and collective CALL pattern are the real ones; RCCL is not)."""
     args = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
             "--no-north-star", "--no-extras", "--workload", workload]
-    p = _bench(args, {"VRPGYM_BENCH_ONE_GPU": "1"}, timeout=1500)
+    p = _bench(args, {"VRPGYM_BENCH_ONE_GPU": "1"}, timeout=300)
     assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 8 and out["one_gpu_test_mode"] is True
@@ -147,8 +149,7 @@ def test_bench_two_ranks_over_rccl(workload):
     args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
             "--no-north-star", "--no-extras", "--workload", workload]
     env = {k: v for k, v in os.environ.items() if k != "VRPGYM_BENCH_ONE_GPU"}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = _bench(args, env=env, timeout=120)
     assert p.returncode == 0, p.stderr[:4000]
     out = _json_line(p.stdout)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"].startswith("nccl")

@@ -9,12 +9,13 @@ AVG on RCCL, device_id binding) has executed on hardware before the first multi-
 semantics are covered over gloo (tests/test_host_logic.py) and, where two GPUs exist, by
 tests/test_bench_multirank.py::test_bench_two_ranks_over_rccl."""
 import os
-import subprocess
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _proc  # noqa: E402
 
 WORKER = r"""
 import os, sys
@@ -81,7 +82,6 @@ def test_rccl_backend_single_rank(tmp_path):
     script.write_text(WORKER)
     port = str(31500 + os.getpid() % 2000)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, str(script), ROOT, port], env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    p = _proc.run([sys.executable, str(script), ROOT, port], env=env, merge_stderr=True, timeout=240)
     assert p.returncode == 0, p.stdout[-4000:]
     assert "rccl single rank ok" in p.stdout

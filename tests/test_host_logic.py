@@ -175,7 +175,10 @@ def test_c_abi_exports_every_declared_symbol():
     assert len(names) >= 15
     for n in sorted(names):
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
-    assert lib.vrp_abi_version() == 6
+    # one version in three places: the header's macro, the library, the binding (which refuses
+    # to load a library of another ABI)
+    want = int(re.search(r"#define\s+VRP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.vrp_abi_version() == want == vrpgym_hip.ABI_VERSION
     assert len(lib.vrp_source_hash()) == 16
     assert lib.vrp_decoder_derived_bytes() > 0
     assert lib.vrp_encoder_workspace_bytes(512, 20, 512) > 512 * 20 * 128 * 4
@@ -187,6 +190,31 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 12 * 8   # + logit_clip (float, padded)
     assert ctypes.sizeof(vrpgym_hip.DecoderGrads) == 11 * 8
     assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 24 + 4 * 8 + 8 * 18 * 8   # + heads, reserved_
+
+
+def test_graft_entry_build():
+    """The driver's build entry point on a checkout whose library is already built: make is a
+    no-op, the package imports, the ABI matches (round 4 shipped a build() that asserted a stale
+    version and nothing ran it)."""
+    p = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); print('built ok')"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=1200)
+    assert p.returncode == 0 and "built ok" in p.stdout, p.stdout[-3000:]
+
+
+def test_stale_library_is_refused(tmp_path):
+    """A library of another ABI (an old build left in the tree) must not be called into."""
+    src = tmp_path / "stale.c"
+    src.write_text("int vrp_abi_version(void) { return 5; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    code = ("import sys; sys.path.insert(0, %r); import vrpgym_hip\n"
+            "try:\n    vrpgym_hip.lib()\nexcept RuntimeError as e:\n    print('refused:', e)\n"
+            % os.path.join(ROOT, "vrp-gym_amd"))
+    env = dict(os.environ, VRPGYM_HIP_LIB=str(so))
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "refused:" in p.stdout and "ABI 5" in p.stdout, p.stdout[-2000:]
 
 
 def test_product_fails_loudly_without_gpu():
@@ -285,7 +313,7 @@ assert vrpgym_hip.library_path().endswith("_asan.so")
 header = open(os.path.join(%(root)r, "include", "vrpgym_hip.h")).read()
 for n in sorted(set(re.findall(r"\b(vrp_[a-z_0-9]+)\s*\(", header))):
     assert hasattr(lib, n), n
-assert lib.vrp_abi_version() == 6 and lib.vrp_decoder_derived_bytes() > 0
+assert lib.vrp_abi_version() == vrpgym_hip.ABI_VERSION and lib.vrp_decoder_derived_bytes() > 0
 for B, N in ((1, 2), (512, 20), (8192, 40), (2048, 100), (5, 128)):
     assert lib.vrp_encoder_workspace_bytes(B, N, 512) > 0
     for kind in (0, 1, 2):

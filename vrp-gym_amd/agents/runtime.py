@@ -324,12 +324,7 @@ class RolloutResult:
     @property
     def T(self):
         if self._T is None:
-            nd = self.notdone[: self.max_steps + 1].cpu()
-            if int(nd[self.max_steps]) == -1:
-                raise RuntimeError("persistent decode kernel: a wave timed out waiting for another "
-                                   "graph's mask (grid not fully resident?); rerun with "
-                                   "VRP_NO_PERSISTENT=1")
-            nd = nd[: self.max_steps]
+            nd = self.notdone[: self.max_steps].cpu()
             zero = (nd == 0).nonzero()
             self._T = int(zero[0].item()) + 1 if len(zero) else self.max_steps
         return self._T

@@ -12,7 +12,7 @@ void vrp_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *vrp_last_error(void) { return g_err; }
-extern "C" int vrp_abi_version(void) { return 6; }
+extern "C" int vrp_abi_version(void) { return VRP_ABI_VERSION; }
 // sha256 (first 16 hex digits) over the kernel sources this library was built from, set by the
 // Makefile: measurements kept under profiles/ (PMC traffic) carry it, and bench.py reports them
 // only for the build they were taken on

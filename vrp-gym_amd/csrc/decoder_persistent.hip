@@ -21,14 +21,32 @@
 //     aside: vrp_persistent_finalize adds it iff the batch ran on (T - 1 > ta_b).  Later steps
 //     of a finished graph are self-loops on the depot with reward 0 and log-prob 0: nothing to
 //     compute; it publishes its (constant) mask for all remaining steps at once.
-// Requires every workgroup of the grid to be resident: vrp_persistent_eligible admits only
-// B <= vrp_persistent_capacity() (occupancy of THIS kernel x the compute units a census kernel
-// finds usable, i.e. a CU mask or a partition shrinks it), and persistent launches of one
-// device are serialised across streams.  Spins are bounded all the same: a wave that gives up
-// sets `err`, publishes valid words for its remaining steps (so nobody else waits for it) and
-// leaves; persistent_finalize_kernel then turns the accumulators into NaN, so every consumer
-// sees the failure without a host synchronisation.
-#include "decoder_step.h"
+// FAST only when every workgroup of the grid is resident -- CORRECT whether or not it is:
+//   * vrp_persistent_eligible admits only B <= vrp_persistent_capacity() (occupancy of THIS
+//     kernel x the compute units a census kernel finds usable), persistent launches of one
+//     process are serialised across streams, and processes that share a device take turns
+//     through a lease word in shared memory (device_lease_claim below): whoever does not hold
+//     it runs one launch per step;
+//   * none of that is relied upon.  A wait lasts at most `spin_ticks` of the wall clock
+//     (20 ms); the first wave that gives up raises `err`, every other wave sees it at its next
+//     hand-off (lane 8 reads it together with the eight mask words; a spinning lane polls it)
+//     and leaves: a grid that cannot make progress drains in a few tens of milliseconds;
+//   * every graph saves the state it was launched with (visited row, location, load,
+//     accumulators) before it overwrites anything, and persistent_finalize_kernel -- one
+//     workgroup, launched behind the grid in any case -- on `err` puts that state back and
+//     walks the remaining steps itself with the per-step kernel's body (decoder_rt_body.h),
+//     one workgroup barrier per step instead of hand-off words.  The step kernels are
+//     bit-identical (tests/test_gpu_parity.py), the in-kernel noise is counter-based: the
+//     episode's results are those of an undisturbed run.  No host round trip, no NaN, no
+//     exception; the host learns about it from a pinned counter (vrp_persistent_failures) and
+//     backs off from the persistent path for a while.
+#include <atomic>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include "decoder_rt_body.h"
 
 struct PersistParams {
   StepParams s;               // s.t = first step of the launch (>= 1)
@@ -37,8 +55,15 @@ struct PersistParams {
   float *ret;                 // (B) reward of the way back after ta (0 if none)
   int32_t *wb_cur;            // (B) node the graph stood on before its way back (-1: none)
   double *wb_load;            // (B) its load there (IRP)
-  int32_t *err;
+  int32_t *err;               // raised by the first wave that gives up waiting
   int32_t *census;            // residency census mode (vrp_persistent_capacity): {arrived, saw all}
+  long long spin_ticks;       // longest wait for a hand-off word, in wall_clock64() ticks
+  int32_t *fail_host;         // pinned host counter: episodes of this device that fell back
+  // the state this launch started from (saved by every graph before it overwrites anything)
+  uint8_t *sv_visited;        // (B,N)
+  int32_t *sv_cur, *sv_last;  // (B)
+  double *sv_load;            // (B)
+  float *sv_accl, *sv_accp;   // (B)
 };
 
 // The workgroup is ONE wave: its LDS operations execute in program order, so a barrier between
@@ -51,7 +76,36 @@ struct PersistParams {
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
 #define PERSIST_VALID (1ull << 63)
-#define PERSIST_SPIN_LIMIT (1 << 20)  // ~1 s of polling; a legitimate wait is microseconds
+
+// One hand-off wait.  Lanes 0..7 poll the mask word of "their" graph until bit 63 shows; lane 8
+// reads the error flag in the same round trip (and reports "not valid" when it is raised), so a
+// wave whose words are all there still leaves a failed episode at its next step.  A legitimate
+// wait is microseconds; a lane gives up after `limit` wall-clock ticks (20 ms) or as soon as it
+// sees the flag (polled every 16 spins).  Returns the word (bit 63 clear = give up).
+__device__ __forceinline__ unsigned long long persist_wait(const unsigned long long *hist_row, int B,
+                                                           int b, int lane, const int32_t *err,
+                                                           long long limit) {
+  unsigned long long w = PERSIST_VALID;
+  if (lane < 8) {
+    const unsigned long long *src = hist_row + (b * 8 + lane) % B;
+    w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(w & PERSIST_VALID)) {
+      const long long start = wall_clock64();
+      int spins = 0;
+      do {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 15) == 0 &&
+            (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+             wall_clock64() - start > limit))
+          break;
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while (!(w & PERSIST_VALID));
+    }
+  } else if (lane == 8) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) w = 0ull;
+  }
+  return w;
+}
 
 __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams pp) {
   const StepParams &p = pp.s;
@@ -114,6 +168,15 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
 #pragma unroll
     for (int h = 0; h < 8; ++h) sc[h] = srow[h * N + ln];
   }
+  // what the fallback (persistent_finalize_kernel) restarts from, should this launch fail
+  if (inN) pp.sv_visited[(size_t)b * N + lane] = (uint8_t)vis;
+  if (lane == 0) {
+    pp.sv_cur[b] = cur;
+    pp.sv_last[b] = last;
+    pp.sv_load[b] = load0;
+    pp.sv_accl[b] = accl;
+    pp.sv_accp[b] = accp;
+  }
   const int cnt = (n4 - part + 7) >> 3;          // float4 of a row owned by this lane
   const int nchunk = (((n4 + 7) >> 3) + RT_U - 1) / RT_U;
   const float4 *rtb = reinterpret_cast<const float4 *>(p.RT) + (size_t)b * N * n4 + part;
@@ -150,25 +213,13 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
     }
     // ---- the eight other graphs' masks of this step (first step: the byte rows in memory)
     if (t > t0) {
-      unsigned long long w = PERSIST_VALID;
-      if (lane < 8) {
-        const unsigned long long *src = pp.hist + (size_t)t * B + (b * 8 + lane) % B;
-        int spins = 0;
-        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (!(w & PERSIST_VALID)) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > PERSIST_SPIN_LIMIT) break;
-          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      const unsigned long long w = persist_wait(pp.hist + (size_t)t * B, B, b, lane, pp.err,
+                                                pp.spin_ticks);
       if (__any(!(w & PERSIST_VALID))) {
-        // gave up (the grid is not fully resident, or a graph it depends on gave up): flag the
-        // episode as failed, let everybody who waits for THIS graph go on, and leave the loop
+        // gave up (the grid is not fully resident), or somebody else did: the episode is void --
+        // raise the flag (everybody who waits for THIS graph sees it within a few polls) and
+        // leave; persistent_finalize_kernel reruns the steps from the saved state
         if (lane == 0) __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long word = (__ballot(inN && own_mask) & ~PERSIST_VALID) | PERSIST_VALID;
-        for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
-          __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
       const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
@@ -433,6 +484,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
   float ret = 0.f;
   double wb_load = 1.0;
   float loadf = (float)load0;   // the softmax's load factor (IRP); later steps: from wave 0
+  // what the fallback (persistent_finalize_kernel) restarts from, should this launch fail
+  if (wave == 0) {
+    if (inN) pp.sv_visited[(size_t)b * N + lane] = (uint8_t)vis;
+    if (lane == 0) {
+      pp.sv_cur[b] = cur;
+      pp.sv_last[b] = last;
+      pp.sv_load[b] = load0;
+      pp.sv_accl[b] = accl;
+      pp.sv_accp[b] = accp;
+    }
+  }
   // the selectable list of the first step
   {
     const bool s_i = inN && !own_mask;
@@ -472,28 +534,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
     // ---- the eight other graphs' masks of this step (first step: the byte rows in memory)
     if (t > t0) {
       if (wave == 0) {
-        unsigned long long w = PERSIST_VALID;
-        if (lane < 8) {
-          const unsigned long long *src = pp.hist + (size_t)t * B + (b * 8 + lane) % B;
-          int spins = 0;
-          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while (!(w & PERSIST_VALID)) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > PERSIST_SPIN_LIMIT) break;
-            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          wrd_s[lane] = w;
-        }
+        const unsigned long long w = persist_wait(pp.hist + (size_t)t * B, B, b, lane, pp.err,
+                                                  pp.spin_ticks);
+        if (lane < 8) wrd_s[lane] = w;
         if (__any(!(w & PERSIST_VALID))) {
-          // gave up: flag the episode, let everybody who waits for THIS graph go on, leave
+          // gave up, or somebody else did: raise the flag and leave (see the one-wave kernel)
           if (lane == 0) {
             __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ctl_s[1] = 1;
           }
-          const unsigned long long word = (__ballot(inN && own_mask) & ~PERSIST_VALID) | PERSIST_VALID;
-          for (int tt = t + 1 + lane; tt <= p.max_steps; tt += 64)
-            __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       P4_BARRIER();
@@ -682,43 +731,65 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
 // T - 1 = max_b ta_b; the way back of a graph counts iff the batch ran on after its ta
 // (otherwise the episode ended with the graph on its last customer: location and load are
 // put back); notdone[t] as the per-step launches would have left it.  One workgroup.
-__global__ __launch_bounds__(256) void persistent_finalize_kernel(int B, int t0, int max_steps,
-                                                                  const int32_t *__restrict__ ta,
-                                                                  const float *__restrict__ ret,
-                                                                  const int32_t *__restrict__ wb_cur,
-                                                                  const double *__restrict__ wb_load,
-                                                                  float *__restrict__ acc_loss,
-                                                                  float *__restrict__ acc_logp,
-                                                                  int32_t *__restrict__ env_cur,
-                                                                  double *__restrict__ env_load,
-                                                                  int32_t *__restrict__ notdone,
-                                                                  const int32_t *__restrict__ err) {
+//
+// If the grid raised `err` (a wave waited 20 ms for a mask word: the grid was not resident, e.g.
+// another process' grid held the compute units), this workgroup IS the per-step path: it puts
+// the saved state back and runs steps t0 .. of all B graphs itself, four graphs at a time, with
+// the body of decode_step_rt_kernel<1, 4> (same arithmetic, same operation order: results are
+// bit-identical to an undisturbed launch) and a workgroup barrier where that path has a kernel
+// boundary.  Slow (one CU) and rare; never wrong, never waiting for anybody.
+__device__ int32_t g_fail_sink;   // fail_host stand-in when no pinned word could be allocated
+__global__ __launch_bounds__(256) void persistent_finalize_kernel(PersistParams pp) {
+  const StepParams &p = pp.s;
+  const int B = p.B, N = p.N, t0 = p.t, max_steps = p.max_steps;
+  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float a_s[4][8 * 64];
+  __shared__ __attribute__((aligned(16))) float u_s[4][64];
+  __shared__ int sel_s[4][64];
   __shared__ int smax[4];
-  // a wave gave up waiting for another graph's mask (the grid was not fully resident): the
-  // host sees notdone[max_steps] == -1 when it reads the step count, and every consumer of the
-  // accumulators sees NaN (greedy / baseline rollouts never read the step count)
-  if (*err) {
-    if (threadIdx.x == 0) notdone[max_steps] = -1;
-    const float nan = __builtin_nanf("");
-    for (int b = threadIdx.x; b < B; b += 256) { acc_loss[b] = nan; acc_logp[b] = nan; }
+  if (__hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    // (every workgroup of the grid has run by now -- kernels of a stream do not overlap -- and
+    // saved its graph's state before anything else)
+    for (int i = tid; i < B * N; i += 256) p.env.visited[i] = pp.sv_visited[i];
+    for (int b = tid; b < B; b += 256) {
+      p.env.cur[b] = pp.sv_cur[b];
+      p.last[b] = pp.sv_last[b];
+      if (p.kind == VRP_KIND_IRP) p.env.load[b] = pp.sv_load[b];
+      p.io.acc_loss[b] = pp.sv_accl[b];
+      p.io.acc_logp[b] = pp.sv_accp[b];
+    }
+    __threadfence();
+    __syncthreads();
+    for (int t = t0; t < max_steps; ++t) {
+      // batch-wide done (tsp.py:95): every thread reads the flag the step before left in L2
+      if (__hip_atomic_load(&p.io.notdone[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        break;
+      for (int g0 = 0; g0 < B; g0 += 4)
+        step_rt_body<1, 4, false>(p, t, g0 + (tid >> 6), a_s, u_s, sel_s);
+      __threadfence();
+      __syncthreads();
+    }
+    if (tid == 0)
+      __hip_atomic_fetch_add(pp.fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
-  if (notdone[t0 - 1] == 0) return;
+  if (p.io.notdone[t0 - 1] == 0) return;
+  const int32_t *__restrict__ ta = pp.ta;
   int m = 0;
-  for (int b = threadIdx.x; b < B; b += 256) m = max(m, ta[b]);
+  for (int b = tid; b < B; b += 256) m = max(m, ta[b]);
   m = (int)wave_max((float)m);  // step indices are small integers: exact in fp32
-  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  if ((tid & 63) == 0) smax[tid >> 6] = m;
   __syncthreads();
   const int last_step = max(max(smax[0], smax[1]), max(smax[2], smax[3]));  // T - 1
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = tid; b < B; b += 256) {
     if (last_step > ta[b]) {
-      acc_loss[b] += ret[b];
-    } else if (wb_cur[b] >= 0) {
-      env_cur[b] = wb_cur[b];
-      if (env_load) env_load[b] = wb_load[b];
+      p.io.acc_loss[b] += pp.ret[b];
+    } else if (pp.wb_cur[b] >= 0) {
+      p.env.cur[b] = pp.wb_cur[b];
+      if (p.kind == VRP_KIND_IRP) p.env.load[b] = pp.wb_load[b];
     }
   }
-  for (int t = t0 + threadIdx.x; t < max_steps; t += 256) notdone[t] = t < last_step ? 1 : 0;
+  for (int t = t0 + tid; t < max_steps; t += 256) p.io.notdone[t] = t < last_step ? 1 : 0;
 }
 
 // ---- residency: how many single-wave workgroups of decode_persistent_kernel run at once ----
@@ -743,8 +814,123 @@ struct PersistDevice {
   int retries4 = 0, retries2 = 0;
   hipEvent_t last = nullptr;     // end of the device's most recent persistent launch
   hipStream_t last_stream = nullptr;  // identity of that launch's stream (compared, never used)
+  // ---- failures (episodes that fell back inside persistent_finalize_kernel) and the back-off
+  int32_t *fail_host = nullptr;  // pinned; incremented by the device
+  bool fail_tried = false;
+  int fail_seen = 0;             // value of *fail_host the host last acted upon
+  long long off_until_ms = 0;    // no persistent launch before this time (CLOCK_MONOTONIC)
+  long long backoff_ms = 0;      // current back-off (doubles per failure, forgotten after a quiet minute)
+  long long last_fail_ms = 0;
+  long long spin_ticks = 0;      // 20 ms in wall_clock64() ticks
+  // ---- the lease word shared by the processes that use this device
+  std::atomic<unsigned long long> *lease = nullptr;
+  bool lease_tried = false;
 };
 static PersistDevice g_pdev[VRP_MAX_DEVICES];
+
+static long long monotonic_ms() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+
+// ---- processes that share a device take turns -------------------------------------------------
+// Each persistent grid is sized against the WHOLE device; two of them from two processes (two
+// ranks mapped to one GPU, a notebook next to a training job) are not resident together, and the
+// in-process serialiser below cannot see the other process.  The abort + fallback above keeps
+// that correct; this keeps it fast: one 8-byte word per device in shared memory,
+//   /dev/shm/vrpgym_hip.<uid>.<pci bus id>  =  owner pid << 40 | time of its last launch (ms),
+// claimed with a compare-and-swap before every persistent launch.  A process may launch if the
+// word is free, its own, or older than the lease (500 ms: the owner went idle or died -- nothing
+// to clean up after a SIGKILL); otherwise it takes the one-launch-per-step path for this
+// episode.  A lease that expires while the owner's launch still sits in a long queue merely costs
+// that episode a fallback.  VRP_PERSISTENT_LEASE=0 turns the coordination off (tests of the
+// fallback); a file that cannot be created or mapped does the same.
+#define LEASE_MS 500
+#define LEASE_TIME_MASK ((1ull << 40) - 1ull)
+static void device_lease_open(PersistDevice &pd, int dev) {
+  pd.lease_tried = true;
+  const char *off = getenv("VRP_PERSISTENT_LEASE");
+  if (off && off[0] == '0') return;
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), dev) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(bus, sizeof(bus), "dev%d", dev);
+  }
+  for (char *c = bus; *c; ++c)
+    if (*c == '/' || *c == ' ') *c = '_';
+  char path[160];
+  snprintf(path, sizeof(path), "/dev/shm/vrpgym_hip.%u.%s", (unsigned)getuid(), bus);
+  const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0600);
+  if (fd < 0) return;
+  void *m = MAP_FAILED;
+  if (ftruncate(fd, 8) == 0) m = mmap(nullptr, 8, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return;
+  pd.lease = reinterpret_cast<std::atomic<unsigned long long> *>(m);
+}
+// true: this process may launch a persistent grid on the device now (and has renewed the lease)
+static bool device_lease_claim(PersistDevice &pd, int dev) {
+  if (!pd.lease_tried) device_lease_open(pd, dev);
+  if (!pd.lease) return true;
+  const unsigned long long me = (unsigned long long)(unsigned)getpid() & 0xFFFFFFull;
+  const unsigned long long now = (unsigned long long)monotonic_ms() & LEASE_TIME_MASK;
+  unsigned long long w = pd.lease->load(std::memory_order_relaxed);
+  for (int tries = 0; tries < 4; ++tries) {
+    const unsigned long long owner = w >> 40, stamp = w & LEASE_TIME_MASK;
+    const bool mine = owner == me, free_ = owner == 0 || stamp > now || now - stamp > LEASE_MS;
+    if (!mine && !free_) return false;
+    if (pd.lease->compare_exchange_weak(w, me << 40 | now, std::memory_order_acq_rel)) return true;
+  }
+  return false;
+}
+// a clean exit hands the device over at once
+__attribute__((destructor)) static void device_lease_release_all() {
+  const unsigned long long me = (unsigned long long)(unsigned)getpid() & 0xFFFFFFull;
+  for (int d = 0; d < VRP_MAX_DEVICES; ++d) {
+    std::atomic<unsigned long long> *l = g_pdev[d].lease;
+    if (!l) continue;
+    unsigned long long w = l->load(std::memory_order_relaxed);
+    if ((w >> 40) == me) (void)l->compare_exchange_strong(w, 0ull);
+  }
+}
+
+// the pinned failure counter and the spin limit of a device (first use: outside any capture)
+static void persist_device_init(PersistDevice &pd, int dev) {
+  if (pd.fail_tried) return;
+  pd.fail_tried = true;
+  if (hipHostMalloc((void **)&pd.fail_host, 64, hipHostMallocDefault) == hipSuccess) {
+    *pd.fail_host = 0;
+  } else {
+    (void)hipGetLastError();
+    pd.fail_host = nullptr;
+  }
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) {
+    (void)hipGetLastError();
+    khz = 100000;   // gfx9: s_memrealtime counts at 100 MHz
+  }
+  const char *ms = getenv("VRP_PERSISTENT_SPIN_MS");   // tests
+  const int limit_ms = ms && atoi(ms) > 0 ? atoi(ms) : 20;
+  pd.spin_ticks = (long long)khz * limit_ms;
+}
+
+// Failures seen since the last look -> stay off the persistent path for a while: 100 ms after the
+// first, doubling up to 10 s while they keep coming, forgotten after a minute without one.
+// (Locked by the caller.)
+static bool persist_backed_off(PersistDevice &pd) {
+  if (!pd.fail_host) return false;
+  const long long now = monotonic_ms();
+  const int seen = *(volatile int32_t *)pd.fail_host;
+  if (seen != pd.fail_seen) {
+    pd.fail_seen = seen;
+    if (now - pd.last_fail_ms > 60000) pd.backoff_ms = 0;
+    pd.backoff_ms = pd.backoff_ms ? (pd.backoff_ms * 2 > 10000 ? 10000 : pd.backoff_ms * 2) : 100;
+    pd.last_fail_ms = now;
+    pd.off_until_ms = now + pd.backoff_ms;
+  }
+  return now < pd.off_until_ms;
+}
 // (process-wide state besides the thread-local error string: the measured capacity per device and
 // the stream of its last persistent launch; launches from several host threads take this lock)
 #include <mutex>
@@ -761,9 +947,15 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   cus = prop.multiProcessorCount;
+  // (asked for the legacy stream too -- capturing_guard == nullptr: it reports a capture that is
+  // active on another stream of this thread as an error, which counts as "capturing" here)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
+  if (hipStreamIsCapturing(capturing_guard, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusActive;
+  }
   if (cs == hipStreamCaptureStatusNone) {
+    persist_device_init(pd, dev);
     // the census synchronises: never inside a stream capture (the figure of the device
     // properties serves until an eager call gets here).  It must not compete for CU slots with
     // work this process has in flight (a rollout's encoder enqueued just before the first
@@ -835,10 +1027,10 @@ static int persistent_capacity_of(int dev, hipStream_t capturing_guard) {
 }
 
 // compute units a launch can use on the current device (the census' first half); 0 if unknown
-int vrp_usable_cus() {
+int vrp_usable_cus(hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  (void)persistent_capacity_of(dev, nullptr);
+  (void)persistent_capacity_of(dev, st);
   if (dev < 0 || dev >= VRP_MAX_DEVICES) return 0;
   std::lock_guard<std::mutex> guard(g_pdev_lock);
   return g_pdev[dev].cus;
@@ -856,7 +1048,10 @@ static int persistent_wide_capacity_of(int dev, hipStream_t capturing_guard) {
   int &retries = NW == 4 ? pd.retries4 : pd.retries2;
   if (cap >= 0) return cap;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (capturing_guard) (void)hipStreamIsCapturing(capturing_guard, &cs);
+  if (hipStreamIsCapturing(capturing_guard, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusActive;
+  }
   int per_cu = 0;
   if (pd.cus <= 0 || cs != hipStreamCaptureStatusNone ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_persistent4_kernel<NW>, 64 * NW,
@@ -901,21 +1096,44 @@ static int persistent_wide_capacity_of(int dev, hipStream_t capturing_guard) {
 int vrp_persistent_width(int kind, int B, int N, int max_steps, int flags, const vrp_rollout_io *io,
                          hipStream_t st) {
   if (!vrp_persistent_eligible(kind, B, N, max_steps, flags, io, st)) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VRP_MAX_DEVICES) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  {
+    // recent episodes fell back (something else holds the compute units), or another process
+    // holds the device's lease: one launch per step for this episode
+    std::lock_guard<std::mutex> guard(g_pdev_lock);
+    PersistDevice &pd = g_pdev[dev];
+    if (persist_backed_off(pd)) return 0;
+    if (!device_lease_claim(pd, dev)) return 0;
+  }
   const char *forced = getenv("VRP_PERSISTENT_WAVES");   // tests, A/B: "1", "2" or "4" (read per call)
   if (forced && forced[0] == '1') return 1;
   static const bool force = getenv("VRP_PERSISTENT_FORCE") != nullptr;
-  int dev = 0;
-  if (!force && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 1; }
   // One workgroup per CU of slack below the measured capacity: at 128 registers four waves fill a
   // SIMD's register file exactly, and a grid sized to the last slot (B = 2048 two waves wide:
   // 8 workgroups on every CU) stopped being resident as soon as another stream's kernels had
   // fragmented a register file -- tests/test_gpu_persistent_guard.py, two streams: timeouts.
-  const int cus = force ? 0 : vrp_usable_cus();
+  const int cus = force ? 0 : vrp_usable_cus(st);
   if (!(forced && forced[0] == '2'))
     if (force ? B <= 768 : B <= persistent_wide_capacity_of<4>(dev, st) - cus) return 4;
   if (forced && forced[0] == '4') return 1;   // asked for four, not resident: the one-wave kernel
   if (force ? B <= 1792 : B <= persistent_wide_capacity_of<2>(dev, st) - cus) return 2;
   return 1;
+}
+
+// episodes of the current device that a persistent launch of this process could not finish and
+// persistent_finalize_kernel reran (results unaffected): diagnostics and tests
+extern "C" int vrp_persistent_failures(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VRP_MAX_DEVICES) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  std::lock_guard<std::mutex> guard(g_pdev_lock);
+  return g_pdev[dev].fail_host ? *(volatile int32_t *)g_pdev[dev].fail_host : 0;
 }
 
 extern "C" int vrp_persistent_capacity(void) {
@@ -979,18 +1197,7 @@ void vrp_persistent_serialize_end(hipStream_t st, void *token) {
   if (pd->last) (void)hipEventRecord(pd->last, st);
 }
 
-int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st) {
-  DecWs ws = carve_decws(workspace, sp.B, sp.N);
-  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, sp.B, sp.t, sp.max_steps,
-                     ws.ta, ws.ret, ws.wb_cur, ws.wb_load, sp.io.acc_loss, sp.io.acc_logp, sp.env.cur,
-                     sp.kind == VRP_KIND_IRP ? sp.env.load : nullptr, sp.io.notdone, ws.err);
-  VRP_CHECK_LAUNCH("persistent_finalize");
-  return 0;
-}
-
-// steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
-int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
-                                int waves) {
+static PersistParams make_persist_params(const StepParams &sp, void *workspace) {
   DecWs ws = carve_decws(workspace, sp.B, sp.N);
   PersistParams pp;
   pp.s = sp;
@@ -1001,14 +1208,43 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   pp.wb_load = ws.wb_load;
   pp.err = ws.err;
   pp.census = nullptr;
-  // (the hand-off words were cleared by vrp_decode_prologue: one persistent launch per episode)
+  pp.sv_visited = ws.sv_visited;
+  pp.sv_cur = ws.sv_cur;
+  pp.sv_last = ws.sv_last;
+  pp.sv_load = ws.sv_load;
+  pp.sv_accl = ws.sv_accl;
+  pp.sv_accp = ws.sv_accp;
+  pp.spin_ticks = 2000000;   // 20 ms at 100 MHz
+  pp.fail_host = nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < VRP_MAX_DEVICES) {
+    std::lock_guard<std::mutex> guard(g_pdev_lock);
+    if (g_pdev[dev].spin_ticks > 0) pp.spin_ticks = g_pdev[dev].spin_ticks;
+    pp.fail_host = g_pdev[dev].fail_host;
+  } else {
+    (void)hipGetLastError();
+  }
+  if (!pp.fail_host && hipGetSymbolAddress((void **)&pp.fail_host, HIP_SYMBOL(g_fail_sink)) != hipSuccess) {
+    (void)hipGetLastError();
+    pp.fail_host = ws.err + 1;   // (the flag's 256-byte slot)
+  }
+  return pp;
+}
+
+// steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
+int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
+                                int waves) {
+  const PersistParams pp = make_persist_params(sp, workspace);
+  // (the hand-off words and the error flag were cleared by vrp_decode_prologue: one persistent
+  // launch per episode)
   void *token = nullptr;
   vrp_persistent_serialize_begin(st, &token);
   if (waves == 4) hipLaunchKernelGGL(decode_persistent4_kernel<4>, dim3(sp.B), dim3(256), 0, st, pp);
   else if (waves == 2) hipLaunchKernelGGL(decode_persistent4_kernel<2>, dim3(sp.B), dim3(128), 0, st, pp);
   else hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
-  if (int r = vrp_launch_persistent_finalize(sp, workspace, st)) return r;
+  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, pp);
+  VRP_CHECK_LAUNCH("persistent_finalize");
   vrp_persistent_serialize_end(st, token);
   return 0;
 }

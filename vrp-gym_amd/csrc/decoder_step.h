@@ -78,11 +78,10 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
                                 int waves = 1);
 int vrp_persistent_width(int kind, int B, int N, int max_steps, int flags, const vrp_rollout_io *io,
                          hipStream_t st);
-int vrp_launch_persistent_finalize(const StepParams &sp, void *workspace, hipStream_t st);
 void vrp_persistent_serialize_begin(hipStream_t st, void **token);
 void vrp_persistent_serialize_end(hipStream_t st, void *token);
 bool vrp_tile_mfma_supported(int N);
 int vrp_launch_tile_mfma_step(const StepParams &p, hipStream_t st);
 bool vrp_tile2_supported(int N);
-int vrp_usable_cus();   // compute units the residency census found usable (decoder_persistent.hip)
+int vrp_usable_cus(hipStream_t st);   // compute units the residency census found usable (decoder_persistent.hip)
 int vrp_launch_tile2_step(const StepParams &p, hipStream_t st);

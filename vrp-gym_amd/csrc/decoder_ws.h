@@ -83,7 +83,12 @@ struct DecWs {
   float *ret;                    // (B) reward of the forced way back after ta
   int32_t *wb_cur;               // (B) location before the way back
   double *wb_load;               // (B) load before the way back
-  int32_t *err;                  // spin-limit flag
+  int32_t *err;                  // raised by the first wave that gives up waiting
+  // the state a persistent launch started from (its in-kernel fallback restarts there)
+  uint8_t *sv_visited;           // (B,N)
+  int32_t *sv_cur, *sv_last;     // (B)
+  double *sv_load;               // (B)
+  float *sv_accl, *sv_accp;      // (B)
 };
 
 #define VRP_RT_MAX_N 128    // above this the tile kernel (one raw-tile read per step) is used
@@ -91,9 +96,14 @@ struct DecWs {
 // N % 4 == 0 (16-byte table stores), <= 64 rows otherwise
 #define VRP_FUSED_MAX_N 80
 // rows of the hand-off words (one row = one 8-byte word per graph): a step's mask is one word
-// up to 63 nodes (decoder_persistent.hip), two above (the tile-resident kernel of decoder_tile2.hip),
-// for up to 2N steps (max_steps + 1 <= 2N)
-__host__ __device__ static inline int hist_rows(int N) { return N > 63 ? 4 * N : 2 * N; }
+// up to 63 nodes (decoder_persistent.hip), for up to 2N steps (max_steps + 1 <= 2N); larger
+// graphs never take the persistent path and have none
+__host__ __device__ static inline int hist_rows(int N) { return N > 63 ? 0 : 2 * N; }
+// bytes of the saved-state rows (persistent path only, N <= 63)
+static inline size_t persist_save_bytes(int B, int N) {
+  return N > 63 ? 0 : vrp_align_up((size_t)B * N) + 4 * vrp_align_up((size_t)B * 4) +
+                          vrp_align_up((size_t)B * 8);
+}
 // shapes on which the default dispatch sends steps to the raw-tile kernel (decoder.hip,
 // hybrid_shape; IRP excepted there): they get the row-paired copy of the embeddings
 // Round 4: the second-generation tile kernel (decoder_tile2.hip, N <= 100) reads `emb` itself in
@@ -156,6 +166,13 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.wb_cur = (int32_t *)p; p += vrp_align_up((size_t)B * 4);
   w.wb_load = (double *)p; p += vrp_align_up((size_t)B * 8);
   w.err = (int32_t *)p;   p += vrp_align_up(4);
+  const bool sv = N <= 63;
+  w.sv_visited = (uint8_t *)p; p += sv ? vrp_align_up((size_t)B * N) : 0;
+  w.sv_cur = (int32_t *)p;     p += sv ? vrp_align_up((size_t)B * 4) : 0;
+  w.sv_last = (int32_t *)p;    p += sv ? vrp_align_up((size_t)B * 4) : 0;
+  w.sv_accl = (float *)p;      p += sv ? vrp_align_up((size_t)B * 4) : 0;
+  w.sv_accp = (float *)p;      p += sv ? vrp_align_up((size_t)B * 4) : 0;
+  w.sv_load = (double *)p;     p += sv ? vrp_align_up((size_t)B * 8) : 0;
   return w;
 }
 
@@ -168,7 +185,8 @@ static inline int64_t decws_bytes(int B, int N) {
                    vrp_align_up(pairs_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 5 * vrp_align_up((size_t)B * 4) +
                    vrp_align_up((size_t)B * 8) +
-                   vrp_align_up((size_t)hist_rows(N) * B * 8) + vrp_align_up(4));
+                   vrp_align_up((size_t)hist_rows(N) * B * 8) + vrp_align_up(4) +
+                   persist_save_bytes(B, N));
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

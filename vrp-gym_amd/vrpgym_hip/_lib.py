@@ -3,6 +3,7 @@ import ctypes as C
 import os
 
 KIND_TSP, KIND_VRP, KIND_IRP = 0, 1, 2
+ABI_VERSION = 7   # include/vrpgym_hip.h: VRP_ABI_VERSION (struct layouts below mirror that header)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -129,6 +130,7 @@ def _declare(lib):
         "vrp_gemm_nt": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "vrp_step_kernel_name": (C.c_char_p, [i32, i32, i32, i32]),
         "vrp_persistent_capacity": (i32, []),
+        "vrp_persistent_failures": (i32, []),
         "vrp_encoder_kernel_name": (C.c_char_p, [P(EncoderWeights), i32, i32, i32]),
         "vrp_source_hash": (C.c_char_p, []),
         "vrp_last_error": (C.c_char_p, []),
@@ -155,8 +157,17 @@ def lib():
                 f"libvrpgym_hip.so not found at {path}: build it with "
                 "`python __graft_entry__.py` or `make -C vrp-gym_amd/csrc` "
                 "(there is no CPU fallback)")
-        _LIB = C.CDLL(path, mode=C.RTLD_GLOBAL)
-        EXPORTS = _declare(_LIB)
+        cand = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        cand.vrp_abi_version.restype = C.c_int
+        got = cand.vrp_abi_version()
+        if got != ABI_VERSION:
+            # a stale build: its vrp_rollout_io / vrp_encoder_weights layouts differ from the
+            # structs mirrored here -- calling into it would read garbage pointers
+            raise RuntimeError(
+                f"{path} implements ABI {got}, this binding needs {ABI_VERSION}: rebuild it "
+                "(`python __graft_entry__.py` or `make -C vrp-gym_amd/csrc`)")
+        EXPORTS = _declare(cand)
+        _LIB = cand
     return _LIB
 
 
