@@ -28,15 +28,16 @@ import torch
 import agents, vrpgym_hip as hip
 from copy import deepcopy
 from agents import runtime
-from gym_vrp.envs import VRPEnv
+from gym_vrp.envs import VRPEnv, IRPEnv
 cap = hip.lib().vrp_persistent_capacity()
 B, N = 2048, 20
-env = VRPEnv(N, B, 1, 13)
-agent = agents.VRPAgent(seed=69)
+KIND = int(os.environ.get("GUARD_KIND", "1"))
+env = (VRPEnv if KIND == 1 else IRPEnv)(N, B, 1, 13)
+agent = (agents.VRPAgent if KIND == 1 else agents.IRPAgent)(seed=69)
 agent.model.eval()
-steps = runtime.max_steps_for(1, N)
+steps = runtime.max_steps_for(KIND, N)
 noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
-out = {"capacity": cap, "kernel": hip.lib().vrp_step_kernel_name(1, B, N, 0).decode()}
+out = {"capacity": cap, "kernel": hip.lib().vrp_step_kernel_name(KIND, B, N, 0).decode()}
 res = []
 for persistent in (False, True):
     with torch.no_grad():
@@ -44,6 +45,28 @@ for persistent in (False, True):
                             persistent=persistent)
     torch.cuda.synchronize()
     res.append(r)
+# the traces a training step records (masks, IRP loads) through both paths
+rec = []
+for persistent in (False, True):
+    with torch.no_grad():
+        r = runtime.rollout(agent.model, deepcopy(env), False, noise=noise, record=True,
+                            persistent=persistent)
+    torch.cuda.synchronize()
+    rec.append(r)
+Tr = rec[0].T
+out["traces_equal"] = bool(rec[1].T == Tr and torch.equal(rec[0].actions[:Tr], rec[1].actions[:Tr])
+                           and torch.equal(rec[0].mask_trace[:Tr], rec[1].mask_trace[:Tr])
+                           and (rec[0].load_trace is None
+                                or torch.equal(rec[0].load_trace[:Tr], rec[1].load_trace[:Tr]))
+                           and torch.equal(rec[0].acc_logp, rec[1].acc_logp))
+final = [deepcopy(env) for _ in range(2)]
+for e, persistent in zip(final, (False, True)):
+    with torch.no_grad():
+        runtime.rollout(agent.model, e, True, persistent=persistent)
+torch.cuda.synchronize()
+out["env_state_equal"] = bool(torch.equal(final[0]._visited, final[1]._visited)
+                              and torch.equal(final[0]._cur, final[1]._cur)
+                              and torch.equal(final[0]._load, final[1]._load))
 out["nan"] = bool(torch.isnan(res[1].acc_loss).any())
 out["T"] = [res[0].T, res[1].T]
 out["failures"] = hip.lib().vrp_persistent_failures()
@@ -77,7 +100,7 @@ def test_capacity_on_the_whole_device():
     full = _child({})
     assert full["capacity"] == cap and full["kernel"] == "decode_persistent_kernel"
     assert full["equal"] and not full["nan"] and full["T"][0] == full["T"][1]
-    assert full["failures"] == 0, full
+    assert full["traces_equal"] and full["env_state_equal"] and full["failures"] == 0, full
 
 
 def test_cu_mask_falls_back_before_the_episode():
@@ -91,7 +114,8 @@ def test_cu_mask_falls_back_before_the_episode():
     assert r["equal"] and not r["nan"] and r["failures"] == 0, r
 
 
-def test_forced_non_resident_grid_falls_back_transparently():
+@pytest.mark.parametrize("kind", [1, 2])
+def test_forced_non_resident_grid_falls_back_transparently(kind):
     """B = 2048 single-wave workgroups forced onto 32 compute units: most of the grid waits for
     words of workgroups that have no slot.  The waits give up after 20 ms, the grid drains, and the
     finalize kernel reruns the steps: exactly the per-step path's results, in seconds."""
@@ -99,9 +123,11 @@ def test_forced_non_resident_grid_falls_back_transparently():
     if probe["capacity"] >= 2048:
         pytest.skip("this runtime ignores ROC_GLOBAL_CU_MASK")
     r = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff", "VRP_PERSISTENT_FORCE": "1",
-                "VRP_PERSISTENT_LEASE": "0"}, timeout=120)
+                "VRP_PERSISTENT_LEASE": "0", "GUARD_KIND": str(kind)}, timeout=120)
+    print("forced non-resident episodes:", r)
     assert r["equal"] and not r["nan"] and r["T"][0] == r["T"][1], r
-    print("forced non-resident episode:", r)
+    assert r["traces_equal"] and r["env_state_equal"], r
+    assert r["failures"] >= 1, r      # the first forced episode cannot have been resident
     assert r["seconds"] < 90, r
 
 
@@ -115,8 +141,8 @@ import agents, vrpgym_hip as hip
 from agents import runtime
 from gym_vrp.envs import VRPEnv
 tag, start_file = sys.argv[1], sys.argv[2]
+B, N, ROLLOUTS = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 torch.cuda.set_device(0)
-B, N = 1024, 40
 env = VRPEnv(N, B, 1, 17)
 agent = agents.VRPAgent(seed=69)
 agent.model.eval()
@@ -132,7 +158,7 @@ t0 = time.time()
 h = hashlib.sha256()
 torch.manual_seed(11)
 with torch.no_grad():
-    for i in range(50):
+    for i in range(ROLLOUTS):
         r = runtime.rollout(agent.model, env, False, reset_env=True)
         h.update(r.acc_loss.cpu().numpy().tobytes())
         h.update(r.acc_logp.cpu().numpy().tobytes())
@@ -149,7 +175,7 @@ print("RESULT " + json.dumps({"digest": h.hexdigest(), "seconds": time.time() - 
 """
 
 
-def _pair(tmp_path, extra_env, concurrent):
+def _pair(tmp_path, extra_env, concurrent, shape=(1024, 40, 50)):
     env = dict(os.environ)
     env.update(extra_env)
     script = tmp_path / "pair_child.py"
@@ -158,7 +184,8 @@ def _pair(tmp_path, extra_env, concurrent):
     outs = {}
 
     def one(tag, start):
-        p = _proc.run([sys.executable, str(script), tag, start], env=env, timeout=200)
+        p = _proc.run([sys.executable, str(script), tag, start] + [str(x) for x in shape], env=env,
+                      timeout=200)
         outs[tag] = p
 
     if concurrent:
@@ -180,18 +207,21 @@ def _pair(tmp_path, extra_env, concurrent):
     return res
 
 
-@pytest.mark.parametrize("lease", ["1", "0"])
-def test_two_independent_processes_share_one_gpu(tmp_path, lease):
+@pytest.mark.parametrize("lease,shape", [("1", (1024, 40, 50)), ("0", (1024, 40, 50)),
+                                         ("0", (2048, 20, 600)), ("1", (2048, 20, 600))])
+def test_two_independent_processes_share_one_gpu(tmp_path, lease, shape):
     """50 sampled VRP-40 x 1024 rollouts + 5 REINFORCE epochs in each of two unrelated processes
     on cuda:0 at the same time, default settings.  lease=1: they take turns on the persistent
     grid through the shared lease word.  lease=0: nothing coordinates them -- both launch grids
     sized against the whole device, hand-off waits time out, episodes fall back in-kernel.
-    Either way: every number equals the solo run's, and both finish in well under a minute."""
+    Either way: every number equals the solo run's, and both finish in well under a minute.
+    (2048, 20, 600): two one-wave grids of 2048 workgroups do not fit the device together, and 600
+    back-to-back episodes per process overlap for certain.)"""
     extra = {"VRP_PERSISTENT_LEASE": lease}
-    solo = _pair(tmp_path, extra, concurrent=False)
+    solo = _pair(tmp_path, extra, concurrent=False, shape=shape)
     assert solo["a"]["digest"] == solo["b"]["digest"]          # deterministic to begin with
     assert solo["a"]["failures"] == 0, solo
-    both = _pair(tmp_path, extra, concurrent=True)
+    both = _pair(tmp_path, extra, concurrent=True, shape=shape)
     print("solo", solo, "\nconcurrent", both)
     for t in "ab":
         assert both[t]["digest"] == solo["a"]["digest"], (t, both, solo)
