@@ -101,6 +101,10 @@ typedef struct vrp_encoder_weights {
   const float *node_embed_weight, *node_embed_bias;    /* (128,node_dim) */
   const float *depot_embed_weight, *depot_embed_bias;  /* (128,2) or NULL */
   vrp_encoder_layer layer[8];
+  const void *split;   /* vrp_encoder_prepare's output for THESE weights, or NULL.  With it the
+                        * eval-mode kernels run their dense products on the bf16 matrix cores (each
+                        * fp32 operand as three bf16 planes, six MFMAs per product: fp32 accuracy at
+                        * 2.7x the fp32 MFMA rate, csrc/encoder_x3.h); without it, on the fp32 MFMA. */
 } vrp_encoder_weights;
 
 typedef struct vrp_decoder_weights {
@@ -118,6 +122,13 @@ typedef struct vrp_decoder_weights {
 int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden);
 int64_t vrp_decoder_workspace_bytes(int kind, int B, int N);
 int64_t vrp_decoder_derived_bytes(void);
+
+/* Splits the dense weights of every layer (in_proj, out_proj, ff.0, ff.2) into three bf16 planes
+ * in MFMA fragment order for vrp_encoder_weights.split (vrp_encoder_split_bytes bytes; hidden a
+ * multiple of 128).  Re-run whenever those parameters change (the shipped binding compares the
+ * tensors' version counters before every launch); a stale buffer means stale weights. */
+int64_t vrp_encoder_split_bytes(int hidden, int num_layers);
+int vrp_encoder_prepare(const vrp_encoder_weights *w, void *split, void *stream);
 
 /* N1-N3  GraphEncoder.forward agents/graph_encoder.py:41-58, GraphDemandEncoder
  * .forward :95-138, MultiHeadAttentionLayer.forward :183-198, BatchNorm :141-154.

@@ -64,6 +64,30 @@ class _PaddedFF:
             self.version = ver
 
 
+class _SplitWeights:
+    """The encoder's dense weights as three bf16 planes in MFMA fragment order
+    (vrp_encoder_prepare; csrc/encoder_x3.h): what lets the eval-mode kernels run their fp32
+    products on the bf16 matrix cores.  One device buffer per encoder, refreshed in place when a
+    weight's version counter moves (optimizer step, load_state_dict, the zero-padded feed-forward
+    shadows being re-synced), so captured hipGraphs keep pointing at it."""
+
+    def __init__(self, w, mats, dev):
+        lib = hip.lib()
+        self.mats = mats
+        self.buf = torch.empty(int(lib.vrp_encoder_split_bytes(w.hidden, w.num_layers)),
+                               dtype=torch.uint8, device=dev)
+        self.version = None
+        w.split = self.buf.data_ptr()
+
+    def sync(self, w):
+        ver = tuple((t._version, t.data_ptr()) for t in self.mats)
+        if ver != self.version:
+            dev = self.buf.device
+            hip.check(hip.lib().vrp_encoder_prepare(C.byref(w), self.buf.data_ptr(),
+                                                    hip.current_stream(dev)))
+            self.version = ver
+
+
 def invalidate(module):
     _struct_cache.pop(module, None)
     _derived_cache.pop(module, None)
@@ -123,6 +147,8 @@ def encoder_struct(enc):
     if hit is not None:
         for pad in hit[2]:
             pad.sync()
+        if hit[3] is not None:
+            hit[3].sync(hit[0])
         return hit[0]
     node_dim, emb, hidden, heads = enc._dims
     if not check_supported_dims(emb, heads, hidden):
@@ -165,7 +191,17 @@ def encoder_struct(enc):
             L.ff0_weight, L.ff0_bias = P(layer.ff[0].weight), P(layer.ff[0].bias)
             L.ff2_weight = P(layer.ff[2].weight)
         L.ff2_bias = P(layer.ff[2].bias)
-    _struct_cache[enc] = (w, keep, padded)
+    split = None
+    if enc.node_embed.weight.is_cuda and heads == HEADS and os.environ.get("VRP_ENCODER_FP32") is None:
+        mats = []
+        for i, layer in enumerate(enc.attention_layers):
+            att = layer.attention_layer
+            pad = padded[i] if padded else None
+            mats += [att.in_proj_weight, att.out_proj.weight,
+                     pad.w0 if pad else layer.ff[0].weight, pad.w2 if pad else layer.ff[2].weight]
+        split = _SplitWeights(w, mats, enc.node_embed.weight.device)
+        split.sync(w)
+    _struct_cache[enc] = (w, keep, padded, split)
     return w
 
 
@@ -196,7 +232,7 @@ def decoder_struct(dec):
     w.out_proj_weight, w.out_proj_bias = P(att.out_proj.weight), P(att.out_proj.bias)
     w.kp_weight, w.att_output_weight = P(dec._kp.weight), P(dec._att_output.weight)
     w.context_proj_weight = P(dec._context_proj.weight)
-    _struct_cache[dec] = (w, keep, [])
+    _struct_cache[dec] = (w, keep, [], None)
     return w
 
 

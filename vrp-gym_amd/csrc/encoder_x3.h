@@ -1,0 +1,137 @@
+// fp32 matrix products on the bf16 matrix cores (round 5).
+//
+// gfx950 runs v_mfma_f32_16x16x4_f32 at 1/16 of the rate of v_mfma_f32_16x16x32_bf16
+// (MI355X_MICROARCH.md: 157 TFLOP/s against 2.5 PFLOP/s dense), and every eval-mode encoder
+// kernel is bound by it.  An fp32 value is the exact sum of three bf16 values up to 2^-24 of
+// itself: h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), each rounded to nearest even, both
+// subtractions exact.  A product x y is then h h' + (h m' + m h') + (h l' + l h' + m m') up to
+// 3 * 2^-24 |x y| (the dropped cross terms m l', l m', l l'), i.e. SIX bf16 MFMAs with fp32
+// accumulation -- products of bf16 pairs are exact in fp32 -- carry an fp32 GEMM at 16 / 6 = 2.7x
+// the fp32 MFMA rate.  Measured against fp64 on random data (tools/micro/bf16x3_probe.hip,
+// profiles/r05_bf16x3_probe.txt): K = 128: rms error 1.7e-7 vs 2.3e-7 for the fp32 MFMA / an fmaf
+// chain; K = 512: 7.6e-7 vs 9.1e-7.  Not a reduced-precision path: the error is that of fp32.
+//
+// What makes it pay is WHERE the splitting happens (5.5 VALU instructions per element):
+//   * weights are split once per parameter update (vrp_encoder_prepare) into fragment order:
+//     a lane's operand of one MFMA is 16 contiguous bytes, a wave's load 1 KB = eight whole lines;
+//   * activations are split by their PRODUCER -- the epilogue lane that owns the accumulator
+//     element -- and live in LDS as three bf16 planes; the eight consumer waves of a tile read
+//     ready-made operands (one ds_read_b128 per plane and k-chunk), nobody splits twice.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define X3_PITCH 136   // bf16 per LDS row of one plane: 128 + 8 (272 B: the 16 rows of a b128 read
+                       // start 4 banks apart -> the 16 lanes of a row group cover all 64 banks)
+#define X3_FRAG 6144   // bf16 per weight fragment: 3 planes x 4 k-chunks x 64 lanes x 8
+
+struct Bf3 { __bf16 h, m, l; };
+__device__ __forceinline__ Bf3 x3_split(float x) {
+  Bf3 s;
+  s.h = (__bf16)x;
+  const float r1 = x - (float)s.h;
+  s.m = (__bf16)r1;
+  s.l = (__bf16)(r1 - (float)s.m);
+  return s;
+}
+// one element into the three planes of an LDS tile ([3][rows][X3_PITCH])
+__device__ __forceinline__ void x3_store(__bf16 *tile, int plane_elems, int row, int col, float v) {
+  const Bf3 s = x3_split(v);
+  __bf16 *p = tile + row * X3_PITCH + col;
+  p[0] = s.h;
+  p[plane_elems] = s.m;
+  p[2 * plane_elems] = s.l;
+}
+// four consecutive columns
+__device__ __forceinline__ void x3_store4(__bf16 *tile, int plane_elems, int row, int col,
+                                          float v0, float v1, float v2, float v3) {
+  const Bf3 a = x3_split(v0), b = x3_split(v1), c = x3_split(v2), d = x3_split(v3);
+  __bf16 *p = tile + row * X3_PITCH + col;
+  *reinterpret_cast<bf16x4 *>(p) = bf16x4{a.h, b.h, c.h, d.h};
+  *reinterpret_cast<bf16x4 *>(p + plane_elems) = bf16x4{a.m, b.m, c.m, d.m};
+  *reinterpret_cast<bf16x4 *>(p + 2 * plane_elems) = bf16x4{a.l, b.l, c.l, d.l};
+}
+
+// A weight fragment: 16 weight rows (= output columns) x 128 k, three planes, in registers.
+// Lane (i16, q) holds, per plane and chunk j, k = 32 j + 8 q .. + 7 of weight row i16.
+struct Frag3 { bf16x8 p[3][4]; };
+__device__ __forceinline__ void x3_load_frag(Frag3 &f, const __bf16 *__restrict__ frag, int lane) {
+  const bf16x8 *src = reinterpret_cast<const bf16x8 *>(frag) + lane;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.p[p][j] = src[(p * 4 + j) * 64];
+}
+
+#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// acc[rt] (16 rows x 16 columns, D: row = 4 (lane >> 4) + r, column = lane & 15) +=
+// A(rows 16 rt .., 128 k; LDS planes) W^T(fragment).  Small terms first, h h' last.
+template <int RT16>
+__device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, int plane_elems,
+                                       const Frag3 &w, int lane) {
+  const int i16 = lane & 15, q = lane >> 4;
+  const __bf16 *ap = tile + i16 * X3_PITCH + 8 * q;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16x8 a[RT16][3];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[rt][p] = *reinterpret_cast<const bf16x8 *>(ap + p * plane_elems + rt * 16 * X3_PITCH + 32 * j);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][1], w.p[1][j], acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[2][j], acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][2], w.p[0][j], acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[1][j], acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][1], w.p[0][j], acc[rt]);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[0][j], acc[rt]);
+  }
+}
+
+// ---- the split weights of one encoder (vrp_encoder_prepare) ------------------------------------
+// Per layer, in fragments of X3_FRAG bf16: in_proj rows 16 t .. (24 fragments), out_proj (8),
+// ff.0 (hidden / 16), ff.2 (8 row tiles x hidden / 128 k-slices, slice-minor).
+__host__ __device__ static inline int x3_layer_frags(int hidden) { return 32 + hidden / 16 + hidden / 16; }
+__host__ __device__ static inline int x3_frag_win(int t) { return t; }
+__host__ __device__ static inline int x3_frag_wo(int t) { return 24 + t; }
+__host__ __device__ static inline int x3_frag_w1(int t) { return 32 + t; }
+__host__ __device__ static inline int x3_frag_w2(int hidden, int t, int s) {
+  return 32 + hidden / 16 + t * (hidden / 128) + s;
+}
+
+// one thread per (fragment, lane, plane-independent chunk): reads 8 fp32, writes 3 x 16 bytes
+__global__ __launch_bounds__(256) void x3_prepare_kernel(vrp_encoder_weights w, __bf16 *__restrict__ out) {
+  const int hidden = w.hidden, per_layer = x3_layer_frags(hidden);
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // (layer, frag, chunk j, lane)
+  const int lane = idx & 63, j = (idx >> 6) & 3, f = idx >> 8;
+  if (f >= per_layer * w.num_layers) return;
+  const int l = f / per_layer, fi = f - l * per_layer;
+  const vrp_encoder_layer &L = w.layer[l];
+  const int i16 = lane & 15, q = lane >> 4;
+  const float *src;
+  if (fi < 24) src = L.in_proj_weight + (size_t)(16 * fi + i16) * 128;
+  else if (fi < 32) src = L.out_proj_weight + (size_t)(16 * (fi - 24) + i16) * 128;
+  else if (fi < 32 + hidden / 16) src = L.ff0_weight + (size_t)(16 * (fi - 32) + i16) * 128;
+  else {
+    const int r = fi - 32 - hidden / 16, t = r / (hidden / 128), s = r - t * (hidden / 128);
+    src = L.ff2_weight + (size_t)(16 * t + i16) * hidden + 128 * s;
+  }
+  src += 32 * j + 8 * q;
+  bf16x8 h, m, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const Bf3 s = x3_split(src[e]);
+    h[e] = s.h; m[e] = s.m; lo[e] = s.l;
+  }
+  bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + (size_t)f * X3_FRAG) + lane;
+  dst[(0 * 4 + j) * 64] = h;
+  dst[(1 * 4 + j) * 64] = m;
+  dst[(2 * 4 + j) * 64] = lo;
+}

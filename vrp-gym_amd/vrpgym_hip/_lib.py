@@ -36,7 +36,7 @@ class EncoderWeights(C.Structure):
                 ("num_layers", C.c_int32), ("heads", C.c_int32), ("reserved_", C.c_int32),
                 ("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
                 ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
-                ("layer", EncoderLayer * 8)]
+                ("layer", EncoderLayer * 8), ("split", c_vp)]
 
 
 class EncoderLayerGrads(C.Structure):
@@ -93,6 +93,8 @@ def _declare(lib):
         "vrp_decoder_workspace_bytes": (i64, [i32, i32, i32]),
         "vrp_decoder_derived_bytes": (i64, []),
         "vrp_encoder_forward": (i32, [P(EncoderWeights), i32, i32, i32, vp, vp, vp, vp, vp]),
+        "vrp_encoder_split_bytes": (i64, [i32, i32]),
+        "vrp_encoder_prepare": (i32, [P(EncoderWeights), vp, vp]),
         "vrp_decoder_prepare": (i32, [i32, P(DecoderWeights), vp, vp]),
         "vrp_decode_prologue": (i32, [i32, vp, i32, i32, vp, vp, vp]),
         "vrp_decode_step": (i32, [i32, vp, P(DecoderWeights), P(Env), vp, vp, P(RolloutIO),
