@@ -2309,6 +2309,10 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     if (!su.from_env && r < rows) v = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
     *reinterpret_cast<float4 *>(stage + r * EB_LD + c4) = v;
   }
+  // the attention writes only the rows of real nodes: the others must be finite from the start
+  // (they are multiplied by zero weights downstream, and 0 x NaN is NaN)
+  for (int i = tid; i < 3 * PE / 8; i += 512)
+    reinterpret_cast<float4 *>(AT3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (su.from_env) {
     __syncthreads();
     if (blockIdx.x == 0 && tid < su.nflags) su.notdone[tid] = 0;
@@ -2508,6 +2512,267 @@ static bool encoder_stack_x3_applies(const vrp_encoder_weights *w) {
   return encoder_x3_enabled(w) && w->num_layers <= 3;
 }
 
+// ---- out-proj + BN1 + FF + BN2 for LARGE row counts on the bf16 matrix cores -----------------
+// encoder_block8_kernel's scheme (persistent workgroups, a wave owns 16 output columns, hidden
+// slices alternate between two buffers, the next tile's attention rows travel behind the last
+// stage) on 64-row tiles of three-plane operands: 3 buffers x 3 planes x 64 rows x 272 B = 153 KB.
+// The attention rows arrive in fp32 and are split by the thread that stores them into LDS; the
+// residual and y1 stay in the owning lane's registers.  Nine stages per tile, two fragment buffers
+// that swap roles from tile to tile (the body is instantiated for both assignments).
+template <int RT16>
+__global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
+    const float *__restrict__ att, const float *__restrict__ x, const __bf16 *__restrict__ lf_,
+    const float *__restrict__ bo, const float *__restrict__ norm1, const float *__restrict__ b1,
+    const float *__restrict__ b2, const float *__restrict__ norm2, float *__restrict__ y, int rows,
+    int hidden, int ntiles) {
+  constexpr int RTW = 16 * RT16, PE = RTW * X3_PITCH, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16 *hb0 = reinterpret_cast<__bf16 *>(smem);   // attention tile / hidden slices (roles alternate)
+  __bf16 *hb1 = hb0 + 3 * PE;
+  __bf16 *XB3 = hb1 + 3 * PE;                        // y1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int c = wave * 16 + i16;
+  const int nchunk = hidden / 128;
+  float4 pa[PF];
+  auto fetch_att = [&](int tile) {
+    const int row0 = tile * RTW;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < rows) pa[u] = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+    }
+  };
+  auto store_att = [&](__bf16 *dst) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      x3_store4(dst, PE, r, c4, pa[u].x, pa[u].y, pa[u].z, pa[u].w);
+    }
+  };
+  const float bb_o = bo[c], mean1 = norm1[c], mult1 = norm1[128 + c], beta1 = norm1[256 + c];
+  const float bb_2 = b2[c], mean2 = norm2[c], mult2 = norm2[128 + c], beta2 = norm2[256 + c];
+  int tile = blockIdx.x;
+  __bf16 *abuf = hb0, *other = hb1;
+  if (tile < ntiles) { fetch_att(tile); store_att(abuf); }
+  Frag3 fa, fb;
+  x3_load_frag(fa, lf_ + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
+  __syncthreads();
+  // one tile; fa holds the Wo fragment on entry (nine stages: the next tile's arrives in fb and
+  // is moved over, 48 register moves per tile)
+#define FA fa
+#define FB fb
+  while (tile < ntiles) {
+    // (the weights do not change from tile to tile; an opaque zero keeps the compiler from
+    // hoisting the nine fragment loads out of this loop into registers it does not have)
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const __bf16 *lf = lf_ + zero;
+    const int row0 = tile * RTW, valid = rows - row0;
+    float xr[RT16][4];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        xr[rt][r] = row < valid ? x[(size_t)(row0 + row) * 128 + c] : 0.f;
+      }
+    f32x4v acc[RT16], gacc[RT16];
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt) { acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; gacc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    // ---- y1 = BN1(x + att Wo^T + bo) ----------------------------------------------------------
+    x3_load_frag(FB, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);
+    x3_mma<RT16>(acc, abuf, PE, FA, lane);
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        xr[rt][r] = (acc[rt][r] + bb_o + xr[rt][r] - mean1) * mult1 + beta1;
+        x3_store(XB3, PE, rt * 16 + 4 * q + r, c, xr[rt][r]);
+        if (r == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    __syncthreads();
+    // ---- hidden slices: up (y1 -> slice planes in LDS), down (slice -> g in registers) ---------
+    auto slice_up = [&](int ch, const Frag3 &f, __bf16 *hb) {
+      const float bb = b1[ch * 128 + c];
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      x3_mma<RT16>(acc, XB3, PE, f, lane);
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          x3_store(hb, PE, rt * 16 + 4 * q + r, c, fmaxf(acc[rt][r] + bb, 0.f));
+          if (r == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    x3_load_frag(FA, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
+    slice_up(0, FB, abuf);     // the attention rows are dead by now
+    __syncthreads();
+    for (int ch = 0; ch + 1 < nchunk; ++ch) {
+      __bf16 *hcur = (ch & 1) ? other : abuf, *hnext = (ch & 1) ? abuf : other;
+      x3_load_frag(FB, lf + (size_t)x3_frag_w1((ch + 1) * 8 + wave) * X3_FRAG, lane);
+      x3_mma<RT16>(gacc, hcur, PE, FA, lane);
+      x3_load_frag(FA, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      slice_up(ch + 1, FB, hnext);
+      __syncthreads();
+    }
+    // last way down; the next tile's attention rows travel behind it into the free buffer
+    __bf16 *hlast = ((nchunk - 1) & 1) ? other : abuf, *hfree = ((nchunk - 1) & 1) ? abuf : other;
+    const int next = tile + gridDim.x;
+    if (next < ntiles) fetch_att(next);
+    x3_load_frag(FB, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);   // Wo for the next tile
+    x3_mma<RT16>(gacc, hlast, PE, FA, lane);
+    if (next < ntiles) store_att(hfree);
+    // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * q + r;
+        if (row < valid)
+          y[(size_t)(row0 + row) * 128 + c] = (gacc[rt][r] + bb_2 + xr[rt][r] - mean2) * mult2 + beta2;
+      }
+    __syncthreads();   // next tile's attention rows complete, XB3 and hlast free
+    abuf = hfree; other = hlast;
+    tile = next;
+    fa = fb;
+  }
+#undef FA
+#undef FB
+}
+
+template <int RT16>
+static int launch_encoder_block8_x3(const float *att, const float *x, const vrp_encoder_weights *w,
+                                    int l, const float *norm1, const float *norm2, float *y, int rows,
+                                    hipStream_t st) {
+  constexpr int RTW = 16 * RT16;
+  const size_t lds = (size_t)3 * 3 * RTW * X3_PITCH * 2;
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_block8_x3_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_block8_x3: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set.mark();
+  }
+  const vrp_encoder_layer &L = w->layer[l];
+  const __bf16 *lf = reinterpret_cast<const __bf16 *>(w->split) +
+                     (size_t)l * x3_layer_frags(w->hidden) * X3_FRAG;
+  const int ntiles = (rows + RTW - 1) / RTW;
+  hipLaunchKernelGGL(encoder_block8_x3_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, att, x,
+                     lf, L.out_proj_bias, norm1, L.ff0_bias, L.ff2_bias, norm2, y, rows, w->hidden,
+                     ntiles);
+  VRP_CHECK_LAUNCH("encoder_block8_x3");
+  return 0;
+}
+
+// ---- in_proj + attention of whole graphs, LARGE batches, in_proj on the bf16 matrix cores ------
+// encoder_qkv_attn8_kernel with the projection as six bf16 MFMAs per product: the input tile is
+// split by the threads that store it into LDS (three planes, overlaid by q|k|v once every wave has
+// finished reading them), the three 16-column fragments of a wave's 48-column block alternate
+// between two fragment buffers.  The attention (K = 16 per head) stays on the fp32 MFMA.
+template <int RT16>
+__global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *__restrict__ x,
+                                                                    const __bf16 *__restrict__ lf_,
+                                                                    const float *__restrict__ bin,
+                                                                    float *__restrict__ att, int B,
+                                                                    int N, int G, int ntiles) {
+  constexpr int RTW = 16 * RT16, PE = RTW * X3_PITCH, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Q_s = smem;                                   // [RTW][QA_QLD] q | k | v (fp32)
+  __bf16 *X3 = reinterpret_cast<__bf16 *>(smem);       // [3][RTW][X3_PITCH]: the input tile first
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  float4 pf[PF];
+  auto fetch = [&](int tile) {
+    const int g0 = tile * G;
+    const int rows = min(G, B - g0) * N;
+    const size_t row0 = (size_t)g0 * N;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+    }
+  };
+  float bb[3];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) bb[ct] = bin[wave * 48 + ct * 16 + i16];
+  Frag3 fa, fb;
+  x3_load_frag(fa, lf_ + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    int zero;   // (keeps the fragment loads inside the loop: see encoder_block8_x3_kernel)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const __bf16 *lf = lf_ + zero;
+    const int g0 = tile * G;
+    const int graphs = min(G, B - g0);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      x3_store4(X3, PE, r, c4, pf[u].x, pf[u].y, pf[u].z, pf[u].w);
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    f32x4v acc[3][RT16];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) acc[ct][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
+    x3_mma<RT16>(acc[0], X3, PE, fa, lane);
+    x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
+    x3_mma<RT16>(acc[1], X3, PE, fb, lane);
+    x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);   // the next tile's first
+    x3_mma<RT16>(acc[2], X3, PE, fa, lane);
+    fa = fb;
+    __syncthreads();   // every wave is done with the input planes: q|k|v may overlay them
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      const int col = wave * 48 + ct * 16 + i16;
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[ct][rt][r] + bb[ct];
+    }
+    __syncthreads();
+    float *o = att + (size_t)g0 * N * VRP_EMB;
+    if (N <= 32) qa8_stage_attention_mfma<2>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    else if (N <= 48) qa8_stage_attention_mfma<3>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    else qa8_stage_attention_mfma<4>(Q_s, N, graphs, RTW - 1, o, lane, wave, VRP_EMB);
+    __syncthreads();   // everybody done with Q_s before the next tile's planes land on it
+  }
+}
+
+static int launch_qkv_attn8_x3(const float *x, const vrp_encoder_weights *w, int l, float *att, int B,
+                               int N, hipStream_t st) {
+  constexpr int RT16 = 5, RTW = 80;
+  const size_t lds = (size_t)RTW * QA_QLD * sizeof(float);
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_qkv_attn8_x3_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("qkv_attn8_x3: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set.mark();
+  }
+  const __bf16 *lf = reinterpret_cast<const __bf16 *>(w->split) +
+                     (size_t)l * x3_layer_frags(w->hidden) * X3_FRAG;
+  const int G = RTW / N, ntiles = (B + G - 1) / G;
+  hipLaunchKernelGGL(encoder_qkv_attn8_x3_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, x, lf,
+                     w->layer[l].in_proj_bias, att, B, N, G, ntiles);
+  VRP_CHECK_LAUNCH("encoder_qkv_attn8_x3");
+  return 0;
+}
+
 // small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
 static bool encoder_stack_applies(const vrp_encoder_weights *w, int train, int B, int N) {
   static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
@@ -2678,7 +2943,8 @@ extern "C" const char *vrp_encoder_kernel_name(const vrp_encoder_weights *w, int
   const int R = B * N;
   if (train) return "gemm_nt / gemm_rows + encoder_attention_mfma + bn_* per layer (train mode)";
   if (N <= 64 && (80 / N) * N * 4 >= 3 * 80 && R >= 256 * 80)
-    return "encoder_qkv_attn8_kernel<5> + encoder_block8_kernel<5> per layer";
+    return encoder_x3_enabled(w) ? "encoder_qkv_attn8_x3_kernel<5> + encoder_block8_x3_kernel<4> per layer"
+                                 : "encoder_qkv_attn8_kernel<5> + encoder_block8_kernel<5> per layer";
   return "qkv/attention + encoder_block* per layer";
 }
 
@@ -2709,7 +2975,9 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
     } else if (!train && N <= 64 && (80 / N) * N * 4 >= 3 * 80 && !qa_off) {
       // large batches, eval mode: in_proj + attention of 80 / N whole graphs per workgroup
       // (only when the graphs fill at least three quarters of the five row tiles)
-      if (int r = launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
+      if (int r = encoder_x3_enabled(w) ? launch_qkv_attn8_x3(cur, w, l, ws.att, B, N, st)
+                                        : launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st))
+        return r;
     } else if (heads == 8 && qkv_attn_graph_applies(train, B, N)) {
       // 64 < N <= 102, eval mode: in_proj + attention of one graph per workgroup pass, q|k|v in LDS
       if (int r = launch_qkv_attn_graph(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
@@ -2738,7 +3006,8 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       else if ((rtw_env && rtw_env[0] == '8') || (!rtw_env && R >= 256 * 80))
         // >= one 80-row tile per CU: persistent 8-wave kernel (827 vs 914 us per layer for
         // the 64-row kernel at 8192 x 40)
-        r = launch_encoder_block8<5>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
+        r = encoder_x3_enabled(w) ? launch_encoder_block8_x3<4>(ws.att, cur, w, l, n1, n2, nxt, R, st)
+                                  : launch_encoder_block8<5>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows
         r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 12 * 1024)   // small batches: at most one workgroup per CU (256 CUs)

@@ -72,26 +72,29 @@ __device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, 
                                        const Frag3 &w, int lane) {
   const int i16 = lane & 15, q = lane >> 4;
   const __bf16 *ap = tile + i16 * X3_PITCH + 8 * q;
+  // the operands of (chunk j, row tile rt) are read while the MFMAs of the item before run:
+  // two operand sets alive at a time, not 4 x RT16 (the scheduling fences keep the compiler
+  // from hoisting every LDS read of the stage to its top)
+  bf16x8 a[2][3];
+  auto rd = [&](bf16x8 (&d)[3], int it) {
+    const int j = it / RT16, rt = it - j * RT16;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    bf16x8 a[RT16][3];
+    for (int p = 0; p < 3; ++p)
+      d[p] = *reinterpret_cast<const bf16x8 *>(ap + p * plane_elems + rt * 16 * X3_PITCH + 32 * j);
+  };
+  rd(a[0], 0);
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        a[rt][p] = *reinterpret_cast<const bf16x8 *>(ap + p * plane_elems + rt * 16 * X3_PITCH + 32 * j);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][1], w.p[1][j], acc[rt]);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[2][j], acc[rt]);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][2], w.p[0][j], acc[rt]);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[1][j], acc[rt]);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][1], w.p[0][j], acc[rt]);
-#pragma unroll
-    for (int rt = 0; rt < RT16; ++rt) acc[rt] = X3_MFMA(a[rt][0], w.p[0][j], acc[rt]);
+  for (int it = 0; it < 4 * RT16; ++it) {
+    const int j = it / RT16, rt = it - j * RT16, cur = it & 1;
+    if (it + 1 < 4 * RT16) rd(a[cur ^ 1], it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[rt] = X3_MFMA(a[cur][1], w.p[1][j], acc[rt]);
+    acc[rt] = X3_MFMA(a[cur][0], w.p[2][j], acc[rt]);
+    acc[rt] = X3_MFMA(a[cur][2], w.p[0][j], acc[rt]);
+    acc[rt] = X3_MFMA(a[cur][0], w.p[1][j], acc[rt]);
+    acc[rt] = X3_MFMA(a[cur][1], w.p[0][j], acc[rt]);
+    acc[rt] = X3_MFMA(a[cur][0], w.p[0][j], acc[rt]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
