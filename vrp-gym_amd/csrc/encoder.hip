@@ -2339,36 +2339,36 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     norms = norm_s;
   }
   __syncthreads();
-  // the layer input in this lane's accumulator layout (row = 16 rt + 4 q + r, column c): kept in
-  // registers as the residual, and split into the A-operand planes
-  float xres[RT16][4];
+  // the layer input in this lane's accumulator layout (row = 16 rt + i16, columns cq .. cq + 3):
+  // kept in registers as the residual, and split into the A-operand planes
+  const int cq = wave * 16 + 4 * q;
+  float4 xres[RT16];
 #pragma unroll
-  for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rt * 16 + 4 * q + r;
-      xres[rt][r] = stage[row * EB_LD + c];
-      x3_store(XB3, PE, row, c, xres[rt][r]);
-    }
+  for (int rt = 0; rt < RT16; ++rt) {
+    const int row = rt * 16 + i16;
+    xres[rt] = x3_ld4(stage + row * EB_LD + cq);
+    x3_store4v(XB3, PE, row, cq, xres[rt]);
+  }
   __syncthreads();
   f32x4v acc[RT16], gacc[RT16];
   auto zero = [&](f32x4v (&a)[RT16]) {
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) a[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   };
+  // fragment buffers: fa = in_proj tiles 0 / 2, ff.0 slices; fb = in_proj tile 1, out_proj, ff.2 slices
   for (int l = 0; l < w.num_layers; ++l) {
     const vrp_encoder_layer &L = w.layer[l];
     const __bf16 *lf = split + (size_t)l * per_layer * X3_FRAG;
     // ---- in_proj: three 16-column tiles of this wave's 48-column block -> q | k | v (fp32) ----
     auto proj_tile = [&](int ct, const Frag3 &f) {
-      const int col = wave * 48 + ct * 16 + i16;
-      const float bb = L.in_proj_bias[col];
+      const int col0 = wave * 48 + ct * 16 + 4 * q;
+      const float4 bb = x3_ld4(L.in_proj_bias + col0);
       zero(acc);
       x3_mma<RT16>(acc, XB3, PE, f, lane);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[rt][r] + bb;
+        *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + col0) =
+            make_float4(acc[rt][0] + bb.x, acc[rt][1] + bb.y, acc[rt][2] + bb.z, acc[rt][3] + bb.w);
     };
     x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
     proj_tile(0, fa);
@@ -2388,55 +2388,66 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     // ---- y1 = BN1(x + att Wo^T + bo) -----------------------------------------------------------
     {
       const float *n1 = norms + (2 * l) * 384;
-      const float bb = L.out_proj_bias[c], mean = n1[c], mult = n1[128 + c], beta = n1[256 + c];
+      const float4 bb = x3_ld4(L.out_proj_bias + cq), mean = x3_ld4(n1 + cq),
+                   mult = x3_ld4(n1 + 128 + cq), beta = x3_ld4(n1 + 256 + cq);
       zero(acc);
       x3_mma<RT16>(acc, AT3, PE, fb, lane);
+      x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
-      for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          xres[rt][r] = (acc[rt][r] + bb + xres[rt][r] - mean) * mult + beta;
-          x3_store(XB3, PE, rt * 16 + 4 * q + r, c, xres[rt][r]);
-        }
+      for (int rt = 0; rt < RT16; ++rt) {
+        xres[rt].x = (acc[rt][0] + bb.x + xres[rt].x - mean.x) * mult.x + beta.x;
+        xres[rt].y = (acc[rt][1] + bb.y + xres[rt].y - mean.y) * mult.y + beta.y;
+        xres[rt].z = (acc[rt][2] + bb.z + xres[rt].z - mean.z) * mult.z + beta.z;
+        xres[rt].w = (acc[rt][3] + bb.w + xres[rt].w - mean.w) * mult.w + beta.w;
+        x3_store4v(XB3, PE, rt * 16 + i16, cq, xres[rt]);
+      }
     }
     __syncthreads();
     // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T ----------------------
-    auto slice_up = [&](int ch, const Frag3 &f, __bf16 *hb) {
-      const float bb = L.ff0_bias[ch * 128 + c];
-      zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, f, lane);
-#pragma unroll
-      for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          x3_store(hb, PE, rt * 16 + 4 * q + r, c, fmaxf(acc[rt][r] + bb, 0.f));
+    // Slice ch + 1 goes up (MFMAs) BEFORE slice ch comes down: its epilogue -- ReLU, split, plane
+    // stores -- is then issued between the MFMAs of the way down.
+    auto up_store = [&](int rt, const float4 &b1v, __bf16 *hb) {
+      x3_store4(hb, PE, rt * 16 + i16, cq, fmaxf(acc[rt][0] + b1v.x, 0.f), fmaxf(acc[rt][1] + b1v.y, 0.f),
+                fmaxf(acc[rt][2] + b1v.z, 0.f), fmaxf(acc[rt][3] + b1v.w, 0.f));
     };
     zero(gacc);
-    x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
-    slice_up(0, fa, AT3);
+    {
+      const float4 b1v = x3_ld4(L.ff0_bias + cq);
+      zero(acc);
+      x3_mma<RT16>(acc, XB3, PE, fa, lane);
+      if (nchunk > 1) x3_load_frag(fa, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, AT3);
+    }
     __syncthreads();
     for (int ch = 0; ch + 1 < nchunk; ++ch) {
       __bf16 *hcur = (ch & 1) ? H1 : AT3, *hnext = (ch & 1) ? AT3 : H1;
-      x3_load_frag(fa, lf + (size_t)x3_frag_w1((ch + 1) * 8 + wave) * X3_FRAG, lane);
-      x3_mma<RT16>(gacc, hcur, PE, fb, lane);
+      const float4 b1v = x3_ld4(L.ff0_bias + (ch + 1) * 128 + cq);
+      zero(acc);
+      x3_mma<RT16>(acc, XB3, PE, fa, lane);                                   // up: slice ch + 1
+      if (ch + 2 < nchunk) x3_load_frag(fa, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      x3_mma<RT16>(gacc, hcur, PE, fb, lane, [&](int it) {                    // down: slice ch
+        if (it < RT16) up_store(it, b1v, hnext);
+      });
       x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
-      slice_up(ch + 1, fa, hnext);
       __syncthreads();
     }
     {
       const float *n2 = norms + (2 * l + 1) * 384;
-      const float bb = L.ff2_bias[c], mean = n2[c], mult = n2[128 + c], beta = n2[256 + c];
+      const float4 bb = x3_ld4(L.ff2_bias + cq), mean = x3_ld4(n2 + cq),
+                   mult = x3_ld4(n2 + 128 + cq), beta = x3_ld4(n2 + 256 + cq);
       if (l + 1 < w.num_layers)
         x3_load_frag(fa, lf + (size_t)(per_layer + x3_frag_win(wave * 3)) * X3_FRAG, lane);
       x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, fb, lane);
       // ---- y = BN2(y1 + g + b2): the next layer's input ----------------------------------------
 #pragma unroll
-      for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          xres[rt][r] = (gacc[rt][r] + bb + xres[rt][r] - mean) * mult + beta;
-          if (l + 1 < w.num_layers) x3_store(XB3, PE, rt * 16 + 4 * q + r, c, xres[rt][r]);
-        }
+      for (int rt = 0; rt < RT16; ++rt) {
+        xres[rt].x = (gacc[rt][0] + bb.x + xres[rt].x - mean.x) * mult.x + beta.x;
+        xres[rt].y = (gacc[rt][1] + bb.y + xres[rt].y - mean.y) * mult.y + beta.y;
+        xres[rt].z = (gacc[rt][2] + bb.z + xres[rt].z - mean.z) * mult.z + beta.z;
+        xres[rt].w = (gacc[rt][3] + bb.w + xres[rt].w - mean.w) * mult.w + beta.w;
+        if (l + 1 < w.num_layers) x3_store4v(XB3, PE, rt * 16 + i16, cq, xres[rt]);
+      }
     }
     __syncthreads();
   }
@@ -2444,8 +2455,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   // constants on the way
 #pragma unroll
   for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) stage[(rt * 16 + 4 * q + r) * EB_LD + c] = xres[rt][r];
+    *reinterpret_cast<float4 *>(stage + (rt * 16 + i16) * EB_LD + cq) = xres[rt];
   __syncthreads();
   for (int idx = tid; idx < rows * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
@@ -2533,7 +2543,7 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int c = wave * 16 + i16;
+  const int cq = wave * 16 + 4 * q;                  // this lane's four output columns
   const int nchunk = hidden / 128;
   float4 pa[PF];
   auto fetch_att = [&](int tile) {
@@ -2549,21 +2559,21 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
-      x3_store4(dst, PE, r, c4, pa[u].x, pa[u].y, pa[u].z, pa[u].w);
+      x3_store4v(dst, PE, r, c4, pa[u]);
     }
   };
-  const float bb_o = bo[c], mean1 = norm1[c], mult1 = norm1[128 + c], beta1 = norm1[256 + c];
-  const float bb_2 = b2[c], mean2 = norm2[c], mult2 = norm2[128 + c], beta2 = norm2[256 + c];
+  const float4 bb_o = x3_ld4(bo + cq), mean1 = x3_ld4(norm1 + cq), mult1 = x3_ld4(norm1 + 128 + cq),
+               beta1 = x3_ld4(norm1 + 256 + cq);
+  const float4 bb_2 = x3_ld4(b2 + cq), mean2 = x3_ld4(norm2 + cq), mult2 = x3_ld4(norm2 + 128 + cq),
+               beta2 = x3_ld4(norm2 + 256 + cq);
   int tile = blockIdx.x;
   __bf16 *abuf = hb0, *other = hb1;
   if (tile < ntiles) { fetch_att(tile); store_att(abuf); }
+  // fragment buffers: fa = out_proj and the ff.2 slices, fb = the ff.0 slices
   Frag3 fa, fb;
   x3_load_frag(fa, lf_ + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
+  x3_load_frag(fb, lf_ + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);
   __syncthreads();
-  // one tile; fa holds the Wo fragment on entry (nine stages: the next tile's arrives in fb and
-  // is moved over, 48 register moves per tile)
-#define FA fa
-#define FB fb
   while (tile < ntiles) {
     // (the weights do not change from tile to tile; an opaque zero keeps the compiler from
     // hoisting the nine fragment loads out of this loop into registers it does not have)
@@ -2571,78 +2581,80 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     const __bf16 *lf = lf_ + zero;
     const int row0 = tile * RTW, valid = rows - row0;
-    float xr[RT16][4];
+    // the residual rows in this lane's accumulator layout: row 16 rt + i16, columns cq .. cq + 3
+    float4 xr[RT16];
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * q + r;
-        xr[rt][r] = row < valid ? x[(size_t)(row0 + row) * 128 + c] : 0.f;
-      }
+    for (int rt = 0; rt < RT16; ++rt) {
+      const int row = rt * 16 + i16;
+      xr[rt] = row < valid ? x3_ld4(x + (size_t)(row0 + row) * 128 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     f32x4v acc[RT16], gacc[RT16];
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) { acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; gacc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     // ---- y1 = BN1(x + att Wo^T + bo) ----------------------------------------------------------
-    x3_load_frag(FB, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);
-    x3_mma<RT16>(acc, abuf, PE, FA, lane);
+    x3_mma<RT16>(acc, abuf, PE, fa, lane);
+    x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        xr[rt][r] = (acc[rt][r] + bb_o + xr[rt][r] - mean1) * mult1 + beta1;
-        x3_store(XB3, PE, rt * 16 + 4 * q + r, c, xr[rt][r]);
-        if (r == 3) __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int rt = 0; rt < RT16; ++rt) {
+      xr[rt].x = (acc[rt][0] + bb_o.x + xr[rt].x - mean1.x) * mult1.x + beta1.x;
+      xr[rt].y = (acc[rt][1] + bb_o.y + xr[rt].y - mean1.y) * mult1.y + beta1.y;
+      xr[rt].z = (acc[rt][2] + bb_o.z + xr[rt].z - mean1.z) * mult1.z + beta1.z;
+      xr[rt].w = (acc[rt][3] + bb_o.w + xr[rt].w - mean1.w) * mult1.w + beta1.w;
+      x3_store4v(XB3, PE, rt * 16 + i16, cq, xr[rt]);
+    }
     __syncthreads();
-    // ---- hidden slices: up (y1 -> slice planes in LDS), down (slice -> g in registers) ---------
-    auto slice_up = [&](int ch, const Frag3 &f, __bf16 *hb) {
-      const float bb = b1[ch * 128 + c];
+    // ---- hidden slices: slice ch + 1 goes up BEFORE slice ch comes down; its epilogue (ReLU,
+    // split, plane stores) is issued between the MFMAs of the way down --------------------------
+    auto up_store = [&](int rt, const float4 &b1v, __bf16 *hb) {
+      x3_store4(hb, PE, rt * 16 + i16, cq, fmaxf(acc[rt][0] + b1v.x, 0.f), fmaxf(acc[rt][1] + b1v.y, 0.f),
+                fmaxf(acc[rt][2] + b1v.z, 0.f), fmaxf(acc[rt][3] + b1v.w, 0.f));
+    };
+    {
+      const float4 b1v = x3_ld4(b1 + cq);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      x3_mma<RT16>(acc, XB3, PE, f, lane);
+      x3_mma<RT16>(acc, XB3, PE, fb, lane);
+      if (nchunk > 1) x3_load_frag(fb, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
 #pragma unroll
-      for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-          x3_store(hb, PE, rt * 16 + 4 * q + r, c, fmaxf(acc[rt][r] + bb, 0.f));
-          if (r == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    x3_load_frag(FA, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
-    slice_up(0, FB, abuf);     // the attention rows are dead by now
+      for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, abuf);   // the attention rows are dead by now
+    }
     __syncthreads();
     for (int ch = 0; ch + 1 < nchunk; ++ch) {
       __bf16 *hcur = (ch & 1) ? other : abuf, *hnext = (ch & 1) ? abuf : other;
-      x3_load_frag(FB, lf + (size_t)x3_frag_w1((ch + 1) * 8 + wave) * X3_FRAG, lane);
-      x3_mma<RT16>(gacc, hcur, PE, FA, lane);
-      x3_load_frag(FA, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
-      slice_up(ch + 1, FB, hnext);
+      const float4 b1v = x3_ld4(b1 + (ch + 1) * 128 + cq);
+#pragma unroll
+      for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      x3_mma<RT16>(acc, XB3, PE, fb, lane);                                   // up: slice ch + 1
+      if (ch + 2 < nchunk) x3_load_frag(fb, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      x3_mma<RT16>(gacc, hcur, PE, fa, lane, [&](int it) {                    // down: slice ch
+        if (it < RT16) up_store(it, b1v, hnext);
+      });
+      x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
       __syncthreads();
     }
     // last way down; the next tile's attention rows travel behind it into the free buffer
     __bf16 *hlast = ((nchunk - 1) & 1) ? other : abuf, *hfree = ((nchunk - 1) & 1) ? abuf : other;
     const int next = tile + gridDim.x;
     if (next < ntiles) fetch_att(next);
-    x3_load_frag(FB, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);   // Wo for the next tile
-    x3_mma<RT16>(gacc, hlast, PE, FA, lane);
+    x3_load_frag(fb, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // ff.0 slice 0 of the next tile
+    x3_mma<RT16>(gacc, hlast, PE, fa, lane);
+    x3_load_frag(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);   // Wo of the next tile
     if (next < ntiles) store_att(hfree);
     // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
 #pragma unroll
-    for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * q + r;
-        if (row < valid)
-          y[(size_t)(row0 + row) * 128 + c] = (gacc[rt][r] + bb_2 + xr[rt][r] - mean2) * mult2 + beta2;
-      }
+    for (int rt = 0; rt < RT16; ++rt) {
+      const int row = rt * 16 + i16;
+      if (row < valid)
+        *reinterpret_cast<float4 *>(y + (size_t)(row0 + row) * 128 + cq) =
+            make_float4((gacc[rt][0] + bb_2.x + xr[rt].x - mean2.x) * mult2.x + beta2.x,
+                        (gacc[rt][1] + bb_2.y + xr[rt].y - mean2.y) * mult2.y + beta2.y,
+                        (gacc[rt][2] + bb_2.z + xr[rt].z - mean2.z) * mult2.z + beta2.z,
+                        (gacc[rt][3] + bb_2.w + xr[rt].w - mean2.w) * mult2.w + beta2.w);
+    }
     __syncthreads();   // next tile's attention rows complete, XB3 and hlast free
     abuf = hfree; other = hlast;
     tile = next;
-    fa = fb;
   }
-#undef FA
-#undef FB
 }
 
 template <int RT16>
@@ -2701,11 +2713,13 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
       if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
     }
   };
-  float bb[3];
+  float4 bb[3];
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) bb[ct] = bin[wave * 48 + ct * 16 + i16];
+  for (int ct = 0; ct < 3; ++ct) bb[ct] = x3_ld4(bin + wave * 48 + ct * 16 + 4 * q);
+  // fragment buffers: fb holds column tile 1 for good, fa alternates between tiles 0 and 2
   Frag3 fa, fb;
   x3_load_frag(fa, lf_ + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);
+  x3_load_frag(fb, lf_ + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
   int tile = blockIdx.x;
   if (tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += gridDim.x) {
@@ -2717,7 +2731,7 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
-      x3_store4(X3, PE, r, c4, pf[u].x, pf[u].y, pf[u].z, pf[u].w);
+      x3_store4v(X3, PE, r, c4, pf[u]);
     }
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
@@ -2726,21 +2740,20 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) acc[ct][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
     x3_mma<RT16>(acc[0], X3, PE, fa, lane);
     x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
     x3_mma<RT16>(acc[1], X3, PE, fb, lane);
-    x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);   // the next tile's first
     x3_mma<RT16>(acc[2], X3, PE, fa, lane);
-    fa = fb;
+    x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);   // the next tile's first
     __syncthreads();   // every wave is done with the input planes: q|k|v may overlay them
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
-      const int col = wave * 48 + ct * 16 + i16;
+      const int col0 = wave * 48 + ct * 16 + 4 * q;
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Q_s[(rt * 16 + 4 * q + r) * QA_QLD + col] = acc[ct][rt][r] + bb[ct];
+        *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + col0) =
+            make_float4(acc[ct][rt][0] + bb[ct].x, acc[ct][rt][1] + bb[ct].y,
+                        acc[ct][rt][2] + bb[ct].z, acc[ct][rt][3] + bb[ct].w);
     }
     __syncthreads();
     float *o = att + (size_t)g0 * N * VRP_EMB;

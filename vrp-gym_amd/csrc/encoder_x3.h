@@ -16,7 +16,10 @@
 //     a lane's operand of one MFMA is 16 contiguous bytes, a wave's load 1 KB = eight whole lines;
 //   * activations are split by their PRODUCER -- the epilogue lane that owns the accumulator
 //     element -- and live in LDS as three bf16 planes; the eight consumer waves of a tile read
-//     ready-made operands (one ds_read_b128 per plane and k-chunk), nobody splits twice.
+//     ready-made operands (one ds_read_b128 per plane and k-chunk), nobody splits twice;
+//   * the weights are the MFMA's FIRST operand, so an epilogue lane owns four consecutive columns
+//     of one row (8-byte plane stores, 16-byte fp32 accesses), and the epilogue of a stage is
+//     issued in slices between the MFMAs of the next one (x3_mma's `fill`).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -65,16 +68,23 @@ __device__ __forceinline__ void x3_load_frag(Frag3 &f, const __bf16 *__restrict_
 }
 
 #define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-// acc[rt] (16 rows x 16 columns, D: row = 4 (lane >> 4) + r, column = lane & 15) +=
-// A(rows 16 rt .., 128 k; LDS planes) W^T(fragment).  Small terms first, h h' last.
-template <int RT16>
+struct X3NoFill { __device__ __forceinline__ void operator()(int) const {} };
+// acc[rt] += W(fragment: 16 output columns) A(rows 16 rt .., 128 k; LDS planes)^T, the WEIGHTS as the
+// first operand: D[column][row] puts an activation row on the lane (row = 16 rt + (lane & 15)) and
+// FOUR CONSECUTIVE output columns 4 (lane >> 4) + e in its registers -- an epilogue converts and
+// stores 8-byte pieces per plane (and 16-byte fp32 pieces to global memory) instead of single
+// elements.  Small terms first, h h' last.  `fill(it)` runs ahead of the MFMAs of item `it`
+// (= chunk it / RT16, row tile it % RT16) inside the same scheduling region: the callers hand the
+// previous stage's epilogue over in RT16 slices, so that its VALU / LDS work issues in the
+// shadow of these MFMAs (the two waves of a SIMD run the same stage at the same time: an epilogue
+// after the last MFMA would find the matrix pipe idle).
+template <int RT16, typename Fill = X3NoFill>
 __device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, int plane_elems,
-                                       const Frag3 &w, int lane) {
+                                       const Frag3 &w, int lane, Fill fill = Fill()) {
   const int i16 = lane & 15, q = lane >> 4;
   const __bf16 *ap = tile + i16 * X3_PITCH + 8 * q;
-  // the operands of (chunk j, row tile rt) are read while the MFMAs of the item before run:
-  // two operand sets alive at a time, not 4 x RT16 (the scheduling fences keep the compiler
-  // from hoisting every LDS read of the stage to its top)
+  // the operands of item it + 1 are read while the MFMAs of item it run: two operand sets alive
+  // (the scheduling fences keep the compiler from hoisting every LDS read of the stage to its top)
   bf16x8 a[2][3];
   auto rd = [&](bf16x8 (&d)[3], int it) {
     const int j = it / RT16, rt = it - j * RT16;
@@ -88,14 +98,20 @@ __device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, 
     const int j = it / RT16, rt = it - j * RT16, cur = it & 1;
     if (it + 1 < 4 * RT16) rd(a[cur ^ 1], it + 1);
     __builtin_amdgcn_sched_barrier(0);
-    acc[rt] = X3_MFMA(a[cur][1], w.p[1][j], acc[rt]);
-    acc[rt] = X3_MFMA(a[cur][0], w.p[2][j], acc[rt]);
-    acc[rt] = X3_MFMA(a[cur][2], w.p[0][j], acc[rt]);
-    acc[rt] = X3_MFMA(a[cur][0], w.p[1][j], acc[rt]);
-    acc[rt] = X3_MFMA(a[cur][1], w.p[0][j], acc[rt]);
-    acc[rt] = X3_MFMA(a[cur][0], w.p[0][j], acc[rt]);
+    fill(it);
+    acc[rt] = X3_MFMA(w.p[1][j], a[cur][1], acc[rt]);
+    acc[rt] = X3_MFMA(w.p[2][j], a[cur][0], acc[rt]);
+    acc[rt] = X3_MFMA(w.p[0][j], a[cur][2], acc[rt]);
+    acc[rt] = X3_MFMA(w.p[1][j], a[cur][0], acc[rt]);
+    acc[rt] = X3_MFMA(w.p[0][j], a[cur][1], acc[rt]);
+    acc[rt] = X3_MFMA(w.p[0][j], a[cur][0], acc[rt]);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+// the lane's four columns as one value
+__device__ __forceinline__ float4 x3_ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void x3_store4v(__bf16 *tile, int plane_elems, int row, int col, const float4 &v) {
+  x3_store4(tile, plane_elems, row, col, v.x, v.y, v.z, v.w);
 }
 
 // ---- the split weights of one encoder (vrp_encoder_prepare) ------------------------------------
