@@ -2490,8 +2490,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   }
 }
 
-// the x3 stack kernel: pre-split weights present, at most three layers (LDS: 2 x 38 KB of operand
-// planes + 73 KB q|k|v + the BN affines = 158 KB of the 160), VRP_ENCODER_FP32=1 = A/B aid
+// the x3 stack kernel: pre-split weights present, at most five layers (LDS: 2 x 36 KB of operand
+// planes + 73 KB q|k|v + 3 KB of BN affines per layer <= 160 KB), VRP_ENCODER_FP32=1 = A/B aid
 static bool encoder_x3_enabled(const vrp_encoder_weights *w) {
   static const bool off = getenv("VRP_ENCODER_FP32") != nullptr;
   return !off && w->split != nullptr;
@@ -2519,7 +2519,7 @@ static int launch_encoder_stack_x3(const vrp_encoder_weights *w, const float *x,
   return 0;
 }
 static bool encoder_stack_x3_applies(const vrp_encoder_weights *w) {
-  return encoder_x3_enabled(w) && w->num_layers <= 3;
+  return encoder_x3_enabled(w) && w->num_layers <= 5;
 }
 
 // ---- out-proj + BN1 + FF + BN2 for LARGE row counts on the bf16 matrix cores -----------------
