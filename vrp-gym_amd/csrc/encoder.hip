@@ -2211,26 +2211,8 @@ __global__ __launch_bounds__(512) void encoder_stack_kernel(vrp_encoder_weights 
   ST_MARK(ST_SLOTS - 1);
 }
 
-template <int RT16>
-static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, const float *norms,
-                                float *y, int B, int N, const StackSetup &su, const StackEpilogue &ep,
-                                hipStream_t st) {
-  constexpr int RTW = 16 * RT16;
-  const size_t lds = ((size_t)RTW * (2 * EB_LD + QA_QLD) + 16 * 384) * sizeof(float);
-  static VrpAttrOnce attr_set;
-  if (!attr_set.done() && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_stack_kernel<RT16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      vrp_set_error("encoder_stack: cannot raise dynamic LDS to %zu bytes", lds);
-      return 1;
-    }
-    attr_set.mark();
-  }
-  const int G = RTW / N;
-  hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
-                     norms, y, B, N, G, su, ep);
-  VRP_CHECK_LAUNCH("encoder_stack");
 #ifdef VRP_STACK_TRACE
+static void stack_trace_dump() {
   {
     static int calls = 0;
     if (++calls == 8) {   // a warm launch
@@ -2259,6 +2241,30 @@ static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, co
       }
     }
   }
+}
+#endif
+
+template <int RT16>
+static int launch_encoder_stack(const vrp_encoder_weights *w, const float *x, const float *norms,
+                                float *y, int B, int N, const StackSetup &su, const StackEpilogue &ep,
+                                hipStream_t st) {
+  constexpr int RTW = 16 * RT16;
+  const size_t lds = ((size_t)RTW * (2 * EB_LD + QA_QLD) + 16 * 384) * sizeof(float);
+  static VrpAttrOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&encoder_stack_kernel<RT16>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      vrp_set_error("encoder_stack: cannot raise dynamic LDS to %zu bytes", lds);
+      return 1;
+    }
+    attr_set.mark();
+  }
+  const int G = RTW / N;
+  hipLaunchKernelGGL(encoder_stack_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
+                     norms, y, B, N, G, su, ep);
+  VRP_CHECK_LAUNCH("encoder_stack");
+#ifdef VRP_STACK_TRACE
+  stack_trace_dump();
 #endif
   return 0;
 }
@@ -2299,6 +2305,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   const int rows = graphs * N;
   const size_t row0 = (size_t)g0 * N;
   const float *norms = norms_in;
+  ST_MARK(0);
+  ST_MARK(1);
   const int hidden = w.hidden, nchunk = hidden / 128, per_layer = x3_layer_frags(hidden);
   const __bf16 *split = reinterpret_cast<const __bf16 *>(w.split);
   Frag3 fa, fb;
@@ -2349,6 +2357,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     xres[rt] = x3_ld4(stage + row * EB_LD + cq);
     x3_store4v(XB3, PE, row, cq, xres[rt]);
   }
+  ST_MARK(2);
   __syncthreads();
   f32x4v acc[RT16], gacc[RT16];
   auto zero = [&](f32x4v (&a)[RT16]) {
@@ -2359,6 +2368,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   for (int l = 0; l < w.num_layers; ++l) {
     const vrp_encoder_layer &L = w.layer[l];
     const __bf16 *lf = split + (size_t)l * per_layer * X3_FRAG;
+    ST_MARK(4 + 24 * l);
     // ---- in_proj: three 16-column tiles of this wave's 48-column block -> q | k | v (fp32) ----
     auto proj_tile = [&](int ct, const Frag3 &f) {
       const int col0 = wave * 48 + ct * 16 + 4 * q;
@@ -2377,14 +2387,18 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     x3_load_frag(fb, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
     proj_tile(2, fa);
     x3_load_frag(fa, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // arrives during the attention
+    ST_MARK(4 + 24 * l + 1);
     __syncthreads();
+    ST_MARK(4 + 24 * l + 2);
     {
       const AttSinkX3 sink{AT3, PE};
       if (N <= 16) qa8_stage_attention_mfma_to<1>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
       else if (N <= 32) qa8_stage_attention_mfma_to<2>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
       else qa8_stage_attention_mfma_to<3>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
     }
+    ST_MARK(4 + 24 * l + 3);
     __syncthreads();
+    ST_MARK(4 + 24 * l + 4);
     // ---- y1 = BN1(x + att Wo^T + bo) -----------------------------------------------------------
     {
       const float *n1 = norms + (2 * l) * 384;
@@ -2402,7 +2416,9 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
         x3_store4v(XB3, PE, rt * 16 + i16, cq, xres[rt]);
       }
     }
+    ST_MARK(4 + 24 * l + 5);
     __syncthreads();
+    ST_MARK(4 + 24 * l + 6);
     // ---- g = sum over 128-wide hidden slices of relu(y1 W1c^T + b1c) W2c^T ----------------------
     // Slice ch + 1 goes up (MFMAs) BEFORE slice ch comes down: its epilogue -- ReLU, split, plane
     // stores -- is then issued between the MFMAs of the way down.
@@ -2419,19 +2435,25 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, AT3);
     }
+    ST_MARK(4 + 24 * l + 7);
     __syncthreads();
+    ST_MARK(4 + 24 * l + 8);
     for (int ch = 0; ch + 1 < nchunk; ++ch) {
       __bf16 *hcur = (ch & 1) ? H1 : AT3, *hnext = (ch & 1) ? AT3 : H1;
       const float4 b1v = x3_ld4(L.ff0_bias + (ch + 1) * 128 + cq);
       zero(acc);
       x3_mma<RT16>(acc, XB3, PE, fa, lane);                                   // up: slice ch + 1
       if (ch + 2 < nchunk) x3_load_frag(fa, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      ST_MARK(4 + 24 * l + 9 + 3 * ch);
       x3_mma<RT16>(gacc, hcur, PE, fb, lane, [&](int it) {                    // down: slice ch
         if (it < RT16) up_store(it, b1v, hnext);
       });
       x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      ST_MARK(4 + 24 * l + 10 + 3 * ch);
       __syncthreads();
+      ST_MARK(4 + 24 * l + 11 + 3 * ch);
     }
+    ST_MARK(4 + 24 * l + 17);
     {
       const float *n2 = norms + (2 * l + 1) * 384;
       const float4 bb = x3_ld4(L.ff2_bias + cq), mean = x3_ld4(n2 + cq),
@@ -2439,6 +2461,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       if (l + 1 < w.num_layers)
         x3_load_frag(fa, lf + (size_t)(per_layer + x3_frag_win(wave * 3)) * X3_FRAG, lane);
       x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, fb, lane);
+      ST_MARK(4 + 24 * l + 21);
       // ---- y = BN2(y1 + g + b2): the next layer's input ----------------------------------------
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) {
@@ -2449,8 +2472,10 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
         if (l + 1 < w.num_layers) x3_store4v(XB3, PE, rt * 16 + i16, cq, xres[rt]);
       }
     }
+    ST_MARK(4 + 24 * l + 23);
     __syncthreads();
   }
+  ST_MARK(ST_SLOTS - 3);
   // ---- result: through the fp32 staging rows, coalesced 16-byte stores; the decoder's per-graph
   // constants on the way
 #pragma unroll
@@ -2488,6 +2513,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       if (sink == 1.2345678e-30f) y[0] = sink;   // never true: the loads must not be elided
     }
   }
+  ST_MARK(ST_SLOTS - 2);
+  ST_MARK(ST_SLOTS - 1);
 }
 
 // the x3 stack kernel: pre-split weights present, at most five layers (LDS: 2 x 36 KB of operand
@@ -2516,6 +2543,9 @@ static int launch_encoder_stack_x3(const vrp_encoder_weights *w, const float *x,
   hipLaunchKernelGGL(encoder_stack_x3_kernel<RT16>, dim3((B + G - 1) / G), dim3(512), lds, st, *w, x,
                      norms, y, B, N, G, su, ep);
   VRP_CHECK_LAUNCH("encoder_stack_x3");
+#ifdef VRP_STACK_TRACE
+  stack_trace_dump();
+#endif
   return 0;
 }
 static bool encoder_stack_x3_applies(const vrp_encoder_weights *w) {
