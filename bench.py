@@ -436,11 +436,13 @@ def step_kernel_roofline(kind, N, B, greedy, device, reps=5, extra_flags=0, per_
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md; = vector peak)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same table): 16 x the fp32 MFMA rate
 
 
 def encoder_roofline(kind, N, B, device, reps=20):
     """The encoder phase of the rollout (vrp_rollout_encode: set-up + all layers; ONE launch,
-    encoder_stack_kernel<3>, for small eval-mode batches) against the fp32 MFMA peak.
+    encoder_stack_x3_kernel<3>, for small eval-mode batches) against the matrix-core ceiling of
+    its arithmetic (see below; the fp32 MFMA peak for the fp32 kernels, VRP_ENCODER_FP32=1).
     Flops = B*N*(1 180 160 + 1 536 N) (projections, attention, feed-forward of
     three layers); time = HIP events around the launches on the library's stream."""
     import ctypes as C
@@ -472,16 +474,37 @@ def encoder_roofline(kind, N, B, device, reps=20):
         if i >= 3:
             ts.append(e0.elapsed_time(e1) * 1e-3)
     avg = float(np.mean(ts))
-    flops = B * N * (1180160 + 1536 * N)
+    dense, attn = B * N * 1180160, B * N * 1536 * N
+    flops = dense + attn
     name = lib.vrp_encoder_kernel_name(C.byref(ew), 0, B, N)
-    return {"bound": "mfma", "kernel": name.decode() if name else "?",
-            "workload": f"kind{kind}_N{N}_B{B}", "achieved": round(flops / avg / 1e12, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / avg / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(avg * 1e6, 2),
-            "timer": "HIP events around vrp_rollout_encode (one launch for small eval-mode "
-                     "batches; the per-layer kernels otherwise)",
-            "launches_timed": reps}
+    name = name.decode() if name else "?"
+    out = {"bound": "mfma", "kernel": name, "workload": f"kind{kind}_N{N}_B{B}",
+           "achieved": round(flops / avg / 1e12, 2), "unit": "TFLOP/s", "traffic": None,
+           "algorithmic_flops_per_launch": flops, "avg_launch_us": round(avg * 1e6, 2),
+           "timer": "HIP events around vrp_rollout_encode (one launch for small eval-mode "
+                    "batches; the per-layer kernels otherwise)",
+           "launches_timed": reps}
+    if "_x3" in name:
+        # Round 5: the dense products (projections, feed-forward: 1 180 160 of the flops per row)
+        # run as SIX bf16 MFMAs per fp32 product on three-plane operands (csrc/encoder_x3.h), the
+        # attention (1 536 N per row, K = 16 per head) on the fp32 MFMA.  The ceiling of that mix,
+        # in algorithmic (fp32-equivalent) flops: dense at 2 500 / 6 TFLOP/s + attention at 157.3.
+        bound_s = 6.0 * dense / (MFMA_BF16_PEAK_TFLOPS * 1e12) + attn / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        peak = flops / bound_s / 1e12
+        out.update({
+            "peak": round(peak, 1), "frac": round(flops / avg / 1e12 / peak, 4),
+            "arithmetic": "fp32 operands as three bf16 planes, six v_mfma_f32_16x16x32_bf16 per "
+                          "product, fp32 accumulation (error = that of the fp32 MFMA: "
+                          "profiles/r05_bf16x3_probe.txt); attention on v_mfma_f32_16x16x4_f32",
+            "peak_is": "algorithmic flops / (6 x dense flops / 2500 TFLOP/s bf16 + attention flops "
+                       "/ 157.3 TFLOP/s fp32)",
+            "issued_bf16_mfma_tflops": round(6.0 * dense / avg / 1e12, 1),
+            "bf16_mfma_peak": MFMA_BF16_PEAK_TFLOPS,
+            "vs_fp32_mfma_peak": round(flops / avg / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
+    else:
+        out.update({"peak": MFMA_F32_PEAK_TFLOPS,
+                    "frac": round(flops / avg / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)})
+    return out
 
 
 def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
@@ -737,6 +760,12 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": r["ms_per_step"], "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "fp32 results throughout (tour cost / log-prob within 1e-5 of the reference's "
+                      "CPU fp32 path; env bookkeeping fp64 / integer, bit-exact).  The eval-mode "
+                      "encoder's and the decoder prologue's dense products run on the bf16 matrix "
+                      "cores with every fp32 operand carried as three bf16 planes (six MFMAs per "
+                      "product, fp32 accumulation): measured error equal to the fp32 MFMA's "
+                      "(profiles/r05_bf16x3_probe.txt), same parity tests, same tolerances",
         "data": "synthetic" + (" (instances drawn on the device, Philox stream, reference "
                                "distributions)" if mode == "train" else
                                " (reference-exact numpy-stream instances, resident in HBM)"),

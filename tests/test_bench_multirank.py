@@ -175,8 +175,12 @@ def test_bench_single_rank_line_has_contract_keys():
     r = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "kernel"):
         assert k in r, k
-    assert r["bound"] == "mfma" and r["kernel"] == "encoder_stack_kernel<3>" and r["unit"] == "TFLOP/s"
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] == "mfma" and r["kernel"] == "encoder_stack_x3_kernel<3>" and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    # six bf16 MFMAs per fp32 product: the ceiling is priced on the bf16 matrix peak, and the
+    # fraction can never exceed 1 (the figure against the fp32 MFMA peak is reported beside it)
+    assert 157.3 < r["peak"] <= 2500.0 / 6 + 0.1 and 0 < r["frac"] < 1
+    assert abs(r["issued_bf16_mfma_tflops"] / r["bf16_mfma_peak"] - r["frac"]) < 0.05
     assert r == {**out["roofline_encoder"], "share_of_rollout": r["share_of_rollout"]}
     r = out["roofline_step"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",

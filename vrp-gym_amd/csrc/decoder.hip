@@ -24,6 +24,7 @@
 //     head h of graph b reads mask row (8b+h) mod B (graph_decoder.py:93-94).
 #include <stdlib.h>
 #include "decoder_step.h"
+#include "x3_common.h"
 
 // ------------------------------------------------------------------ derived weights
 extern "C" int64_t vrp_decoder_derived_bytes(void) { return (int64_t)sizeof(float) * derived_floats(); }
@@ -113,6 +114,29 @@ __global__ __launch_bounds__(256) void pack_fold_weights_kernel(const float *__r
   }
 }
 
+// Wproj = [Wq_last | Wk | M^T | Wv] (1536,128) as three bf16 planes in the fragment order of the
+// fused prologue's stage 1 (decoder_ws.h: WprojX3).  One thread per (fragment, chunk, lane).
+__global__ __launch_bounds__(256) void pack_proj_x3_kernel(const float *__restrict__ Wproj,
+                                                           __bf16 *__restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // 96 fragments x 4 chunks x 64 lanes
+  if (idx >= 96 * 256) return;
+  const int lane = idx & 63, j = (idx >> 6) & 3, f = idx >> 8;
+  const int c = f % 3, X = (f / 3) & 3, h = f / 12;
+  const int j16 = lane & 15, q = lane >> 4;
+  const float *src = Wproj + (size_t)(X * 384 + h * VRP_HD + 16 * c + j16) * VRP_EMB +
+                     64 * (q & 1) + 32 * (q >> 1) + 8 * j;
+  bf16x8 hp, mp, lp;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const Bf3 s = x3_split(src[e]);
+    hp[e] = s.h; mp[e] = s.m; lp[e] = s.l;
+  }
+  bf16x8 *dst = reinterpret_cast<bf16x8 *>(out + (size_t)f * X3_FRAG) + lane;
+  dst[(0 * 4 + j) * 64] = hp;
+  dst[(1 * 4 + j) * 64] = mp;
+  dst[(2 * 4 + j) * 64] = lp;
+}
+
 extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void *derived,
                                    void *stream) {
   VRP_REQUIRE(w && derived, "decoder_prepare: NULL argument");
@@ -175,6 +199,9 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   hipLaunchKernelGGL(pack_fold_weights_kernel, dim3(96), dim3(256), 0, st,
                      d.Wproj + (size_t)1152 * 128, d.M, d.WvP, d.MP);
   VRP_CHECK_LAUNCH("pack_fold_weights");
+  hipLaunchKernelGGL(pack_proj_x3_kernel, dim3(96), dim3(256), 0, st, d.Wproj,
+                     reinterpret_cast<__bf16 *>(d.WprojX3));
+  VRP_CHECK_LAUNCH("pack_proj_x3");
   return 0;
 }
 

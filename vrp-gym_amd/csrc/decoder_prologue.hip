@@ -11,6 +11,7 @@
 // ([QL | KK | KM | VV], 1536 floats per node: 2 GB at 8192 x 40) never exist in memory.
 // N > 80: projection GEMM into PROJ, then pair_tables_kernel.
 #include "decoder_ws.h"
+#include "x3_common.h"
 
 // graph embedding = mean over nodes (sum, then divide; graph_decoder.py:75-77) and
 // cvec[b][m] = e_m . mb in one launch: one workgroup per graph, threads 0..127 own an
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
 struct PrologueParams {
   int kind, B, N, G, npacks;
   const float *emb, *Wproj, *bproj, *QG, *qc0, *wload;
+  const __bf16 *WprojX3;   // Derived::WprojX3 (the X3 instances' stage-1 weights)
   float *SG, *C0, *SLD, *row0, *SL, *RT;
 };
 
@@ -86,11 +88,21 @@ struct PrologueParams {
 // (seven tiles: 392 registers otherwise, plus the stage-2 temporaries, of the 512 a lone wave of
 // a SIMD has).  Quarter qi + 1 is requested ahead of quarter qi's 48 RT_ MFMAs; both halves read
 // the rows (the second time from L2).  Same k order per accumulator.
-template <int RT_, bool VEC, bool RING = (RT_ > 5)>
+// X3 (round 5, up to five row tiles): stage 1 -- 86 % of the kernel's flops -- on the bf16 matrix
+// cores.  The head's weight slices sit in LDS as pre-split fragments (Derived::WprojX3: a wave's
+// operand read is 1 KB contiguous), the embedding rows are split once per pack in registers
+// (three planes of the 32 k-values a lane holds per row tile: chunk j = values 8 j .. 8 j + 7)
+// and reused by all twelve (projection, column tile) products: six v_mfma_f32_16x16x32_bf16 per
+// 32 k instead of eight v_mfma_f32_16x16x4_f32 at a sixteenth of the rate.  The accumulator
+// layout is the same, so stage 2 (fp32 MFMA straight from the accumulators) is untouched.
+template <int RT_, bool VEC, bool RING = (RT_ > 5), bool X3 = false>
 __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams p) {
+  static_assert(!(X3 && RING), "the x3 stage 1 serves the whole-pack (non-ring) instances");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *wl = lds;                              // [4][48][PT_LD] weight slices of this head
-  float *bl = wl + 4 * 48 * PT_LD;              // [4][48] bias slices
+  float *wl = lds;                              // [4][48][PT_LD] weight slices of this head, or
+  const __bf16 *wl3 = reinterpret_cast<const __bf16 *>(lds);   // X3: [4][3] fragments of X3_FRAG bf16
+  constexpr int WL_FLOATS = X3 ? 12 * X3_FRAG / 2 : 4 * 48 * PT_LD;
+  float *bl = wl + WL_FLOATS;                   // [4][48] bias slices
   int *rowinfo = reinterpret_cast<int *>(bl + 4 * 48);  // [80] row of a pack -> graph << 8 | node
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,11 +116,16 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
   const int first = (xcd * nsub + sub) * 4 + wave;
   const bool fold = p.kind == VRP_KIND_IRP;
 
-  for (int i = tid; i < 4 * 48 * 32; i += 256) {
-    const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
-    const float4 v = *reinterpret_cast<const float4 *>(
-        p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
-    *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
+  if constexpr (X3) {
+    const float4 *src = reinterpret_cast<const float4 *>(p.WprojX3 + (size_t)h * 12 * X3_FRAG);
+    for (int i = tid; i < 12 * X3_FRAG / 8; i += 256) reinterpret_cast<float4 *>(lds)[i] = src[i];
+  } else {
+    for (int i = tid; i < 4 * 48 * 32; i += 256) {
+      const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
+      const float4 v = *reinterpret_cast<const float4 *>(
+          p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
+      *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
+    }
   }
   if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
   if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
@@ -245,6 +262,55 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
         // quarter 0 for whoever runs stage 1 next: this pack's second half, or the next pack
         if (H == 0) load_quarter(pack, 0, 0);
         else if (pack + stride < p.npacks) load_quarter(pack + stride, 0, 0);
+      } else if constexpr (X3) {
+#pragma unroll
+        for (int Y = 0; Y < 2; ++Y)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float4 bb = *reinterpret_cast<const float4 *>(bl + (2 * H + Y) * 48 + 16 * c + 4 * q);
+#pragma unroll
+            for (int r = 0; r < RT_; ++r) acc[Y][c][r] = f32x4{bb.x, bb.y, bb.z, bb.w};
+          }
+        // k-chunk by k-chunk: the rows' 8 values of the chunk are split into planes (RT_ x 3
+        // operands alive, not 4 RT_ x 3: the fp32 rows stay for the second half), then all six
+        // (projection, column tile) products of the chunk run against them
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          bf16x8 ep[RT_][3];
+#pragma unroll
+          for (int r = 0; r < RT_; ++r) {
+            float x8[8] = {ef[r][8 * j], ef[r][8 * j + 1], ef[r][8 * j + 2], ef[r][8 * j + 3],
+                           ef[r][8 * j + 4], ef[r][8 * j + 5], ef[r][8 * j + 6], ef[r][8 * j + 7]};
+            // (opaque to the optimiser: the second half must split again, not keep the first
+            // half's 12 RT_ operand registers alive across stage 2)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(x8[e]));
+            x3_split8(x8, ep[r][0], ep[r][1], ep[r][2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int Y = 0; Y < 2; ++Y)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const bf16x8 *wf =
+                  reinterpret_cast<const bf16x8 *>(wl3 + (size_t)((2 * H + Y) * 3 + c) * X3_FRAG) + lane;
+              const bf16x8 wh = wf[(0 * 4 + j) * 64], wm = wf[(1 * 4 + j) * 64], wlo = wf[(2 * 4 + j) * 64];
+              // weights x rows, small terms first: m m', h l', l h', h m', m h', h h'
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wm, ep[r][1], acc[Y][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wh, ep[r][2], acc[Y][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wlo, ep[r][0], acc[Y][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wh, ep[r][1], acc[Y][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wm, ep[r][0], acc[Y][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wh, ep[r][0], acc[Y][c][r]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else
 #pragma unroll
       for (int Y = 0; Y < 2; ++Y)
@@ -435,25 +501,37 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
   }
 }
 
-template <int RT_, bool VEC>
-static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
-  const size_t lds = sizeof(float) * (4 * 48 * PT_LD + 4 * 48) + sizeof(int) * PT_MAXROWS;
+// VRP_PROLOGUE_FP32=1: stage 1 on the fp32 MFMA at every size (A/B aid)
+static bool prologue_x3_enabled() {
+  static const bool off = getenv("VRP_PROLOGUE_FP32") != nullptr;
+  return !off;
+}
+template <int RT_, bool VEC, bool X3>
+static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
+  const size_t lds = sizeof(float) * ((X3 ? 12 * X3_FRAG / 2 : 4 * 48 * PT_LD) + 4 * 48) + sizeof(int) * PT_MAXROWS;
   static VrpAttrOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("prologue_tables: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
     }
     attr_set.mark();
   }
-  // one workgroup per CU (100 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
+  // one workgroup per CU (100 - 150 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
   // batch has fewer packs than wave slots
   int nsub = 4;
   while (nsub > 1 && 8 * (nsub / 2) * 4 >= p.npacks) nsub /= 2;
-  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC>), dim3(64 * nsub), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>), dim3(64 * nsub), dim3(256), lds, st, p);
   VRP_CHECK_LAUNCH("prologue_tables");
   return 0;
+}
+template <int RT_, bool VEC>
+static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
+  if constexpr (RT_ <= 5) {
+    if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true>(p, st);
+  }
+  return launch_prologue_tables_as<RT_, VEC, false>(p, st);
 }
 
 template <bool VEC>
@@ -479,6 +557,7 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   p.G = G;
   p.npacks = (B + G - 1) / G;
   p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
+  p.WprojX3 = reinterpret_cast<const __bf16 *>(d.WprojX3);
   p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.SL = w.SL; p.RT = w.RT;
   return p;
 }

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include "common.h"
 
+#define VRP_WPROJ_X3_FLOATS (8 * 12 * 6144 / 2)   // 96 fragments of 6144 bf16
 struct Derived {
   float *Wproj;  // (1536,128) = [Wq_last | Wk | M^T | Wv]
   float *bproj;  // (1536)       0 | bk | 0 | bv
@@ -26,6 +27,10 @@ struct Derived {
   float *WvP;    // (384*128)  v_proj rows in MFMA fragment order: [head][k4][col tile][lane][4],
                  //            lane (i16, q) = Wv[48 head + 16 tile + i16][16 k4 + 4 q ..+3]
   float *MP;     // (128*384)  M in fragment order: [col tile][k4][lane][4] = M[16 tile + i16][16 k4 + 4 q ..+3]
+  float *WprojX3;  // Wproj once more for the fused prologue's projections on the bf16 matrix cores
+                   // (x3_common.h): [head 8][X 4][column tile 3] fragments of X3_FRAG bf16 = three
+                   // planes x four k-chunks x 64 lanes x 8; lane (j16, q), chunk j holds row
+                   // X*384 + 48 head + 16 tile + j16, k = 64 (q & 1) + 32 (q >> 1) + 8 j .. + 7
 };
 
 static inline Derived carve_derived(void *base) {
@@ -48,12 +53,13 @@ static inline Derived carve_derived(void *base) {
   d.AfT = p;   p += 1024 * 128;
   d.WvP = p;   p += 384 * 128;
   d.MP = p;    p += 128 * 384;
+  d.WprojX3 = p; p += VRP_WPROJ_X3_FLOATS;
   return d;
 }
 
 static inline int64_t derived_floats() {
   return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
-         128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384;
+         128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384 + VRP_WPROJ_X3_FLOATS;
 }
 
 // ------------------------------------------------------------------ per-episode workspace

@@ -22,8 +22,7 @@
 //     issued in slices between the MFMAs of the next one (x3_mma's `fill`).
 #pragma once
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#include "x3_common.h"
 
 // LDS image of one plane: [rows][128] bf16, 256 B per row, NO padding; the 16-byte chunk c of row r
 // sits at chunk position c ^ (r & 15).  A ds_read_b128 is served in four groups of 16 lanes
@@ -36,17 +35,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int x3_off(int row, int col) {
   return row * X3_PITCH + ((((col >> 3) ^ row) & 15) << 3) + (col & 7);
 }
-#define X3_FRAG 6144   // bf16 per weight fragment: 3 planes x 4 k-chunks x 64 lanes x 8
 
-struct Bf3 { __bf16 h, m, l; };
-__device__ __forceinline__ Bf3 x3_split(float x) {
-  Bf3 s;
-  s.h = (__bf16)x;
-  const float r1 = x - (float)s.h;
-  s.m = (__bf16)r1;
-  s.l = (__bf16)(r1 - (float)s.m);
-  return s;
-}
 // one element into the three planes of an LDS tile ([3][rows][X3_PITCH])
 __device__ __forceinline__ void x3_store(__bf16 *tile, int plane_elems, int row, int col, float v) {
   const Bf3 s = x3_split(v);
@@ -76,7 +65,6 @@ __device__ __forceinline__ void x3_load_frag(Frag3 &f, const __bf16 *__restrict_
     for (int j = 0; j < 4; ++j) f.p[p][j] = src[(p * 4 + j) * 64];
 }
 
-#define X3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 struct X3NoFill { __device__ __forceinline__ void operator()(int) const {} };
 // acc[rt] += W(fragment: 16 output columns) A(rows 16 rt .., 128 k; LDS planes)^T, the WEIGHTS as the
 // first operand: D[column][row] puts an activation row on the lane (row = 16 rt + (lane & 15)) and
