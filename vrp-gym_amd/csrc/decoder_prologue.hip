@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void graph_mean_cvec_kernel(const float *__res
 // k = koff(q) + s, koff = {0, 64, 32, 96}: with LDS rows of 132 floats the two lane groups
 // that one ds_read_b128 pass serves together (q = 0 with 1, 2 with 3) are 64 floats apart,
 // which makes the 16-byte reads conflict-free.
+static bool prologue_x3_enabled();
 #define PT_LD 132
 #define PT_MAXROWS 112
 struct PrologueParams {
@@ -287,7 +288,9 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
             for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(x8[e]));
             x3_split8(x8, ep[r][0], ep[r][1], ep[r][2]);
           }
+#ifdef VRP_PRO_X3_FENCE
           __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
           for (int Y = 0; Y < 2; ++Y)
 #pragma unroll
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
 #pragma unroll
               for (int r = 0; r < RT_; ++r) acc[Y][c][r] = X3_MFMA(wh, ep[r][0], acc[Y][c][r]);
             }
+#ifdef VRP_PRO_X3_FENCE
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       } else
 #pragma unroll
@@ -553,7 +558,26 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   p.kind = kind; p.B = B; p.N = N;
   int G = fused_max_rows(N) / N;
   if (G > 4) G = 4;
+  // The x3 stage 1 holds the rows' fp32 values AND a chunk's planes: at five row tiles that is 81
+  // registers more than the VALU-addressable 256, the spill reloads drain the table stores
+  // (vmcnt(0)) and the kernel waits 36 % of its time (profiles/r05_x3_pmc.txt).  Packs of at most
+  // four tiles: N = 20: three graphs (60 rows), N = 40: one (48-row tiles, 40 used).
+  // Among those, the pack size with the fewest (rounds of the 1024 wave slots) x (row tiles per
+  // unit) -- stage 1 is the bulk of a unit: TSP-20 x 512: G = 2 (2048 units, two per wave: 51 us;
+  // G = 3: 1368 units, a third of the waves run twice: 65 us; G = 4 at five tiles: 54 us).
+  static const int max_tiles = getenv("VRP_PRO_X3_TILES") ? atoi(getenv("VRP_PRO_X3_TILES")) : 4;
   if (G > B) G = B;
+  if (prologue_x3_enabled() && fused_max_rows(N) <= 80) {
+    int best = 0;
+    long best_cost = 0;
+    for (int g = G; g >= 1; --g) {
+      const int tiles = (g * N + 15) / 16;
+      if (tiles > max_tiles && g > 1) continue;
+      const long units = (long)((B + g - 1) / g) * 8, cost = ((units + 1023) / 1024) * tiles;
+      if (!best || cost < best_cost) { best = g; best_cost = cost; }
+    }
+    G = best;
+  }
   p.G = G;
   p.npacks = (B + G - 1) / G;
   p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
