@@ -1571,6 +1571,155 @@ __global__ __launch_bounds__(512) void gemm_rows_kernel(
   }
 }
 
+// ---- the same GEMM on the bf16 matrix cores (round 5; encoder_x3.h) ---------------------------
+// gemm_rows_kernel's stages -- (column pass, 128-wide K chunk), the A chunk of a stage in LDS, the
+// next one behind the current stage's MFMAs -- with three-plane operands: the threads that store
+// an A chunk into LDS split it (64-row tiles: 2 x 48 KB of planes + the 33 KB fp32 image the
+// epilogue goes through); the W fragment of the next stage arrives in fp32 behind the MFMAs, as
+// before, and is split in registers once per stage (32 values per lane: W is a raw parameter or
+// an activation here, nobody pre-split it).  Weights as the first MFMA operand: a lane owns four
+// consecutive columns of a row of the result image (16-byte LDS stores).  Same epilogue.
+template <int RT16>
+__global__ __launch_bounds__(512) void gemm_rows_x3_kernel(
+    const float *__restrict__ A, int lda, const float *__restrict__ W_, int ldw,
+    const float *__restrict__ bias_, const float *__restrict__ R, int ldr,
+    const float *__restrict__ norm_, const float *__restrict__ gate, float *__restrict__ C, int ldc,
+    int M, int N, int K, int relu, int ntiles) {
+  constexpr int RTW = 16 * RT16, PE = RTW * X3_PITCH, PF = RTW * 32 / 512;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16 *const Abuf0 = reinterpret_cast<__bf16 *>(smem), *const Abuf1 = Abuf0 + 3 * PE;
+  float *const Cs = reinterpret_cast<float *>(Abuf1 + 3 * PE);     // [RTW][EB_LD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int ncb = N >> 7, nkc = K >> 7, nst = ncb * nkc;
+  float4 pa[PF];
+  auto fetchA = [&](int tile, int kc) {
+    const int row0 = tile * RTW;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < M) pa[u] = *reinterpret_cast<const float4 *>(A + (size_t)(row0 + r) * lda + kc * 128 + c4);
+    }
+  };
+  auto storeA = [&](__bf16 *dst) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      x3_store4v(dst, PE, r, c4, pa[u]);
+    }
+  };
+  // a W fragment in fp32: lane (i16 = weight row, q), chunk j: k = 32 j + 8 q .. + 7 (two float4)
+  float4 wn[8];
+  auto load_wn = [&](const float *wrow, int piece) { wn[piece] = *reinterpret_cast<const float4 *>(wrow + 32 * (piece >> 1) + 4 * (piece & 1)); };
+  Frag3 wf;
+  auto split_wn = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x8[8] = {wn[2 * j].x, wn[2 * j].y, wn[2 * j].z, wn[2 * j].w,
+                           wn[2 * j + 1].x, wn[2 * j + 1].y, wn[2 * j + 1].z, wn[2 * j + 1].w};
+      x3_split8(x8, wf.p[0][j], wf.p[1][j], wf.p[2][j]);
+    }
+  };
+  int tile = blockIdx.x;
+  int cur = 0;
+  if (tile < ntiles) { fetchA(tile, 0); storeA(Abuf0); }
+  {
+    const float *w0 = W_ + (size_t)(wave * 16 + i16) * ldw + 8 * q;
+#pragma unroll
+    for (int piece = 0; piece < 8; ++piece) load_wn(w0, piece);
+    split_wn();
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    int zero;   // (keeps the tile-invariant weight loads inside the loop, see encoder_block8_kernel)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const float *W = W_ + zero, *bias = bias_ ? bias_ + zero : nullptr, *norm = norm_ ? norm_ + zero : nullptr;
+    const int row0 = tile * RTW, valid = M - row0;
+    const int next_tile = tile + gridDim.x;
+    f32x4v acc[RT16];
+    for (int st = 0; st < nst; ++st) {
+      const int cb = st / nkc, kc = st - cb * nkc;
+      if (kc == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+      }
+      const bool last_stage = st + 1 == nst;
+      const bool tile_left = next_tile < ntiles;
+      const bool fetch = (nkc > 1) ? (!last_stage || tile_left) : (last_stage && tile_left);
+      if (fetch) fetchA(last_stage ? next_tile : tile, last_stage ? 0 : (kc + 1 == nkc ? 0 : kc + 1));
+      const bool epi = kc + 1 == nkc;
+      float4 rv[PF], gv[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+        rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (epi && r < valid) {
+          if (R) rv[u] = *reinterpret_cast<const float4 *>(R + (size_t)(row0 + r) * ldr + cb * 128 + c4);
+          if (gate) gv[u] = *reinterpret_cast<const float4 *>(gate + (size_t)(row0 + r) * ldc + cb * 128 + c4);
+        }
+      }
+      const int cq = cb * 128 + (tid & 31) * 4;
+      float4 bz = make_float4(0.f, 0.f, 0.f, 0.f), nmean = bz, nbeta = bz;
+      float4 nmult = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (epi) {
+        if (bias) bz = *reinterpret_cast<const float4 *>(bias + cq);
+        if (norm) {
+          nmean = *reinterpret_cast<const float4 *>(norm + cq);
+          nmult = *reinterpret_cast<const float4 *>(norm + 128 + cq);
+          nbeta = *reinterpret_cast<const float4 *>(norm + 256 + cq);
+        }
+      }
+      {
+        // next stage's W fragment: stage st + 1 of this tile, or stage 0 of the next tile
+        const int sn = last_stage ? 0 : st + 1;
+        const int cbn = sn / nkc, kcn = sn - cbn * nkc;
+        const float *wp = W + (size_t)(cbn * 128 + wave * 16 + i16) * ldw + kcn * 128 + 8 * q;
+        x3_mma<RT16>(acc, cur ? Abuf1 : Abuf0, PE, wf, lane, [&](int it) { if (it < 8) load_wn(wp, it); });
+      }
+      if (fetch) storeA(cur ? Abuf0 : Abuf1);
+      if (epi) {
+        // the 64 x 128 block of this pass goes through LDS so that residual, gate and result
+        // move as 16-byte pieces of whole rows
+#pragma unroll
+        for (int rt = 0; rt < RT16; ++rt)
+          *reinterpret_cast<float4 *>(Cs + (rt * 16 + i16) * EB_LD + wave * 16 + 4 * q) =
+              make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+          if (r < valid) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(Cs + r * EB_LD + c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float rr[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+            const float gg[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+            const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
+            const float nm[4] = {nmean.x, nmean.y, nmean.z, nmean.w};
+            const float nu[4] = {nmult.x, nmult.y, nmult.z, nmult.w};
+            const float nb[4] = {nbeta.x, nbeta.y, nbeta.z, nbeta.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] += bb[e];
+              if (R) v[e] += rr[e];
+              if (norm) v[e] = (v[e] - nm[e]) * nu[e] + nb[e];
+              if (relu) v[e] = fmaxf(v[e], 0.f);
+              if (gate && !(gg[e] > 0.f)) v[e] = 0.f;
+            }
+            *reinterpret_cast<float4 *>(C + (size_t)(row0 + r) * ldc + cb * 128 + c4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+      split_wn();
+      if (fetch || epi) __syncthreads();   // next A chunk in place / everybody done with Cs
+      if (fetch) cur ^= 1;
+    }
+  }
+}
+
 // (Round 4, measured and NOT kept -- DESIGN.md 3.5: the pass epilogue spread over the next pass's
 // k-step groups, 127 vs 117 us at 81920 x 384 x 128; two four-wave workgroups of 48-row tiles per
 // CU instead of one eight-wave workgroup of 80 rows, 187 vs 120 us.  PMC on this kernel: matrix
@@ -1739,6 +1888,25 @@ int vrp_launch_gemm_rows(const float *A, int lda, const float *W, int ldw, const
     if (N == 256)
       return gate ? launch_gemm_rows_wide<2, true>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st)
                   : launch_gemm_rows_wide<2, false>(A, lda, W, ldw, bias, gate, C, ldc, M, relu, st);
+  }
+  static const bool fp32 = getenv("VRP_GEMM_FP32") != nullptr;   // A/B aid: the fp32-MFMA kernel
+  if (!fp32) {
+    constexpr int RT16 = 4, RTW = 64;
+    const size_t lds = (size_t)2 * 3 * RTW * X3_PITCH * 2 + (size_t)RTW * EB_LD * sizeof(float);
+    static VrpAttrOnce attr_set;
+    if (!attr_set.done()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_rows_x3_kernel<RT16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        vrp_set_error("gemm_rows_x3: cannot raise dynamic LDS to %zu bytes", lds);
+        return 1;
+      }
+      attr_set.mark();
+    }
+    const int ntiles = (M + RTW - 1) / RTW;
+    hipLaunchKernelGGL(gemm_rows_x3_kernel<RT16>, dim3(min(ntiles, 256)), dim3(512), lds, st, A, lda, W,
+                       ldw, bias, R, ldr, norm, gate, C, ldc, M, N, K, relu, ntiles);
+    VRP_CHECK_LAUNCH("gemm_rows_x3");
+    return 0;
   }
   constexpr int RT16 = 5, RTW = 80;
   const size_t lds = (size_t)3 * RTW * EB_LD * sizeof(float);
