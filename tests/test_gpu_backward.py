@@ -360,3 +360,70 @@ def test_training_step_is_bitwise_reproducible(kind, B, N):
         assert torch.equal(g1[n], g2[n]), n
     for n in b1:
         assert torch.equal(b1[n], b2[n]), n
+
+
+@pytest.mark.parametrize("kind,B,N", [(1, 2048, 40), (2, 1024, 40)])
+def test_full_size_training_step_against_oracle_autograd(kind, B, N):
+    """BASELINE configs 3 and 4 (per-GPU shard) at FULL size: one sampled train-mode rollout (batch
+    statistics BatchNorm, running-stat update) + the HIP backward of a REINFORCE-shaped loss,
+    against fp64 autograd through the oracle teacher-forced on the HIP path's own actions and
+    masks (what __graft_entry__.smoke() does at B = 16; graph_tsp_agent.py:178-186,
+    graph_encoder.py:141-154).  Checked: the accumulated log-probability of every graph, the
+    loss scalar, and every parameter's gradient relative to its own scale (+ a floor tied to the
+    largest gradient: biases in front of a train-mode BatchNorm have an exactly-zero gradient)."""
+    import time
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import IRPEnv, VRPEnv
+    from oracle import envs as oenv
+    from oracle import policy as opol
+    t0 = time.time()
+    Agent = (None, agents.VRPAgent, agents.IRPAgent)[kind]
+    Env = (None, VRPEnv, IRPEnv)[kind]
+    agent = Agent(seed=69)
+    model = agent.model
+    model.train()
+    env = Env(N, B, 1, 69)
+    torch.manual_seed(3)
+    res = runtime.rollout(model, env, greedy=False, train=True, record=True)
+    logp = runtime.attach_grad(model, env, res)
+    wgt = torch.linspace(-1.0, 1.0, B, device=logp.device)
+    model.zero_grad()
+    loss = (wgt * logp).mean()
+    loss.backward()
+    T = res.T
+    sd, _ = opol.init_state_dicts((None, oenv.VRP, oenv.IRP)[kind], 69)
+    psd = {k: (v.detach().double().requires_grad_("running" not in k) if v.is_floating_point() else v.detach())
+           for k, v in sd.items()}
+    x = res.x3.cpu().double()     # [x, y, demand]: the embeddings read the columns they are built for
+    dmask = res.depot_mask.cpu().bool() if res.depot_mask is not None else None
+    emb = opol.encoder_forward(psd, x, dmask, train=True)
+    assert (emb.detach() - res.emb.cpu().double()).abs().max().item() < 2e-4
+    ep = opol.DecoderEpisode(psd, emb)
+    acts, masks = res.actions[:T].cpu(), res.mask_trace[:T].cpu().double()
+    loads = res.load_trace[:T].cpu().double() if res.load_trace is not None else None
+    total = torch.zeros(B, dtype=torch.float64)
+    for t in range(T):
+        u = ep.logits(masks[t], None if loads is None else loads[t])
+        total = total + (u - u.logsumexp(-1, keepdim=True)).gather(1, acts[t][:, None])[:, 0]
+        ep.advance(acts[t])
+    want_loss = (wgt.cpu().double() * total).mean()
+    want_loss.backward()
+    dlogp = (logp.detach().cpu().double() - total.detach()).abs().max().item()
+    dloss = abs(loss.item() - want_loss.item())
+    gmax = max(v.grad.abs().max().item() for v in psd.values() if torch.is_tensor(v) and v.grad is not None)
+    worst, worst_name = 0.0, ""
+    for name, p in model.named_parameters():
+        want = psd[name].grad
+        if want is None:
+            assert p.grad is None, name
+            continue
+        rel = ((p.grad.cpu().double() - want).abs().max().item() / (want.abs().max().item() + 1e-3 * gmax))
+        if rel > worst:
+            worst, worst_name = rel, name
+    print(f"kind {kind} B {B} N {N} T {T}: max |d logp| {dlogp:.2e}, |d loss| {dloss:.2e} "
+          f"(loss {want_loss.item():.6f}), worst relative gradient error {worst:.2e} ({worst_name}), "
+          f"{time.time() - t0:.1f} s")
+    assert dlogp < 5e-4, dlogp           # a sum of T <= 78 fp32 step log-probabilities
+    assert dloss < 1e-5 * max(1.0, abs(want_loss.item())) + 2e-5, dloss
+    assert worst < 5e-3, (worst, worst_name)

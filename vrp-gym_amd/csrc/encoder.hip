@@ -2691,6 +2691,8 @@ static bool encoder_x3_enabled(const vrp_encoder_weights *w) {
   static const bool off = getenv("VRP_ENCODER_FP32") != nullptr;
   return !off && w->split != nullptr;
 }
+// the large-batch x3 kernels index their rows with 32-bit element offsets
+static bool encoder_x3_rows_ok(long rows) { return rows * 128 < (1l << 31); }
 template <int RT16>
 static int launch_encoder_stack_x3(const vrp_encoder_weights *w, const float *x, const float *norms,
                                    float *y, int B, int N, const StackSetup &su,
@@ -2750,7 +2752,7 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
       pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < rows) pa[u] = *reinterpret_cast<const float4 *>(att + (size_t)(row0 + r) * 128 + c4);
+      if (row0 + r < rows) pa[u] = *reinterpret_cast<const float4 *>(att + ((row0 + r) * 128 + c4));   // (32-bit offsets: rows * 128 < 2^31)
     }
   };
   auto store_att = [&](__bf16 *dst) {
@@ -2760,10 +2762,6 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
       x3_store4v(dst, PE, r, c4, pa[u]);
     }
   };
-  const float4 bb_o = x3_ld4(bo + cq), mean1 = x3_ld4(norm1 + cq), mult1 = x3_ld4(norm1 + 128 + cq),
-               beta1 = x3_ld4(norm1 + 256 + cq);
-  const float4 bb_2 = x3_ld4(b2 + cq), mean2 = x3_ld4(norm2 + cq), mult2 = x3_ld4(norm2 + 128 + cq),
-               beta2 = x3_ld4(norm2 + 256 + cq);
   int tile = blockIdx.x;
   __bf16 *abuf = hb0, *other = hb1;
   if (tile < ntiles) { fetch_att(tile); store_att(abuf); }
@@ -2778,13 +2776,17 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     int zero;
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     const __bf16 *lf = lf_ + zero;
+    // (bias / BatchNorm constants of this lane's four columns: 32 registers if kept across the
+    // tile loop -- the kernel then spills, and a spill reload waits for every load in flight, the
+    // prefetched weight fragment among them; fetched where they are used instead, from L1)
+    const float *boz = bo + zero, *n1z = norm1 + zero, *b2z = b2 + zero, *n2z = norm2 + zero;
     const int row0 = tile * RTW, valid = rows - row0;
     // the residual rows in this lane's accumulator layout: row 16 rt + i16, columns cq .. cq + 3
     float4 xr[RT16];
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       const int row = rt * 16 + i16;
-      xr[rt] = row < valid ? x3_ld4(x + (size_t)(row0 + row) * 128 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[rt] = row < valid ? x3_ld4(x + ((row0 + row) * 128 + cq)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     f32x4v acc[RT16], gacc[RT16];
 #pragma unroll
@@ -2792,6 +2794,8 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     // ---- y1 = BN1(x + att Wo^T + bo) ----------------------------------------------------------
     x3_mma<RT16>(acc, abuf, PE, fa, lane);
     x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
+    const float4 bb_o = x3_ld4(boz + cq), mean1 = x3_ld4(n1z + cq), mult1 = x3_ld4(n1z + 128 + cq),
+                 beta1 = x3_ld4(n1z + 256 + cq);
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       xr[rt].x = (acc[rt][0] + bb_o.x + xr[rt].x - mean1.x) * mult1.x + beta1.x;
@@ -2839,11 +2843,13 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     x3_load_frag(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);   // Wo of the next tile
     if (next < ntiles) store_att(hfree);
     // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
+    const float4 bb_2 = x3_ld4(b2z + cq), mean2 = x3_ld4(n2z + cq), mult2 = x3_ld4(n2z + 128 + cq),
+                 beta2 = x3_ld4(n2z + 256 + cq);
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       const int row = rt * 16 + i16;
       if (row < valid)
-        *reinterpret_cast<float4 *>(y + (size_t)(row0 + row) * 128 + cq) =
+        *reinterpret_cast<float4 *>(y + ((row0 + row) * 128 + cq)) =
             make_float4((gacc[rt][0] + bb_2.x + xr[rt].x - mean2.x) * mult2.x + beta2.x,
                         (gacc[rt][1] + bb_2.y + xr[rt].y - mean2.y) * mult2.y + beta2.y,
                         (gacc[rt][2] + bb_2.z + xr[rt].z - mean2.z) * mult2.z + beta2.z,
@@ -2903,17 +2909,14 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
   auto fetch = [&](int tile) {
     const int g0 = tile * G;
     const int rows = min(G, B - g0) * N;
-    const size_t row0 = (size_t)g0 * N;
+    const int row0 = g0 * N;   // (32-bit offsets: B N 128 < 2^31, checked by the launcher)
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
       pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + (row0 + r) * VRP_EMB + c4);
+      if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + ((row0 + r) * VRP_EMB + c4));
     }
   };
-  float4 bb[3];
-#pragma unroll
-  for (int ct = 0; ct < 3; ++ct) bb[ct] = x3_ld4(bin + wave * 48 + ct * 16 + 4 * q);
   // fragment buffers: fb holds column tile 1 for good, fa alternates between tiles 0 and 2
   Frag3 fa, fb;
   x3_load_frag(fa, lf_ + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);
@@ -2924,6 +2927,7 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
     int zero;   // (keeps the fragment loads inside the loop: see encoder_block8_x3_kernel)
     asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
     const __bf16 *lf = lf_ + zero;
+    const float *binz = bin + zero;   // (bias pieces fetched where they are used: 12 registers less)
     const int g0 = tile * G;
     const int graphs = min(G, B - g0);
 #pragma unroll
@@ -2947,11 +2951,12 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
       const int col0 = wave * 48 + ct * 16 + 4 * q;
+      const float4 bb = x3_ld4(binz + col0);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt)
         *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + col0) =
-            make_float4(acc[ct][rt][0] + bb[ct].x, acc[ct][rt][1] + bb[ct].y,
-                        acc[ct][rt][2] + bb[ct].z, acc[ct][rt][3] + bb[ct].w);
+            make_float4(acc[ct][rt][0] + bb.x, acc[ct][rt][1] + bb.y,
+                        acc[ct][rt][2] + bb.z, acc[ct][rt][3] + bb.w);
     }
     __syncthreads();
     float *o = att + (size_t)g0 * N * VRP_EMB;
@@ -3186,7 +3191,7 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
     } else if (!train && N <= 64 && (80 / N) * N * 4 >= 3 * 80 && !qa_off) {
       // large batches, eval mode: in_proj + attention of 80 / N whole graphs per workgroup
       // (only when the graphs fill at least three quarters of the five row tiles)
-      if (int r = encoder_x3_enabled(w) ? launch_qkv_attn8_x3(cur, w, l, ws.att, B, N, st)
+      if (int r = encoder_x3_enabled(w) && encoder_x3_rows_ok((long)B * N) ? launch_qkv_attn8_x3(cur, w, l, ws.att, B, N, st)
                                         : launch_qkv_attn8(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st))
         return r;
     } else if (heads == 8 && qkv_attn_graph_applies(train, B, N)) {
@@ -3217,7 +3222,8 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       else if ((rtw_env && rtw_env[0] == '8') || (!rtw_env && R >= 256 * 80))
         // >= one 80-row tile per CU: persistent 8-wave kernel (827 vs 914 us per layer for
         // the 64-row kernel at 8192 x 40)
-        r = encoder_x3_enabled(w) ? launch_encoder_block8_x3<4>(ws.att, cur, w, l, n1, n2, nxt, R, st)
+        r = encoder_x3_enabled(w) && encoder_x3_rows_ok(R)
+                ? launch_encoder_block8_x3<4>(ws.att, cur, w, l, n1, n2, nxt, R, st)
                                   : launch_encoder_block8<5>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows
         r = launch_encoder_block<64>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
