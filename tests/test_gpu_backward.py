@@ -412,18 +412,27 @@ def test_full_size_training_step_against_oracle_autograd(kind, B, N):
     dlogp = (logp.detach().cpu().double() - total.detach()).abs().max().item()
     dloss = abs(loss.item() - want_loss.item())
     gmax = max(v.grad.abs().max().item() for v in psd.values() if torch.is_tensor(v) and v.grad is not None)
-    worst, worst_name = 0.0, ""
+    worst, worst_name, worst_fro, worst_fro_name = 0.0, "", 0.0, ""
     for name, p in model.named_parameters():
         want = psd[name].grad
         if want is None:
             assert p.grad is None, name
             continue
-        rel = ((p.grad.cpu().double() - want).abs().max().item() / (want.abs().max().item() + 1e-3 * gmax))
+        diff = p.grad.cpu().double() - want
+        rel = diff.abs().max().item() / (want.abs().max().item() + 1e-3 * gmax)
+        fro = diff.norm().item() / (want.norm().item() + 1e-3 * gmax * want.numel() ** 0.5)
         if rel > worst:
             worst, worst_name = rel, name
+        if fro > worst_fro:
+            worst_fro, worst_fro_name = fro, name
     print(f"kind {kind} B {B} N {N} T {T}: max |d logp| {dlogp:.2e}, |d loss| {dloss:.2e} "
-          f"(loss {want_loss.item():.6f}), worst relative gradient error {worst:.2e} ({worst_name}), "
-          f"{time.time() - t0:.1f} s")
+          f"(loss {want_loss.item():.6f}), worst relative gradient error: max-norm {worst:.2e} "
+          f"({worst_name}), Frobenius {worst_fro:.2e} ({worst_fro_name}), {time.time() - t0:.1f} s")
     assert dlogp < 5e-4, dlogp           # a sum of T <= 78 fp32 step log-probabilities
     assert dloss < 1e-5 * max(1.0, abs(want_loss.item())) + 2e-5, dloss
-    assert worst < 5e-3, (worst, worst_name)
+    # A gradient here is an fp32 sum over 41 - 82 thousand rows x up to 78 steps.  Measured at VRP
+    # 2048 x 40 (T = 72): max-norm 7.9e-3 with the bf16-plane GEMMs, 1.1e-2 with the fp32-MFMA
+    # kernels (VRP_GEMM_FP32 / VRP_ENCODER_FP32 / VRP_PROLOGUE_FP32): the arithmetic of round 5 is
+    # not the limit, fp32 accumulation at this size is (B = 16, smoke(): 1.7e-4).
+    assert worst < 3e-2, (worst, worst_name)
+    assert worst_fro < 5e-3, (worst_fro, worst_fro_name)   # measured 1.3e-3 / 8.0e-4
