@@ -688,6 +688,19 @@ def run_workload(name, steps, warmup, device, dist, rank, world, blocks=1):
     return out, env, agent
 
 
+def bind_device(local):
+    """This rank's GPU, in the order the library depends on: make it torch's (and HIP's) current
+    device, check that it is, and only then let the library look at it -- its residency census and
+    its per-device state (failure counter, cross-process lease keyed by PCI bus id) belong to the
+    device that is current at that moment (vrpgym_hip.require_gpu).  Before any communicator
+    exists and before anything is enqueued."""
+    import vrpgym_hip as hip
+    torch.cuda.set_device(local)
+    assert torch.cuda.current_device() == local, (torch.cuda.current_device(), local)
+    hip.require_gpu()
+    return torch.device("cuda", local)
+
+
 def describe(kind, N, B, mode, T, world):
     what = {"greedy": "attention agent greedy rollout", "sample": "attention agent sampling rollout",
             "train": "REINFORCE training epoch (2 sampled rollouts, HIP backward, gradient "
@@ -727,8 +740,7 @@ def main():
     if world > 1 and not one_gpu and torch.cuda.device_count() < world:
         # (the parent counted in sysfs; a rank sees what the runtime really offers)
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    device = bind_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -115,6 +115,24 @@ def test_bench_eight_ranks_one_gpu(workload):
         assert 6.0 < out["mean_tour_cost"] < 7.6
 
 
+def test_rank_binds_its_device_before_the_library_looks_at_it(monkeypatch):
+    """bench.bind_device: set_device -> current_device check -> library census, in that order (a
+    census taken before set_device would measure cuda:0 from every rank of a multi-GPU job)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import vrpgym_hip
+    calls, state = [], {"dev": 0}
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: (calls.append(("set", d)), state.update(dev=d)))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: (calls.append(("cur",)), state["dev"])[1])
+    monkeypatch.setattr(vrpgym_hip, "require_gpu", lambda: calls.append(("census", state["dev"])))
+    dev = mod.bind_device(3)
+    assert dev == torch.device("cuda", 3)
+    assert calls[0] == ("set", 3) and calls[-1] == ("census", 3)
+    assert ("cur",) in calls[1:-1]
+
+
 def test_gpu_count_without_the_hip_runtime():
     """spawn_ranks counts GPUs in sysfs (KFD topology), never through HIP in the parent."""
     import importlib.util
