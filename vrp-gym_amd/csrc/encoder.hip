@@ -2467,7 +2467,6 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int c = wave * 16 + i16;
   const int g0 = blockIdx.x * G;
   const int graphs = min(G, B - g0);
   const int rows = graphs * N;
