@@ -2780,6 +2780,13 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     // prefetched weight fragment among them; fetched where they are used instead, from L1)
     const float *boz = bo + zero, *n1z = norm1 + zero, *b2z = b2 + zero, *n2z = norm2 + zero;
     const int row0 = tile * RTW, valid = rows - row0;
+#ifdef VRP_STACK_TRACE
+    const bool tr_ = tile == (int)(blockIdx.x + gridDim.x);
+#define B8_MARK(i) if (tr_) { ST_MARK(i); }
+#else
+#define B8_MARK(i)
+#endif
+    B8_MARK(0); B8_MARK(1);
     // the residual rows in this lane's accumulator layout: row 16 rt + i16, columns cq .. cq + 3
     float4 xr[RT16];
 #pragma unroll
@@ -2791,10 +2798,11 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) { acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; gacc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
     // ---- y1 = BN1(x + att Wo^T + bo) ----------------------------------------------------------
-    x3_mma<RT16>(acc, abuf, PE, fa, lane);
-    x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
     const float4 bb_o = x3_ld4(boz + cq), mean1 = x3_ld4(n1z + cq), mult1 = x3_ld4(n1z + 128 + cq),
-                 beta1 = x3_ld4(n1z + 256 + cq);
+                 beta1 = x3_ld4(n1z + 256 + cq);   // (requested ahead of the MFMAs that hide them)
+    x3_mma<RT16>(acc, abuf, PE, fa, lane);
+    B8_MARK(2);
+    x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       xr[rt].x = (acc[rt][0] + bb_o.x + xr[rt].x - mean1.x) * mult1.x + beta1.x;
@@ -2803,7 +2811,9 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
       xr[rt].w = (acc[rt][3] + bb_o.w + xr[rt].w - mean1.w) * mult1.w + beta1.w;
       x3_store4v(XB3, PE, rt * 16 + i16, cq, xr[rt]);
     }
+    B8_MARK(3);
     __syncthreads();
+    B8_MARK(4);
     // ---- hidden slices: slice ch + 1 goes up BEFORE slice ch comes down; its epilogue (ReLU,
     // split, plane stores) is issued between the MFMAs of the way down --------------------------
     auto up_store = [&](int rt, const float4 &b1v, __bf16 *hb) {
@@ -2816,34 +2826,48 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
       for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
       x3_mma<RT16>(acc, XB3, PE, fb, lane);
       if (nchunk > 1) x3_load_frag(fb, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
+      B8_MARK(5);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, abuf);   // the attention rows are dead by now
     }
+    B8_MARK(6);
     __syncthreads();
+    B8_MARK(7);
     for (int ch = 0; ch + 1 < nchunk; ++ch) {
       __bf16 *hcur = (ch & 1) ? other : abuf, *hnext = (ch & 1) ? abuf : other;
       const float4 b1v = x3_ld4(b1 + (ch + 1) * 128 + cq);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
       x3_mma<RT16>(acc, XB3, PE, fb, lane);                                   // up: slice ch + 1
+      // fb is free now.  Not the last pair: the next ff.0 slice.  The last pair: the LAST ff.2
+      // slice -- the way down that follows the coming barrier has no way up in front of it to
+      // hide a fragment requested after this pair's way down (measured: 4-8 k cycles exposed)
       if (ch + 2 < nchunk) x3_load_frag(fb, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      else x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      B8_MARK(8 + 3 * ch);
       x3_mma<RT16>(gacc, hcur, PE, fa, lane, [&](int it) {                    // down: slice ch
         if (it < RT16) up_store(it, b1v, hnext);
       });
-      x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      // fa is free: the next ff.2 slice, or (last pair) the next tile's Wo
+      if (ch + 2 < nchunk) x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      else x3_load_frag(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
+      B8_MARK(9 + 3 * ch);
       __syncthreads();
+      B8_MARK(10 + 3 * ch);
     }
     // last way down; the next tile's attention rows travel behind it into the free buffer
     __bf16 *hlast = ((nchunk - 1) & 1) ? other : abuf, *hfree = ((nchunk - 1) & 1) ? abuf : other;
     const int next = tile + gridDim.x;
     if (next < ntiles) fetch_att(next);
-    x3_load_frag(fb, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // ff.0 slice 0 of the next tile
-    x3_mma<RT16>(gacc, hlast, PE, fa, lane);
-    x3_load_frag(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);   // Wo of the next tile
-    if (next < ntiles) store_att(hfree);
-    // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
     const float4 bb_2 = x3_ld4(b2z + cq), mean2 = x3_ld4(n2z + cq), mult2 = x3_ld4(n2z + 128 + cq),
-                 beta2 = x3_ld4(n2z + 256 + cq);
+                 beta2 = x3_ld4(n2z + 256 + cq);   // (requested ahead of the MFMAs that hide them)
+    B8_MARK(20);
+    x3_mma<RT16>(gacc, hlast, PE, fb, lane);   // the last ff.2 slice sits in fb (see the loop; hidden >= 256)
+    B8_MARK(21);
+    x3_load_frag(fb, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // ff.0 slice 0 of the next tile
+    if (next < ntiles) store_att(hfree);
+    B8_MARK(22);
+    // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       const int row = rt * 16 + i16;
@@ -2854,7 +2878,9 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
                         (gacc[rt][2] + bb_2.z + xr[rt].z - mean2.z) * mult2.z + beta2.z,
                         (gacc[rt][3] + bb_2.w + xr[rt].w - mean2.w) * mult2.w + beta2.w);
     }
+    B8_MARK(23);
     __syncthreads();   // next tile's attention rows complete, XB3 and hlast free
+    B8_MARK(24);
     abuf = hfree; other = hlast;
     tile = next;
   }
@@ -2883,6 +2909,26 @@ static int launch_encoder_block8_x3(const float *att, const float *x, const vrp_
                      lf, L.out_proj_bias, norm1, L.ff0_bias, L.ff2_bias, norm2, y, rows, w->hidden,
                      ntiles);
   VRP_CHECK_LAUNCH("encoder_block8_x3");
+#ifdef VRP_STACK_TRACE
+  {
+    static int calls = 0;
+    if (++calls == 5) {
+      hipDeviceSynchronize();
+      static unsigned long long h[512 * 8 * ST_SLOTS];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stack_trace), sizeof(h));
+      for (int wv : {0, 5}) {
+        const unsigned long long *t = h + ((size_t)100 * 8 + wv) * ST_SLOTS;
+        fprintf(stderr, "[block8_x3 trace] block 100 wave %d (second tile), cycles: xr-load+O-mma %llu | O-epi %llu | bar %llu | U0-mma %llu | U0-epi %llu | bar %llu |",
+                wv, t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]);
+        for (int ch = 0; ch < 3; ++ch)
+          fprintf(stderr, " U%d-mma %llu D%d+fill %llu bar %llu |", ch + 1, t[8 + 3 * ch] - (ch ? t[10 + 3 * (ch - 1)] : t[7]),
+                  ch, t[9 + 3 * ch] - t[8 + 3 * ch], t[10 + 3 * ch] - t[9 + 3 * ch]);
+        fprintf(stderr, " fetch %llu | D3-mma %llu | store_att %llu | BN2-epi %llu | bar %llu | total %llu\n", t[20] - t[16],
+                t[21] - t[20], t[22] - t[21], t[23] - t[22], t[24] - t[23], t[24] - t[1]);
+      }
+    }
+  }
+#endif
   return 0;
 }
 
@@ -3221,7 +3267,7 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
       else if ((rtw_env && rtw_env[0] == '8') || (!rtw_env && R >= 256 * 80))
         // >= one 80-row tile per CU: persistent 8-wave kernel (827 vs 914 us per layer for
         // the 64-row kernel at 8192 x 40)
-        r = encoder_x3_enabled(w) && encoder_x3_rows_ok(R)
+        r = encoder_x3_enabled(w) && encoder_x3_rows_ok(R) && w->hidden >= 256
                 ? launch_encoder_block8_x3<4>(ws.att, cur, w, l, n1, n2, nxt, R, st)
                                   : launch_encoder_block8<5>(ws.att, cur, L, n1, n2, nxt, R, w->hidden, st);
       else if (R > 16 * 1024)  // two 64-row workgroups per CU beat one of 128 rows

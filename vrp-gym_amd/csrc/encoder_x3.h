@@ -97,15 +97,25 @@ __device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, 
   for (int it = 0; it < 4 * RT16; ++it) {
     const int j = it / RT16, rt = it - j * RT16, cur = it & 1;
     if (it + 1 < 4 * RT16) rd(a[cur ^ 1], it + 1);
+#ifndef X3_NOFENCE
     __builtin_amdgcn_sched_barrier(0);
+#endif
     fill(it);
+#ifdef X3_SETPRIO
+    __builtin_amdgcn_s_setprio(X3_SETPRIO);
+#endif
     acc[rt] = X3_MFMA(w.p[1][j], a[cur][1], acc[rt]);
     acc[rt] = X3_MFMA(w.p[2][j], a[cur][0], acc[rt]);
     acc[rt] = X3_MFMA(w.p[0][j], a[cur][2], acc[rt]);
     acc[rt] = X3_MFMA(w.p[1][j], a[cur][0], acc[rt]);
     acc[rt] = X3_MFMA(w.p[0][j], a[cur][1], acc[rt]);
     acc[rt] = X3_MFMA(w.p[0][j], a[cur][0], acc[rt]);
+#ifdef X3_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef X3_NOFENCE
     __builtin_amdgcn_sched_barrier(0);
+#endif
   }
 }
 // the lane's four columns as one value
