@@ -1188,75 +1188,108 @@ struct AttSinkX3 {    // ... as three bf16 planes of an LDS tile (encoder_x3.h)
     x3_store4(tile, plane_elems, row, col, a, b, c, d);
   }
 };
-template <int NT, typename Sink>
-__device__ __forceinline__ void qa8_stage_attention_mfma_to(const float *Q_s, int N, int graphs,
-                                                            int max_row, Sink sink, int lane, int wave) {
+// GP graphs at a time (GP = 2 for the stack kernels' small tiles: a wave's life in this stage is a
+// chain LDS read -> score MFMAs -> softmax -> value MFMAs -> store per graph; two graphs side by
+// side give every link of the chain an independent twin to overlap with).  Per graph the
+// arithmetic and its order are unchanged.
+template <int NT, int GP, typename Sink>
+__device__ __forceinline__ void qa8_attention_group(const float *Q_s, int N, int g0, int max_row,
+                                                    Sink sink, int lane, int wave) {
   const int h = wave, i16 = lane & 15, q = lane >> 4;
-  for (int g = 0; g < graphs; ++g) {
-    const int r0 = g * N;
-    float4 qf[NT], kf[NT];
+  float4 qf[GP][NT], kf[GP][NT];
+  float vv[GP][NT][4];  // V[16tn + 4q + r4][d = i16]: the A operand of the second product
+#pragma unroll
+  for (int u = 0; u < GP; ++u) {
+    const int r0 = (g0 + u) * N;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int row = min(r0 + 16 * t + i16, max_row);
       const float4 a = *reinterpret_cast<const float4 *>(Q_s + row * QA_QLD + h * 16 + 4 * q);
-      qf[t] = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
-      kf[t] = *reinterpret_cast<const float4 *>(Q_s + row * QA_QLD + 128 + h * 16 + 4 * q);
+      qf[u][t] = make_float4(a.x * 0.25f, a.y * 0.25f, a.z * 0.25f, a.w * 0.25f);  // 1/sqrt(16)
+      kf[u][t] = *reinterpret_cast<const float4 *>(Q_s + row * QA_QLD + 128 + h * 16 + 4 * q);
     }
-    float vv[NT][4];  // V[16tn + 4q + r4][d = i16]: the A operand of the second product
 #pragma unroll
     for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4)
-        vv[tn][r4] = Q_s[min(r0 + 16 * tn + 4 * q + r4, max_row) * QA_QLD + 256 + h * 16 + i16];
-    f32x4v st[NT][NT];  // st[tn][tm][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
+        vv[u][tn][r4] = Q_s[min(r0 + 16 * tn + 4 * q + r4, max_row) * QA_QLD + 256 + h * 16 + i16];
+  }
+  f32x4v st[GP][NT][NT];  // st[tn][tm][r4] = S[m = 16tm + i16][n = 16tn + 4q + r4]
 #pragma unroll
-    for (int tn = 0; tn < NT; ++tn)
+  for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-      for (int tm = 0; tm < NT; ++tm) {
+    for (int tm = 0; tm < NT; ++tm)
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
         f32x4v d = {0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].x, qf[tm].x, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].y, qf[tm].y, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].z, qf[tm].z, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tn].w, qf[tm].w, d, 0, 0, 0);
-        st[tn][tm] = d;
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][tn].x, qf[u][tm].x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][tn].y, qf[u][tm].y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][tn].z, qf[u][tm].z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][tn].w, qf[u][tm].w, d, 0, 0, 0);
+        st[u][tn][tm] = d;
       }
 #pragma unroll
-    for (int tm = 0; tm < NT; ++tm) {
+  for (int tm = 0; tm < NT; ++tm) {
+    float sum[GP];
+    f32x4v o[GP];
+#pragma unroll
+    for (int u = 0; u < GP; ++u) {
       // softmax over the keys of query row m = 16tm + i16 (graph_encoder.py:172: no mask)
       float mx = -INFINITY;
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          if (16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[tn][tm][r4]);
+          if (16 * tn + 4 * q + r4 < N) mx = fmaxf(mx, st[u][tn][tm][r4]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
+      float sm = 0.f;
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const float pw = (16 * tn + 4 * q + r4 < N) ? exp_nonpos(st[tn][tm][r4] - mx) : 0.f;
-          st[tn][tm][r4] = pw;
-          sum += pw;
+          const float pw = (16 * tn + 4 * q + r4 < N) ? exp_nonpos(st[u][tn][tm][r4] - mx) : 0.f;
+          st[u][tn][tm][r4] = pw;
+          sm += pw;
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      f32x4v o = {0.f, 0.f, 0.f, 0.f};
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      sum[u] = sm;
+    }
+#pragma unroll
+    for (int u = 0; u < GP; ++u) {
+      f32x4v oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4)
-          o = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[tn][r4], st[tn][tm][r4], o, 0, 0, 0);
-      // D[d = 4q + r4][m = i16]
-      const int m = 16 * tm + i16;
-      if (m < N) {
-        const float inv = 1.f / sum;
-        sink(r0 + m, h * 16 + 4 * q, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+          oo = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[u][tn][r4], st[u][tn][tm][r4], oo, 0, 0, 0);
+      o[u] = oo;
+    }
+    // D[d = 4q + r4][m = i16]
+    const int m = 16 * tm + i16;
+    if (m < N) {
+#pragma unroll
+      for (int u = 0; u < GP; ++u) {
+        const float inv = 1.f / sum[u];
+        sink((g0 + u) * N + m, h * 16 + 4 * q, o[u][0] * inv, o[u][1] * inv, o[u][2] * inv, o[u][3] * inv);
       }
     }
   }
+}
+template <int NT, typename Sink>
+__device__ __forceinline__ void qa8_stage_attention_mfma_to(const float *Q_s, int N, int graphs,
+                                                            int max_row, Sink sink, int lane, int wave) {
+  for (int g = 0; g < graphs; ++g) qa8_attention_group<NT, 1>(Q_s, N, g, max_row, sink, lane, wave);
+}
+// the same, two graphs side by side while there are two left
+template <int NT, typename Sink>
+__device__ __forceinline__ void qa8_stage_attention_mfma_pairs(const float *Q_s, int N, int graphs,
+                                                               int max_row, Sink sink, int lane, int wave) {
+  int g = 0;
+  for (; g + 1 < graphs; g += 2) qa8_attention_group<NT, 2>(Q_s, N, g, max_row, sink, lane, wave);
+  if (g < graphs) qa8_attention_group<NT, 1>(Q_s, N, g, max_row, sink, lane, wave);
 }
 template <int NT>
 __device__ __forceinline__ void qa8_stage_attention_mfma(const float *Q_s, int N, int graphs,
@@ -2531,8 +2564,13 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) a[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   };
-  // fragment buffers: fa = in_proj tiles 0 / 2, ff.0 slices; fb = in_proj tile 1, out_proj, ff.2 slices
-  for (int l = 0; l < w.num_layers; ++l) {
+  // One layer.  Two fragment buffers: on entry A holds the layer's first in_proj fragment; A then
+  // carries in_proj tile 2 and the ff.0 slices, B in_proj tile 1, out_proj and the ff.2 slices --
+  // except at the layer's tail: the LAST ff.2 slice goes into A (free after the last way up, so
+  // the request has the way down of the slice before to hide behind; requested into B it would
+  // follow that way down and be needed right after the barrier), and the NEXT layer's first
+  // in_proj fragment into B.  The buffers therefore swap roles from layer to layer.
+  auto layer = [&](int l, Frag3 &A, Frag3 &B) {
     const vrp_encoder_layer &L = w.layer[l];
     const __bf16 *lf = split + (size_t)l * per_layer * X3_FRAG;
     ST_MARK(4 + 24 * l);
@@ -2547,20 +2585,20 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
         *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + col0) =
             make_float4(acc[rt][0] + bb.x, acc[rt][1] + bb.y, acc[rt][2] + bb.z, acc[rt][3] + bb.w);
     };
-    x3_load_frag(fb, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
-    proj_tile(0, fa);
-    x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
-    proj_tile(1, fb);
-    x3_load_frag(fb, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
-    proj_tile(2, fa);
-    x3_load_frag(fa, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // arrives during the attention
+    x3_load_frag(B, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
+    proj_tile(0, A);
+    x3_load_frag(A, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
+    proj_tile(1, B);
+    x3_load_frag(B, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
+    proj_tile(2, A);
+    x3_load_frag(A, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // arrives during the attention
     ST_MARK(4 + 24 * l + 1);
     __syncthreads();
     ST_MARK(4 + 24 * l + 2);
     {
       const AttSinkX3 sink{AT3, PE};
-      if (N <= 16) qa8_stage_attention_mfma_to<1>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
-      else if (N <= 32) qa8_stage_attention_mfma_to<2>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
+      if (N <= 16) qa8_stage_attention_mfma_pairs<1>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
+      else if (N <= 32) qa8_stage_attention_mfma_pairs<2>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
       else qa8_stage_attention_mfma_to<3>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
     }
     ST_MARK(4 + 24 * l + 3);
@@ -2572,8 +2610,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       const float4 bb = x3_ld4(L.out_proj_bias + cq), mean = x3_ld4(n1 + cq),
                    mult = x3_ld4(n1 + 128 + cq), beta = x3_ld4(n1 + 256 + cq);
       zero(acc);
-      x3_mma<RT16>(acc, AT3, PE, fb, lane);
-      x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
+      x3_mma<RT16>(acc, AT3, PE, B, lane);
+      x3_load_frag(B, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) {
         xres[rt].x = (acc[rt][0] + bb.x + xres[rt].x - mean.x) * mult.x + beta.x;
@@ -2597,8 +2635,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     {
       const float4 b1v = x3_ld4(L.ff0_bias + cq);
       zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, fa, lane);
-      if (nchunk > 1) x3_load_frag(fa, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
+      x3_mma<RT16>(acc, XB3, PE, A, lane);
+      if (nchunk > 1) x3_load_frag(A, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, AT3);
     }
@@ -2609,13 +2647,16 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       __bf16 *hcur = (ch & 1) ? H1 : AT3, *hnext = (ch & 1) ? AT3 : H1;
       const float4 b1v = x3_ld4(L.ff0_bias + (ch + 1) * 128 + cq);
       zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, fa, lane);                                   // up: slice ch + 1
-      if (ch + 2 < nchunk) x3_load_frag(fa, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      x3_mma<RT16>(acc, XB3, PE, A, lane);                                   // up: slice ch + 1
+      if (ch + 2 < nchunk) x3_load_frag(A, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
+      else x3_load_frag(A, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);   // the last ff.2 slice
       ST_MARK(4 + 24 * l + 9 + 3 * ch);
-      x3_mma<RT16>(gacc, hcur, PE, fb, lane, [&](int it) {                    // down: slice ch
+      x3_mma<RT16>(gacc, hcur, PE, B, lane, [&](int it) {                    // down: slice ch
         if (it < RT16) up_store(it, b1v, hnext);
       });
-      x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      if (ch + 2 < nchunk) x3_load_frag(B, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      else if (l + 1 < w.num_layers)
+        x3_load_frag(B, lf + (size_t)(per_layer + x3_frag_win(wave * 3)) * X3_FRAG, lane);   // next layer's first
       ST_MARK(4 + 24 * l + 10 + 3 * ch);
       __syncthreads();
       ST_MARK(4 + 24 * l + 11 + 3 * ch);
@@ -2625,9 +2666,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       const float *n2 = norms + (2 * l + 1) * 384;
       const float4 bb = x3_ld4(L.ff2_bias + cq), mean = x3_ld4(n2 + cq),
                    mult = x3_ld4(n2 + 128 + cq), beta = x3_ld4(n2 + 256 + cq);
-      if (l + 1 < w.num_layers)
-        x3_load_frag(fa, lf + (size_t)(per_layer + x3_frag_win(wave * 3)) * X3_FRAG, lane);
-      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, fb, lane);
+      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, A, lane);   // (hidden >= 256: see the loop)
       ST_MARK(4 + 24 * l + 21);
       // ---- y = BN2(y1 + g + b2): the next layer's input ----------------------------------------
 #pragma unroll
@@ -2641,6 +2680,10 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     }
     ST_MARK(4 + 24 * l + 23);
     __syncthreads();
+  };
+  for (int l = 0; l < w.num_layers; l += 2) {
+    layer(l, fa, fb);
+    if (l + 1 < w.num_layers) layer(l + 1, fb, fa);
   }
   ST_MARK(ST_SLOTS - 3);
   // ---- result: through the fp32 staging rows, coalesced 16-byte stores; the decoder's per-graph
@@ -2718,7 +2761,7 @@ static int launch_encoder_stack_x3(const vrp_encoder_weights *w, const float *x,
   return 0;
 }
 static bool encoder_stack_x3_applies(const vrp_encoder_weights *w) {
-  return encoder_x3_enabled(w) && w->num_layers <= 5;
+  return encoder_x3_enabled(w) && w->num_layers <= 5 && w->hidden >= 256;
 }
 
 // ---- out-proj + BN1 + FF + BN2 for LARGE row counts on the bf16 matrix cores -----------------
