@@ -306,17 +306,19 @@ _TRAIN_KEYS = ("du_max", "dlogp_step_max", "dlogp_acc_max")
 _TRAIN_FLOORS = (1e-5, 5e-6, 5e-6)   # half the eval-mode tolerances (2e-5 logits, 1e-5 log-prob)
 
 
-def _reference_to_oracle_ratio():
-    """Largest ratio (reference fp32 error) / (oracle fp32 error), both against fp64, over every
-    measured case whose errors are above the floors (below them the ratio is rounding noise and
-    the floors decide)."""
+def _reference_to_oracle_ratio(quantile=None):
+    """Ratio (reference fp32 error) / (oracle fp32 error), both against fp64, over every measured
+    case whose errors are above the floors (below them the ratio is rounding noise and the floors
+    decide): the largest one, or the given quantile of the sample (the maxima are heavy-tailed:
+    du_max 4.15 once and <= 1.65 otherwise, p95 1.43; dlogp_step_max max 1.55, p95 1.50;
+    dlogp_acc_max max 2.55, p95 1.46)."""
     st = _train_mode_statistics()
     out = []
     for k, fl in zip(_TRAIN_KEYS, _TRAIN_FLOORS):
         rs = [c["reference_fp32_vs_fp64"][k] / c["oracle_fp32_vs_fp64"][k]
               for c in st["cases"] + st["sweep"]
               if c["oracle_fp32_vs_fp64"][k] > fl / 2 and c["reference_fp32_vs_fp64"][k] > fl / 2]
-        out.append(max(rs))
+        out.append(max(rs) if quantile is None else float(np.percentile(rs, quantile)))
     return out
 
 
@@ -329,15 +331,19 @@ def _train_bounds(kind, B, N, o32):
     two legitimate fp32 evaluations (reference, oracle) 1.06e-4 from each other.
 
     The reference's error on THIS test's inputs is estimated from the fp32 oracle's (`o32`,
-    measured by the caller against the same fp64 trace) times the largest reference/oracle ratio
-    the committed measurements show (the maximum of an error trace is heavy-tailed: over the
-    random sweep the reference's maximum is up to that many times the oracle's on the same
-    inputs); where the shape has a committed measurement of its own, at least that."""
-    ratio = _reference_to_oracle_ratio()
+    measured by the caller against the same fp64 trace) times a reference/oracle ratio from the
+    committed measurements:
+      * a shape with a committed measurement of its own (the seven trainrollout_* fixtures): the
+        95th percentile of the ratio over the sweep (1.43 / 1.50 / 1.46), and at least the
+        reference's measured error on exactly that shape -- round 5; until then the sweep's single
+        4.15x outlier widened every bound;
+      * any other shape (tools/parity_sweep.py: random shapes and seeds, where a 1-in-20 tail event
+        of the ratio would be a 1-in-20 spurious failure): the largest ratio observed."""
+    own = [c for c in _train_mode_statistics()["cases"] if (c["kind"], c["B"], c["N"]) == (kind, B, N)]
+    ratio = _reference_to_oracle_ratio(95 if own else None)
     ref = [r * o for r, o in zip(ratio, o32)]
-    for c in _train_mode_statistics()["cases"]:
-        if (c["kind"], c["B"], c["N"]) == (kind, B, N):
-            ref = [max(a, c["reference_fp32_vs_fp64"][k]) for a, k in zip(ref, _TRAIN_KEYS)]
+    for c in own:
+        ref = [max(a, c["reference_fp32_vs_fp64"][k]) for a, k in zip(ref, _TRAIN_KEYS)]
     return tuple(2.0 * max(r, f) for r, f in zip(ref, _TRAIN_FLOORS))
 
 
@@ -507,7 +513,14 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     assert (loss - ol).abs().max().item() < TOL, (loss - ol).abs().max().item()
     acc_tol = TOL * (1 if greedy else max(1, T / 4))
     if train:
-        # against the fp64 sum, within twice the reference's own accumulated error
+        # against the fp64 sum, within twice the reference's own accumulated error -- and never
+        # below what an fp32 accumulator of that magnitude can resolve: the reference sums the
+        # step log-probs in fp32 (graph_tsp_agent.py:86), and next to a sum A one ulp is 2^-23 |A|
+        # (7.6e-6 at |A| in [64, 128): two legitimate fp32 sums of a 100-step episode differ by
+        # more than the 5e-6 floor of _TRAIN_FLOORS.  Round 5's random sweep, seed 12: VRP 1 x 32,
+        # |A| = 137: 1.6e-5 against the floor's 1.0e-5 -- the same number with every kernel of the
+        # round switched off, profiles/r05_parity_sweep_train.log)
+        acc_bound = max(acc_bound, 2.0 * 2.0 ** -23 * olp64.abs().max().item())
         acc_err = (logp.double() - olp64).abs().max().item()
         assert acc_err < (TOL if greedy else acc_bound), (acc_err, acc_bound)
         # two fp32 evaluations may sit on opposite sides of the exact value

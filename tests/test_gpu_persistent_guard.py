@@ -208,7 +208,7 @@ def _pair(tmp_path, extra_env, concurrent, shape=(1024, 40, 50)):
 
 
 @pytest.mark.parametrize("lease,shape", [("1", (1024, 40, 50)), ("0", (1024, 40, 50)),
-                                         ("0", (2048, 20, 600)), ("1", (2048, 20, 600))])
+                                         ("0", (2048, 20, 600))])
 def test_two_independent_processes_share_one_gpu(tmp_path, lease, shape):
     """50 sampled VRP-40 x 1024 rollouts + 5 REINFORCE epochs in each of two unrelated processes
     on cuda:0 at the same time, default settings.  lease=1: they take turns on the persistent
