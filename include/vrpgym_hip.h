@@ -30,7 +30,7 @@ extern "C" {
 
 /* Version of this header's struct layouts and entry points: vrp_abi_version() of a matching
  * library returns it; the shipped binding (vrpgym_hip/_lib.py: ABI_VERSION) refuses any other. */
-#define VRP_ABI_VERSION 7
+#define VRP_ABI_VERSION 8
 
 #define VRP_KIND_TSP 0
 #define VRP_KIND_VRP 1
@@ -39,6 +39,7 @@ extern "C" {
 #define VRP_EMB 128      /* embedding width the kernels are built for            */
 #define VRP_HEADS 8      /* decoder heads (agents/graph_tsp_agent.py:53-55)      */
 #define VRP_MAX_NODES 128
+#define VRP_MAX_LAYERS 16 /* encoder attention layers (graph_encoder.py:30-39 loops num_attention_layers freely) */
 
 /* ---- environment state (replaces the numpy attributes of TSPEnv/IRPEnv) ------ */
 #define VRP_ENV_RESET_ON_ROLLOUT 1 /* vrp_env.flags: vrp_rollout starts the episode itself --
@@ -94,13 +95,13 @@ typedef struct vrp_encoder_layer {
 } vrp_encoder_layer;
 
 typedef struct vrp_encoder_weights {
-  int32_t node_dim, depot_dim, hidden, num_layers;     /* 2|3, 2|0, 512, <=8 */
+  int32_t node_dim, depot_dim, hidden, num_layers;     /* 2|3, 2|0, 512, <= VRP_MAX_LAYERS */
   int32_t heads, reserved_;  /* encoder heads: 8 (0 = 8; every fused kernel), or 4 / 16 (head width
                               * 32 / 8: plain GEMM + per-(graph, head) VALU attention kernels, forward
                               * and backward; graph_encoder.py:170-172) */
   const float *node_embed_weight, *node_embed_bias;    /* (128,node_dim) */
   const float *depot_embed_weight, *depot_embed_bias;  /* (128,2) or NULL */
-  vrp_encoder_layer layer[8];
+  vrp_encoder_layer layer[VRP_MAX_LAYERS];
   const void *split;   /* vrp_encoder_prepare's output for THESE weights, or NULL.  With it the
                         * eval-mode kernels run their dense products on the bf16 matrix cores (each
                         * fp32 operand as three bf16 planes, six MFMAs per product: fp32 accuracy at
@@ -344,7 +345,7 @@ typedef struct vrp_encoder_layer_grads {
 } vrp_encoder_layer_grads;
 typedef struct vrp_encoder_grads {
   float *node_embed_weight, *node_embed_bias, *depot_embed_weight, *depot_embed_bias;
-  vrp_encoder_layer_grads layer[8];
+  vrp_encoder_layer_grads layer[VRP_MAX_LAYERS];
 } vrp_encoder_grads;
 
 /* N1-N3 in train mode with every intermediate kept on a tape (for the backward pass):

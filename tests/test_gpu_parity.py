@@ -611,6 +611,7 @@ def test_non_default_architecture_against_reference(name, path, mode):
 
 
 @pytest.mark.parametrize("hidden,layers,B,N,heads", [(200, 2, 600, 40, 8), (72, 5, 300, 80, 8),
+                                                     (256, 10, 600, 40, 8), (128, 9, 100, 20, 8),
                                                      (520, 1, 64, 20, 8), (512, 3, 600, 40, 4),
                                                      (256, 2, 300, 100, 16), (200, 2, 40, 128, 4)])
 def test_non_default_architecture_encoder_large(hidden, layers, B, N, heads):

@@ -189,7 +189,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(vrpgym_hip.DecoderWeights) == 11 * 8
     assert ctypes.sizeof(vrpgym_hip.RolloutIO) == 12 * 8   # + logit_clip (float, padded)
     assert ctypes.sizeof(vrpgym_hip.DecoderGrads) == 11 * 8
-    assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 24 + 4 * 8 + 8 * 18 * 8 + 8   # + heads, reserved_; split
+    assert ctypes.sizeof(vrpgym_hip.EncoderWeights) == 24 + 4 * 8 + 16 * 18 * 8 + 8   # + heads, reserved_; 16 layers; split
 
 
 def test_graft_entry_build():

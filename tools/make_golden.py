@@ -553,6 +553,7 @@ def gen_arch():
     for kind, hidden, layers, B, N, greedy, heads in [
             (0, 200, 2, 16, 12, True, 8), (1, 64, 3, 16, 12, False, 8), (2, 520, 1, 16, 12, True, 8),
             (1, 300, 4, 24, 20, True, 8),
+            (1, 256, 10, 16, 12, True, 8),   # more than eight layers (round 5: up to sixteen run)
             # encoder head counts other than eight (num_heads; the decoder keeps its eight,
             # graph_tsp_agent.py:53-55)
             (0, 512, 3, 16, 12, True, 4), (1, 512, 3, 24, 20, False, 16), (2, 200, 2, 16, 12, True, 16),

@@ -24,9 +24,10 @@ def check_supported_dims(emb_dim, num_heads, hidden_dim, decoder=False):
     """The kernels are specialised for the reference's embedding width (128) and, in the decoder,
     its eight heads (fixed by the reference too: graph_tsp_agent.py:53-55).  The encoder runs 8
     heads on every fused kernel and 4 or 16 heads (head width 32 / 8) on a plain GEMM + per-head
-    attention path, forward and backward; any `hidden_dim` >= 1 and up to eight attention layers
+    attention path, forward and backward; any `hidden_dim` >= 1 and up to sixteen attention layers
     run (a feed-forward width that is not a multiple of the kernels' 128-wide slices is
-    zero-padded to the next one, see `_PaddedFF`).  Other sizes can be constructed (state_dict
+    zero-padded to the next one, see `_PaddedFF`; more than eight layers run layer by layer instead
+    of through the one-launch stack kernel).  Other sizes can be constructed (state_dict
     compatibility) but not run."""
     if decoder:
         return emb_dim == EMB and num_heads == HEADS
@@ -158,8 +159,8 @@ def encoder_struct(enc):
     w = hip.EncoderWeights()
     w.node_dim, w.hidden, w.num_layers = node_dim, hp, len(enc.attention_layers)
     w.heads = heads
-    if w.num_layers > 8:
-        raise NotImplementedError("at most 8 attention layers")
+    if w.num_layers > hip.MAX_LAYERS:
+        raise NotImplementedError(f"at most {hip.MAX_LAYERS} attention layers")
     keep, padded = [], []
 
     def P(t):

@@ -3085,7 +3085,7 @@ static bool encoder_stack_applies(const vrp_encoder_weights *w, int train, int B
 }
 
 struct EncWs {
-  float *h0, *h1, *qkv, *att, *ff, *norm;  // norm: (16,384) eval-mode BN affines
+  float *h0, *h1, *qkv, *att, *ff, *norm;  // norm: (2 VRP_MAX_LAYERS, 384) eval-mode BN affines
   double *stats;
 };
 
@@ -3098,7 +3098,7 @@ static EncWs carve_encoder(void *ws, int B, int N, int hidden) {
   w.qkv = (float *)p;  p += vrp_align_up(R * 384 * 4);
   w.att = (float *)p;  p += vrp_align_up(R * 128 * 4);
   w.ff = (float *)p;   p += vrp_align_up(R * (size_t)hidden * 4);
-  w.norm = (float *)p; p += vrp_align_up(16 * 384 * 4);
+  w.norm = (float *)p; p += vrp_align_up(2 * VRP_MAX_LAYERS * 384 * 4);
   w.stats = (double *)p;
   return w;
 }
@@ -3107,7 +3107,7 @@ extern "C" int64_t vrp_encoder_workspace_bytes(int B, int N, int hidden) {
   const size_t R = (size_t)B * N;
   // + feature scratch used by vrp_rollout: x (R,3) fp32 and is_depot (R) u8
   return (int64_t)(3 * vrp_align_up(R * 128 * 4) + vrp_align_up(R * 384 * 4) +
-                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(16 * 384 * 4) +
+                   vrp_align_up(R * (size_t)hidden * 4) + vrp_align_up(2 * VRP_MAX_LAYERS * 384 * 4) +
                    bn_sums_bytes() + vrp_align_up(R * 12) + vrp_align_up(R));
 }
 
@@ -3117,7 +3117,7 @@ extern "C" int64_t vrp_encoder_split_bytes(int hidden, int num_layers) {
 }
 extern "C" int vrp_encoder_prepare(const vrp_encoder_weights *w, void *split, void *stream) {
   VRP_REQUIRE(w && split, "encoder_prepare: NULL argument");
-  VRP_REQUIRE(w->hidden >= 128 && w->hidden % 128 == 0 && w->num_layers >= 1 && w->num_layers <= 8,
+  VRP_REQUIRE(w->hidden >= 128 && w->hidden % 128 == 0 && w->num_layers >= 1 && w->num_layers <= VRP_MAX_LAYERS,
               "encoder_prepare: hidden=%d layers=%d", w->hidden, w->num_layers);
   const int threads = x3_layer_frags(w->hidden) * w->num_layers * 256;
   hipLaunchKernelGGL(x3_prepare_kernel, dim3((threads + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -3170,7 +3170,7 @@ __global__ __launch_bounds__(256) void rollout_setup_kernel(
 
 static int encoder_check(const vrp_encoder_weights *w, int B, int N) {
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder: bad shape B=%d N=%d", B, N);
-  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8, "encoder: num_layers=%d", w->num_layers);
+  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= VRP_MAX_LAYERS, "encoder: num_layers=%d", w->num_layers);
   VRP_REQUIRE(w->hidden % 128 == 0, "encoder: hidden=%d must be a multiple of 128", w->hidden);
   VRP_REQUIRE(enc_heads(w) == 8 || enc_heads(w) == 4 || enc_heads(w) == 16,
               "encoder: heads=%d (4, 8 or 16)", w->heads);
@@ -3396,7 +3396,7 @@ struct LayerTape {
   float *X, *QKV, *ATT, *Z1, *Y1, *H, *Z2, *stats1, *stats2;
 };
 struct EncTape {
-  LayerTape layer[8];
+  LayerTape layer[VRP_MAX_LAYERS];
   float *OUT;      // output of the last layer = emb copy is NOT kept; X of layer l+1 = out of l
   double *sums;    // 256 doubles: batch-statistic scratch
 };
@@ -3450,7 +3450,7 @@ extern "C" int vrp_encoder_forward_tape(const vrp_encoder_weights *w, int B, int
   VRP_REQUIRE(w && x && emb && tape, "encoder_tape: NULL argument");
   VRP_REQUIRE(B > 0 && N > 0 && N <= VRP_MAX_NODES, "encoder_tape: bad shape B=%d N=%d", B, N);
   VRP_REQUIRE(enc_heads(w) == 8 || enc_heads(w) == 4 || enc_heads(w) == 16, "encoder: heads=%d", w->heads);
-  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= 8 && w->hidden % 128 == 0,
+  VRP_REQUIRE(w->num_layers >= 1 && w->num_layers <= VRP_MAX_LAYERS && w->hidden % 128 == 0,
               "encoder_tape: unsupported architecture");
   hipStream_t st = (hipStream_t)stream;
   const int R = B * N, L_ = w->num_layers;

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 KIND_TSP, KIND_VRP, KIND_IRP = 0, 1, 2
-ABI_VERSION = 7   # include/vrpgym_hip.h: VRP_ABI_VERSION (struct layouts below mirror that header)
+MAX_LAYERS = 16   # VRP_MAX_LAYERS
+ABI_VERSION = 8   # include/vrpgym_hip.h: VRP_ABI_VERSION (struct layouts below mirror that header)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -36,7 +37,7 @@ class EncoderWeights(C.Structure):
                 ("num_layers", C.c_int32), ("heads", C.c_int32), ("reserved_", C.c_int32),
                 ("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
                 ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
-                ("layer", EncoderLayer * 8), ("split", c_vp)]
+                ("layer", EncoderLayer * MAX_LAYERS), ("split", c_vp)]
 
 
 class EncoderLayerGrads(C.Structure):
@@ -51,7 +52,7 @@ class EncoderGrads(C.Structure):
     """struct vrp_encoder_grads"""
     _fields_ = [("node_embed_weight", c_vp), ("node_embed_bias", c_vp),
                 ("depot_embed_weight", c_vp), ("depot_embed_bias", c_vp),
-                ("layer", EncoderLayerGrads * 8)]
+                ("layer", EncoderLayerGrads * MAX_LAYERS)]
 
 
 class DecoderWeights(C.Structure):
