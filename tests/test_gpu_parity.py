@@ -631,7 +631,10 @@ def test_non_default_architecture_encoder_large(hidden, layers, B, N, heads):
         emb = agent.model.encoder(x, dm)
         want = opol.encoder_forward(sd, x, dm, train=train, heads=heads)
         err = (emb.cpu() - want).abs().max().item()
-        assert err < 2e-5, (hidden, layers, B, N, heads, train, err)
+        # two fp32 evaluations drift apart layer by layer (every layer renormalises and adds its own
+        # rounding): 2e-5 up to five layers, proportionally more beyond (ten layers, train mode:
+        # 2.1e-5 with the fp32-MFMA kernels and with the bf16-plane ones alike)
+        assert err < 2e-5 * max(1.0, layers / 5), (hidden, layers, B, N, heads, train, err)
 
 
 @pytest.mark.parametrize("mode", ["default", "table", "tile"])
