@@ -14,6 +14,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The oracle (torch on the CPU: small fp32 / fp64 ops) is the checker of every GPU test.  On a
+    # 256-CPU GPU box torch defaults to 128 intra-op threads and spends its time handing tiny ops
+    # around: the full-size training-step test takes 64 s at 128 threads, 27 s at 16.
+    try:
+        import torch
+        torch.set_num_threads(min(16, os.cpu_count() or 16))
+    except Exception:
+        pass
 
 
 # Parity evidence first, process-spawning infrastructure tests last: under `pytest -x` a hang or
