@@ -5,6 +5,7 @@ collectives run over gloo (VRPGYM_BENCH_ONE_GPU=1, flagged in the JSON line)."""
 import json
 import os
 import sys
+import warnings
 
 import pytest
 import torch
@@ -14,13 +15,38 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _proc  # noqa: E402
 
 
+# A rank that SHARES cuda:0 with other ranks died of this once in about thirty start-ups of the
+# eight-rank training run on the round-5 pool (2 of 56; none in ~600 steady-state epochs of the same
+# eight ranks, none with serialized launches, none under tools/micro/queue_churn, and it happened
+# with and without the persistent step kernel): DESIGN.md 6.1 has the evidence.  The abort comes
+# from the runtime's queue-error callback, names no kernel and kills the rank.  One GPU per
+# process -- the product's deployment -- has never shown it.  The one-GPU test aid starts such a run
+# again ONCE and says so; a second abort, or any other failure, fails the test.
+SHARED_GPU_ABORT = "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION"
+SHARED_GPU_RESTARTS = []   # (args, first stderr line of the abort) of every restart of this session
+
+
 def _bench(args, extra_env=None, timeout=_proc.SUBPROCESS_TIMEOUT, env=None):
     """bench.py in a process group of its own that cannot outlive the test (tests/_proc.py; the
     launcher inside bench.py gives its ranks the same property)."""
     if env is None:
         env = dict(os.environ)
     env.update(extra_env or {})
-    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, timeout=timeout)
+    shared = env.get("VRPGYM_BENCH_ONE_GPU") == "1" and "--gpus" in args
+    for attempt in range(2):
+        p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, timeout=timeout)
+        if p.returncode == 0 or attempt or not (shared and SHARED_GPU_ABORT in p.stderr):
+            break
+        line = next(l for l in p.stderr.splitlines() if SHARED_GPU_ABORT in l)
+        SHARED_GPU_RESTARTS.append((" ".join(args), line))
+        warnings.warn("ranks sharing cuda:0: one rank aborted (%s); run started again once: %s"
+                      % (SHARED_GPU_ABORT, " ".join(args)))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "shared_gpu_restarts.log"), "a") as fh:
+                fh.write(" ".join(args) + "\n" + line + "\n")
+        except OSError:
+            pass
     if p.returncode != 0:
         # the tail of a torchrun failure is its summary table; keep the whole stream where a
         # gpurun call brings it back, and put the lines that name the cause in front
@@ -212,3 +238,33 @@ def test_bench_single_rank_line_has_contract_keys():
     for name in ("vrp40_b2048_train", "irp40_b1024_train", "vrp100_b2048"):
         assert "error" not in out["other_configs"][name], out["other_configs"][name]
         assert out["other_configs"][name]["ms_per_step"] > 0
+
+
+def test_shared_gpu_abort_restarts_once_and_only_for_that_abort(monkeypatch, tmp_path):
+    """The one-GPU aid's restart rule: once, for the queue-error abort of a rank that shares cuda:0,
+    recorded; everything else -- and a second abort -- is a failure."""
+    class P:
+        def __init__(self, rc, err):
+            self.returncode, self.stderr, self.stdout = rc, err, ""
+    abort = ":0:rocdevice.cpp :3676: Callback: Queue 0x1 aborting with error : " + SHARED_GPU_ABORT
+    script = []
+    calls = []
+
+    def fake_run(cmd, env=None, timeout=None):
+        calls.append(cmd)
+        return script.pop(0)
+    monkeypatch.setattr(_proc, "run", fake_run)
+    one = {"VRPGYM_BENCH_ONE_GPU": "1"}
+    del SHARED_GPU_RESTARTS[:]
+    with pytest.warns(UserWarning, match="started again once"):
+        script[:] = [P(134, abort), P(0, "")]
+        assert _bench(["--gpus", "8"], dict(one)).returncode == 0 and len(calls) == 2
+    assert len(SHARED_GPU_RESTARTS) == 1 and SHARED_GPU_ABORT in SHARED_GPU_RESTARTS[0][1]
+    with pytest.warns(UserWarning):
+        script[:] = [P(134, abort), P(134, abort)]
+        assert _bench(["--gpus", "8"], dict(one)).returncode == 134 and len(calls) == 4
+    script[:] = [P(1, "RuntimeError: something else")]
+    assert _bench(["--gpus", "8"], dict(one)).returncode == 1 and len(calls) == 5
+    script[:] = [P(134, abort)]           # one process per GPU: never restarted
+    env = {k: v for k, v in os.environ.items() if k != "VRPGYM_BENCH_ONE_GPU"}
+    assert _bench(["--gpus", "8"], env=env).returncode == 134 and len(calls) == 6
