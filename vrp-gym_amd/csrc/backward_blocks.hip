@@ -9,8 +9,10 @@
 // Everything is fp32; reductions over rows are done in a fixed order (no float atomics), so
 // gradients are bitwise reproducible.
 #include "common.h"
+#include "x3_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ C = X^T Y (split over rows)
 // X (R,N1), Y (R,N2) row-major.  Workgroup (tile i, tile j, split s) computes the 128x128
@@ -104,6 +106,131 @@ __global__ __launch_bounds__(256, TN_MINWG) void gemm_tn_kernel(const float *__r
       }
 }
 
+// ---- the same product on the bf16 matrix cores (round 5; x3_common.h): every fp32 operand as three
+// bf16 planes, six v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation -- the fp32 MFMA's
+// accuracy (tools/gemm_tn_probe.py: relative error 5e-7 either way).  The inner dimension of this
+// product is the ROW index, so an MFMA operand is eight consecutive rows of one column: a thread
+// fetches rows r .. r + 7 of its four columns (eight 16-byte loads; a wave's load instruction covers
+// two whole 512-byte rows), which IS the 8-value chunk of each of those columns -- the
+// transposition happens in registers, for free.  It splits the four chunks and stores the planes as
+// 16-byte pieces: LDS image [plane][chunk of 8 rows][slot], slot(col) = (col & 3) * 32 +
+// ((col >> 2) + 4 (col & 3)) % 32 -- the store instruction of component c writes 32 consecutive
+// slots, and the 16 columns of an operand read fall on 16 different 16-byte bank groups
+// (SQ_LDS_BANK_CONFLICT = 0).  Waves 2 x 2, a wave owns 4 x 4 tiles of 16 x 16 (64 accumulator
+// registers); a 32-row slab = one MFMA k-step: 24 operand reads, 96 MFMAs per wave; two workgroups
+// per CU.  Measured on one box (81920 rows, product + slab sum): 128 x 512 116 -> 82 us, 384 x 128
+// 96 -> 70 us, 384 x 384 (102400 rows) 328 -> 211 us: 130-143 fp32-equivalent TFLOP/s, which is what
+// a bare loop of these MFMAs reaches on this device (tools/micro/bf16x3_probe: 127-148).  Built and
+// measured, not kept: two LDS buffers with the next slab's split between the MFMAs (one workgroup
+// per CU, one barrier per slab: 93 us), the tiles of a row split on one XCD (no change: the repeated
+// reads already hit the last-level cache), three workgroups per CU (spills: 143 us).
+#define TNX_PLANE (4 * 128 * 8)   // bf16 per plane of a 32-row x 128-column block
+__device__ __forceinline__ int tnx_slot(int col) { return (col & 3) * 32 + (((col >> 2) + 4 * (col & 3)) & 31); }
+__global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float *__restrict__ X, int ldx,
+                                                            const float *__restrict__ Y, int ldy,
+                                                            float *__restrict__ slabs, int R, int N1,
+                                                            int N2, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ps[2 * 3 * TNX_PLANE];   // X planes, Y planes: 48 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128, sp = blockIdx.z;
+  const int r_begin = sp * rows_per_split;
+  const int r_end = min(R, r_begin + rows_per_split);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loader role: matrix (X / Y), chunk of 8 rows, group of 4 columns
+  const int which = tid >> 7, chunk = (tid >> 5) & 3, cg = tid & 31;
+  const float *src = which ? Y + j0 + 4 * cg : X + i0 + 4 * cg;
+  const int lds = which ? ldy : ldx;
+  // Two slabs ahead: a slab's rows are requested two stages before the stage that splits them.
+  // The loads are UNCONDITIONAL (row index clamped, rows outside the split zeroed on arrival):
+  // behind a branch the compiler cannot count what is in flight and waits for everything, i.e. for
+  // the slab requested a moment ago (92 us instead of 82 at 128 x 512).
+  float4 v0[8], v1[8];
+  auto fetch = [&](float4 (&v)[8], int r0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = r0 + 8 * chunk + e;
+      v[e] = *reinterpret_cast<const float4 *>(src + (size_t)min(r, R - 1) * lds);
+    }
+  };
+  auto mask = [&](float4 (&v)[8], int r0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (r0 + 8 * chunk + e >= r_end) v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  bf16x8 *const mine = reinterpret_cast<bf16x8 *>(Ps + which * 3 * TNX_PLANE) + chunk * 128;
+  auto store = [&](const float4 (&v)[8]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float x8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x8[e] = c == 0 ? v[e].x : c == 1 ? v[e].y : c == 2 ? v[e].z : v[e].w;
+      bf16x8 h, m, l;
+      x3_split8(x8, h, m, l);
+      const int slot = c * 32 + ((cg + 4 * c) & 31);
+      mine[slot] = h;
+      mine[slot + TNX_PLANE / 8] = m;
+      mine[slot + 2 * (TNX_PLANE / 8)] = l;
+    }
+  };
+  // operand addresses: plane 0 of chunk q, this lane's column of tile t
+  const bf16x8 *xa[4], *yb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xa[t] = reinterpret_cast<const bf16x8 *>(Ps) + q * 128 + tnx_slot(wm * 64 + 16 * t + i16);
+    yb[t] = reinterpret_cast<const bf16x8 *>(Ps + 3 * TNX_PLANE) + q * 128 + tnx_slot(wn * 64 + 16 * t + i16);
+  }
+  auto mma = [&]() {
+    bf16x8 a[4][3], b[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[t][p] = xa[t][p * (TNX_PLANE / 8)];
+        b[t][p] = yb[t][p * (TNX_PLANE / 8)];
+      }
+    // small terms first: m m', h l', l h', h m', m h', h h' (16 independent accumulators per term)
+#define TNX_TERM(PA, PB)                                                       \
+  _Pragma("unroll") for (int ta = 0; ta < 4; ++ta)                             \
+  _Pragma("unroll") for (int tb = 0; tb < 4; ++tb)                             \
+      acc[ta][tb] = X3_MFMA(a[ta][PA], b[tb][PB], acc[ta][tb]);
+    TNX_TERM(1, 1) TNX_TERM(0, 2) TNX_TERM(2, 0) TNX_TERM(0, 1) TNX_TERM(1, 0) TNX_TERM(0, 0)
+#undef TNX_TERM
+  };
+  fetch(v0, r_begin);
+  fetch(v1, r_begin + 32);
+  for (int r0 = r_begin; r0 < r_end; r0 += 64) {
+    mask(v0, r0);
+    store(v0);
+    __syncthreads();
+    fetch(v0, r0 + 64);
+    mma();
+    __syncthreads();
+    if (r0 + 32 < r_end) {   // (uniform)
+      mask(v1, r0 + 32);
+      store(v1);
+      __syncthreads();
+      fetch(v1, r0 + 96);
+      mma();
+      __syncthreads();
+    }
+  }
+  // D[i = 4 q + e][j = i16] of tile (ta, tb)
+  float *out = slabs + (size_t)sp * N1 * N2;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        out[(size_t)(i0 + wm * 64 + 16 * ta + 4 * q + e) * N2 + j0 + wn * 64 + 16 * tb + i16] = acc[ta][tb][e];
+}
+
 // C[i] (+)= sum_s slabs[s][i]
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs,
                                                           float *__restrict__ C, size_t n,
@@ -155,8 +282,13 @@ int vrp_launch_gemm_tn(const float *X, int ldx, const float *Y, int ldy, float *
   int rps = (R + nsplit - 1) / nsplit;
   rps = (rps + TN_BR - 1) / TN_BR * TN_BR;
   nsplit = (R + rps - 1) / rps;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 128, N2 / 128, nsplit), dim3(256), 0, st, X, ldx, Y,
-                     ldy, (float *)slab_ws, R, N1, N2, rps);
+  static const bool fp32 = getenv("VRP_GEMM_FP32") != nullptr;   // A/B aid: the fp32-MFMA kernel
+  if (fp32)
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(N1 / 128, N2 / 128, nsplit), dim3(256), 0, st, X, ldx, Y,
+                       ldy, (float *)slab_ws, R, N1, N2, rps);
+  else
+    hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3(N1 / 128, N2 / 128, nsplit), dim3(256), 0, st, X, ldx,
+                       Y, ldy, (float *)slab_ws, R, N1, N2, rps);
   VRP_CHECK_LAUNCH("gemm_tn");
   const size_t n = (size_t)N1 * N2;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
