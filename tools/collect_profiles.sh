@@ -40,5 +40,6 @@ VRP_GEMM_VARIANT=rows rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCL
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc/lds_tsp40 -o p -- python3 tools/rollout_loop.py 0 40 8192 3 > $OUT/pmc_lds.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc/lds_tsp20 -o p -- python3 tools/rollout_loop.py 0 20 512 10 > $OUT/pmc_lds20.log 2>&1
 { echo "== bias + residual + ReLU (gemm_rows_kernel)"; VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only (N = 384 / 256, K = 128: gemm_rows_wide_kernel)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only, VRP_GEMM_ROWS_NARROW=1 (gemm_rows_kernel everywhere)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_ROWS_NARROW=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; } > $OUT/gemm_rows_probe.txt
-python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R=" > $OUT/gemm_tn_probe.txt
+{ echo "== gemm_tn_x3_kernel (bf16 planes, the default)"; python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R="; echo "== VRP_GEMM_FP32=1: gemm_tn_kernel (fp32 MFMA), same box"; VRP_GEMM_FP32=1 python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R="; } > $OUT/gemm_tn_probe.txt
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc/lds_gemm_tn -o p -- python3 tools/gemm_tn_probe.py > $OUT/pmc_lds_gemm_tn.log 2>&1
 ls $OUT

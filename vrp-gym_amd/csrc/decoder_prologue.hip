@@ -175,10 +175,13 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
       const int row = 16 * r + j16;
       const float4 *src = reinterpret_cast<const float4 *>(
           p.emb + (R0 + (row < valid ? row : 0)) * VRP_EMB + koff);
+      // UNCONDITIONAL loads (a padding row reads the pack's row 0: finite values whose products are
+      // never stored -- rows and columns of the tables do not mix): behind a branch the compiler
+      // cannot count the requests in flight and makes the first use wait for everything, i.e. for
+      // the table stores issued after these loads
 #pragma unroll
       for (int k4 = 0; k4 < 8; ++k4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < valid) v = src[k4];
+        const float4 v = src[k4];
         ef[r][4 * k4] = v.x; ef[r][4 * k4 + 1] = v.y; ef[r][4 * k4 + 2] = v.z; ef[r][4 * k4 + 3] = v.w;
       }
     }
