@@ -436,3 +436,30 @@ def test_full_size_training_step_against_oracle_autograd(kind, B, N):
     # not the limit, fp32 accumulation at this size is (B = 16, smoke(): 1.7e-4).
     assert worst < 3e-2, (worst, worst_name)
     assert worst_fro < 5e-3, (worst_fro, worst_fro_name)   # measured 1.3e-3 / 8.0e-4
+
+
+def test_step_accounting_does_not_keep_rollouts_alive():
+    """runtime.ROLLOUT_LOG (bench.py's step accounting) keeps a rollout's done flags, not the
+    RolloutResult: a logged result held the 0.7 GB tape of every training rollout of the timed
+    epochs (round 5: eight ranks x 100 epochs ran one GPU out of memory)."""
+    import gc
+    import agents
+    from agents import runtime
+    from gym_vrp.envs import IRPEnv
+    agent = agents.IRPAgent(seed=69)
+    agent.model.train()
+    env = IRPEnv(20, 64, 1, 69)
+    runtime.ROLLOUT_LOG = log = []
+    try:
+        res = runtime.rollout(agent.model, env, greedy=False, train=True, record=True)
+    finally:
+        runtime.ROLLOUT_LOG = None
+    assert len(log) == 1 and isinstance(log[0], runtime.RolloutSteps)
+    assert not hasattr(log[0], "tape") and not hasattr(log[0], "emb")
+    assert res.tape is not None
+    T = res.T
+    env._last_rollout = None
+    del res
+    gc.collect()
+    assert log[0].T == T     # the flags outlive the result, and they are all the entry holds
+    assert all(not isinstance(v, torch.Tensor) or v.numel() <= 4 * 20 for v in vars(log[0]).values())
