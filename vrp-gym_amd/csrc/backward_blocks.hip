@@ -119,11 +119,15 @@ __global__ __launch_bounds__(256, TN_MINWG) void gemm_tn_kernel(const float *__r
 // (SQ_LDS_BANK_CONFLICT = 0).  Waves 2 x 2, a wave owns 4 x 4 tiles of 16 x 16 (64 accumulator
 // registers); a 32-row slab = one MFMA k-step: 24 operand reads, 96 MFMAs per wave; two workgroups
 // per CU.  Measured on one box (81920 rows, product + slab sum): 128 x 512 116 -> 82 us, 384 x 128
-// 96 -> 70 us, 384 x 384 (102400 rows) 328 -> 211 us: 130-143 fp32-equivalent TFLOP/s, which is what
-// a bare loop of these MFMAs reaches on this device (tools/micro/bf16x3_probe: 127-148).  Built and
-// measured, not kept: two LDS buffers with the next slab's split between the MFMAs (one workgroup
-// per CU, one barrier per slab: 93 us), the tiles of a row split on one XCD (no change: the repeated
-// reads already hit the last-level cache), three workgroups per CU (spills: 143 us).
+// 96 -> 70 us, 384 x 384 (102400 rows) 328 -> 211 us: 130-143 fp32-equivalent TFLOP/s.  Ablation at
+// 128 x 512 (82 us with the 9 us slab sum): without the splits 70, without the loads 79, without
+// both 67, without the MFMAs 23 -- the MFMA phase of a slab (24 operand reads behind a barrier, 96
+// MFMAs, a barrier) runs at under half the pipe's rate (26 us of MFMA issue at 16 cycles each,
+// tools/micro/mfma_rate): per slab pair a CU's LDS is busy 2.3 k cycles next to the matrix pipe's
+// 3.1 k, and the two resident workgroups overlap the two only partly.  Built and measured, not
+// kept: two LDS buffers with the next slab's split between the MFMAs (one workgroup per CU, one
+// barrier per slab: 93 us), the tiles of a row split on one XCD (no change: the repeated reads
+// already hit the last-level cache), three workgroups per CU (spills: 143 us).
 #define TNX_PLANE (4 * 128 * 8)   // bf16 per plane of a 32-row x 128-column block
 __device__ __forceinline__ int tnx_slot(int col) { return (col & 3) * 32 + (((col >> 2) + 4 * (col & 3)) & 31); }
 __global__ __launch_bounds__(256, 2) void gemm_tn_x3_kernel(const float *__restrict__ X, int ldx,
