@@ -96,8 +96,18 @@ struct PrologueParams {
 // and reused by all twelve (projection, column tile) products: six v_mfma_f32_16x16x32_bf16 per
 // 32 k instead of eight v_mfma_f32_16x16x4_f32 at a sixteenth of the rate.  The accumulator
 // layout is the same, so stage 2 (fp32 MFMA straight from the accumulators) is untouched.
+// Waves per workgroup of the X3 instances: EIGHT, two per SIMD, on the one copy of the head's weight
+// fragments in LDS (147 KB: one workgroup per CU either way).  The fp32 instances need up to 392
+// registers and run one wave per SIMD; an X3 instance of up to four row tiles takes 184 + its 24 RT_
+// accumulators, so two waves fit the 512-entry file with 24 (three tiles) to 104 (four) registers
+// spilled -- and still the second wave fills more of the first one's stalls than the spills cost:
+// 1246 -> 1157 us at TSP 8192 x 40, 49.3 -> 45.4 us at 512 x 20 (one box, rocprofv3).
+#ifndef PT_X3_WAVES
+#define PT_X3_WAVES 8
+#endif
 template <int RT_, bool VEC, bool RING = (RT_ > 5), bool X3 = false>
-__global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams p) {
+__global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_tables_kernel(PrologueParams p) {
+  constexpr int NWV = X3 ? PT_X3_WAVES : 4, NTH = 64 * NWV;
   static_assert(!(X3 && RING), "the x3 stage 1 serves the whole-pack (non-ring) instances");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                              // [4][48][PT_LD] weight slices of this head, or
@@ -113,15 +123,15 @@ __global__ __launch_bounds__(256, 1) void prologue_tables_kernel(PrologueParams 
   // one XCD at about the same time and share its embedding rows through that L2
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int h = jj & 7, sub = jj >> 3, nsub = gridDim.x >> 6;
-  const int stride = 8 * nsub * 4;
-  const int first = (xcd * nsub + sub) * 4 + wave;
+  const int stride = 8 * nsub * NWV;
+  const int first = (xcd * nsub + sub) * NWV + wave;
   const bool fold = p.kind == VRP_KIND_IRP;
 
   if constexpr (X3) {
     const float4 *src = reinterpret_cast<const float4 *>(p.WprojX3 + (size_t)h * 12 * X3_FRAG);
-    for (int i = tid; i < 12 * X3_FRAG / 8; i += 256) reinterpret_cast<float4 *>(lds)[i] = src[i];
+    for (int i = tid; i < 12 * X3_FRAG / 8; i += NTH) reinterpret_cast<float4 *>(lds)[i] = src[i];
   } else {
-    for (int i = tid; i < 4 * 48 * 32; i += 256) {
+    for (int i = tid; i < 4 * 48 * 32; i += NTH) {
       const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
       const float4 v = *reinterpret_cast<const float4 *>(
           p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
@@ -528,9 +538,10 @@ static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
   }
   // one workgroup per CU (100 - 150 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
   // batch has fewer packs than wave slots
+  constexpr int NWV = X3 ? PT_X3_WAVES : 4;
   int nsub = 4;
-  while (nsub > 1 && 8 * (nsub / 2) * 4 >= p.npacks) nsub /= 2;
-  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>), dim3(64 * nsub), dim3(256), lds, st, p);
+  while (nsub > 1 && 8 * (nsub / 2) * NWV >= p.npacks) nsub /= 2;
+  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>), dim3(64 * nsub), dim3(64 * NWV), lds, st, p);
   VRP_CHECK_LAUNCH("prologue_tables");
   return 0;
 }
@@ -576,7 +587,8 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
     for (int g = G; g >= 1; --g) {
       const int tiles = (g * N + 15) / 16;
       if (tiles > max_tiles && g > 1) continue;
-      const long units = (long)((B + g - 1) / g) * 8, cost = ((units + 1023) / 1024) * tiles;
+      const long slots = 256 * PT_X3_WAVES;   // waves of one launch
+      const long units = (long)((B + g - 1) / g) * 8, cost = ((units + slots - 1) / slots) * tiles;
       if (!best || cost < best_cost) { best = g; best_cost = cost; }
     }
     G = best;
