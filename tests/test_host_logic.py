@@ -386,3 +386,17 @@ def test_host_side_under_sanitizers():
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "SANITIZED-OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+
+
+def test_gemm_tn_x3_lds_slot_map_is_a_conflict_free_permutation():
+    """The LDS image of csrc/backward_blocks.hip:gemm_tn_x3_kernel puts column `col` of a 32-row slab
+    at 16-byte slot (col & 3) * 32 + ((col >> 2) + 4 (col & 3)) % 32 of its (plane, 8-row chunk): a
+    permutation of the 128 columns in which (a) the store instruction of component c (lane cg writes
+    column 4 cg + c) covers 32 CONSECUTIVE slots and (b) the 16 columns an MFMA operand read touches
+    (16 t .. 16 t + 15) fall on 16 different 16-byte groups of the 256-byte bank row."""
+    slot = lambda col: (col & 3) * 32 + (((col >> 2) + 4 * (col & 3)) & 31)
+    assert sorted(slot(c) for c in range(128)) == list(range(128))
+    for c in range(4):
+        assert sorted(slot(4 * cg + c) for cg in range(32)) == list(range(32 * c, 32 * c + 32))
+    for t in range(8):
+        assert len({slot(16 * t + i) % 16 for i in range(16)}) == 16
