@@ -400,3 +400,43 @@ def test_gemm_tn_x3_lds_slot_map_is_a_conflict_free_permutation():
         assert sorted(slot(4 * cg + c) for cg in range(32)) == list(range(32 * c, 32 * c + 32))
     for t in range(8):
         assert len({slot(16 * t + i) % 16 for i in range(16)}) == 16
+
+
+def test_three_bf16_planes_carry_an_fp32_product():
+    """The arithmetic of csrc/x3_common.h restated in numpy (no GPU): x = h + m + l with h = bf16(x),
+    m = bf16(x - h), l = bf16(x - h - m) (round to nearest even, the subtractions exact), and
+    x y ~ mm' + hl' + lh' + hm' + mh' + hh' accumulated in fp32 (small terms first).  Against fp64
+    the six-product sum is as accurate as an fp32 fma chain; two planes (three products) are not."""
+    import numpy as np
+
+    def bf16(x):  # RNE to bfloat16, returned as float32
+        b = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+        b = (b + 0x7FFF + ((b >> 16) & 1)) & 0xFFFF0000
+        return b.astype(np.uint32).view(np.float32)
+
+    rng = np.random.default_rng(0)
+    K = 128
+    a = rng.standard_normal((256, K)).astype(np.float32)
+    b = rng.standard_normal((256, K)).astype(np.float32)
+    ah = bf16(a); am = bf16(a - ah); al = bf16(a - ah - am)
+    bh = bf16(b); bm = bf16(b - bh); bl = bf16(b - bh - bm)
+    # the split is exact up to 2^-24 |x| (three 8-bit mantissas cover fp32's 24 bits)
+    assert np.all(np.abs(a.astype(np.float64) - (ah.astype(np.float64) + am + al)) <= 2.0 ** -23 * np.abs(a))
+    ref = (a.astype(np.float64) * b.astype(np.float64)).sum(1)
+
+    def acc(terms):  # one MFMA = the 32 products of a k-chunk summed, then ONE fp32 add to the accumulator
+        s = np.zeros(256, np.float32)
+        for k0 in range(0, K, 32):
+            for x, y in terms:   # bf16 x bf16 is exact in fp32; the chunk sum in fp64 stands for the
+                d = (x[:, k0:k0 + 32].astype(np.float64) * y[:, k0:k0 + 32]).sum(1)   # pipe's wide adder
+                s = (s.astype(np.float64) + d).astype(np.float32)
+        return s
+
+    six = acc([(am, bm), (ah, bl), (al, bh), (ah, bm), (am, bh), (ah, bh)])
+    three = acc([(ah, bm), (am, bh), (ah, bh)])
+    chain = np.zeros(256, np.float32)
+    for k in range(K):
+        chain = (chain + (a[:, k].astype(np.float64) * b[:, k]).astype(np.float32)).astype(np.float32)
+    rms = lambda v: float(np.sqrt(np.mean((v.astype(np.float64) - ref) ** 2)))
+    assert rms(six) <= 1.5 * rms(chain)          # fp32 accuracy
+    assert rms(three) > 5 * rms(six)             # two planes are not enough
