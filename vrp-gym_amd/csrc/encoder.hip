@@ -1291,6 +1291,85 @@ __device__ __forceinline__ void qa8_stage_attention_mfma_pairs(const float *Q_s,
   for (; g + 1 < graphs; g += 2) qa8_attention_group<NT, 2>(Q_s, N, g, max_row, sink, lane, wave);
   if (g < graphs) qa8_attention_group<NT, 1>(Q_s, N, g, max_row, sink, lane, wave);
 }
+// ---- the same attention, one QUERY ROW PER LANE, no matrix cores (round 6) ---------------------
+// For the stack kernels' tiles (rows = graphs * N <= 48 <= 64 lanes; wave = head): a (graph, head)
+// pair is 2 * 16 * N^2 multiply-adds per product -- at N = 20 the two products of the CU's
+// sixteen pairs are 400 packed-FMA wave instructions per SIMD, while the MFMA form above pads 20
+// keys and 20 queries to 32 x 32, runs on the fp32 MFMA (1/16 of the bf16 rate), and strings LDS
+// reads -> score MFMAs -> two cross-lane maxima -> exponentials -> two cross-lane sums -> value
+// MFMAs into one dependency chain per graph: 10-12 k cycles per layer in the round-5 trace, a
+// fifth of the kernel.  Here a lane keeps its query, its running maximum / sum and its 16 output
+// columns in registers and walks its graph's keys four at a time (online softmax: the rescale of
+// a block of four keys is one exponential and eight packed multiplies); the K / V rows are
+// 16-byte LDS reads that every lane of a graph makes at the same address (broadcast).  No
+// cross-lane step, no padding work, nothing on the matrix pipe.  The exponent is exp2((s - m) *
+// log2 e): the rounding of that product is a relative error of 6e-8 * (1 + |s - m|) on a weight
+// e^-(m - s), i.e. at most 3e-8 of the largest weight.
+template <typename Sink>
+__device__ __forceinline__ void qa8_stage_attention_valu(const float *Q_s, int N, int rows,
+                                                         Sink sink, int lane, int wave) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int h = wave;
+  const int r = min(lane, rows - 1);          // idle lanes shadow the last row (nothing stored)
+  const int kb = (r / N) * N;                 // first row of this lane's graph
+  const float *qrow = Q_s + r * QA_QLD + h * 16;
+  f32x2 q2[8], o2[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 t = *reinterpret_cast<const float4 *>(qrow + 4 * j);
+    q2[2 * j] = f32x2{t.x * 0.25f, t.y * 0.25f};           // 1/sqrt(16), exact
+    q2[2 * j + 1] = f32x2{t.z * 0.25f, t.w * 0.25f};
+    o2[2 * j] = f32x2{0.f, 0.f};
+    o2[2 * j + 1] = f32x2{0.f, 0.f};
+  }
+  const float l2e = 1.44269504088896341f;
+  float m = -INFINITY, l = 0.f;
+  const float *kbase = Q_s + kb * QA_QLD + 128 + h * 16;
+  for (int n0 = 0; n0 < N; n0 += 4) {
+    float sc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float *kr = kbase + min(n0 + i, N - 1) * QA_QLD;
+      f32x2 a = {0.f, 0.f}, b = {0.f, 0.f};                // two chains of four
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4 *>(kr + 4 * j);
+        a = __builtin_elementwise_fma(q2[2 * j], f32x2{t.x, t.y}, a);
+        b = __builtin_elementwise_fma(q2[2 * j + 1], f32x2{t.z, t.w}, b);
+      }
+      a += b;
+      sc[i] = (n0 + i < N) ? a.x + a.y : -INFINITY;
+    }
+    const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+    const float corr = __builtin_amdgcn_exp2f((m - mn) * l2e);   // first block: exp2(-inf) = 0
+    float pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[i] = __builtin_amdgcn_exp2f((sc[i] - mn) * l2e);
+    l = fmaf(l, corr, (pw[0] + pw[1]) + (pw[2] + pw[3]));
+    m = mn;
+    const f32x2 c2 = {corr, corr};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o2[j] *= c2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float *vr = kbase + 128 + min(n0 + i, N - 1) * QA_QLD;
+      const f32x2 p2 = {pw[i], pw[i]};                     // 0 for a key past the graph's last
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 t = *reinterpret_cast<const float4 *>(vr + 4 * j);
+        o2[2 * j] = __builtin_elementwise_fma(p2, f32x2{t.x, t.y}, o2[2 * j]);
+        o2[2 * j + 1] = __builtin_elementwise_fma(p2, f32x2{t.z, t.w}, o2[2 * j + 1]);
+      }
+    }
+  }
+  if (lane < rows) {
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      sink(lane, h * 16 + 4 * j, o2[2 * j].x * inv, o2[2 * j].y * inv, o2[2 * j + 1].x * inv,
+           o2[2 * j + 1].y * inv);
+  }
+}
 template <int NT>
 __device__ __forceinline__ void qa8_stage_attention_mfma(const float *Q_s, int N, int graphs,
                                                          int max_row, float *out, int lane,
@@ -2504,7 +2583,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   const int graphs = min(G, B - g0);
   const int rows = graphs * N;
   const size_t row0 = (size_t)g0 * N;
-  const float *norms = norms_in;
+  const float *norms = norm_s;
   ST_MARK(0);
   ST_MARK(1);
   const int hidden = w.hidden, nchunk = hidden / 128, per_layer = x3_layer_frags(hidden);
@@ -2544,7 +2623,11 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       o[128 + cc] = wt[cc] / sqrtf(rv[cc] + 1e-5f);
       o[256 + cc] = bs[cc];
     }
-    norms = norm_s;
+  } else {
+    // (the affines always sit in LDS: a pointer that is LDS on one path and global memory on the
+    // other makes every access a FLAT load, and a pending FLAT load turns every counted LDS wait
+    // of the stage it is issued in into lgkmcnt(0))
+    for (int i = tid; i < 2 * w.num_layers * 384; i += 512) norm_s[i] = norms_in[i];
   }
   __syncthreads();
   // the layer input in this lane's accumulator layout (row = 16 rt + i16, columns cq .. cq + 3):
@@ -2597,9 +2680,13 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     ST_MARK(4 + 24 * l + 2);
     {
       const AttSinkX3 sink{AT3, PE};
+#ifdef VRP_STACK_ATT_MFMA   // round 5's matrix-core form (A/B aid)
       if (N <= 16) qa8_stage_attention_mfma_pairs<1>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
       else if (N <= 32) qa8_stage_attention_mfma_pairs<2>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
       else qa8_stage_attention_mfma_to<3>(Q_s, N, graphs, RTW - 1, sink, lane, wave);
+#else
+      qa8_stage_attention_valu(Q_s, N, rows, sink, lane, wave);
+#endif
     }
     ST_MARK(4 + 24 * l + 3);
     __syncthreads();

@@ -83,20 +83,27 @@ __device__ __forceinline__ void x3_mma(f32x4v (&acc)[RT16], const __bf16 *tile, 
   const __bf16 *ap[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) ap[j] = tile + i16 * X3_PITCH + (((4 * j + q) ^ i16) << 3);
-  // the operands of item it + 1 are read while the MFMAs of item it run: two operand sets alive
-  // (the scheduling fences keep the compiler from hoisting every LDS read of the stage to its top)
-  bf16x8 a[2][3];
+  // the operands of items it + 1 .. it + X3_DEPTH are read while the MFMAs of item it run: X3_DEPTH + 1
+  // operand sets alive (the scheduling fences keep the compiler from hoisting every LDS read of
+  // the stage to its top).  Depth 1 is enough: depths 2 and 3 measured no different in the stack
+  // kernel (round 6, profiles/r06_stack_trace.txt) -- the LDS round trip is not what a stage waits for.
+#ifndef X3_DEPTH
+#define X3_DEPTH 1
+#endif
+  constexpr int NS = X3_DEPTH + 1, NI = 4 * RT16;
+  bf16x8 a[NS][3];
   auto rd = [&](bf16x8 (&d)[3], int it) {
     const int j = it / RT16, rt = it - j * RT16;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       d[p] = *reinterpret_cast<const bf16x8 *>(ap[j] + p * plane_elems + rt * 16 * X3_PITCH);
   };
-  rd(a[0], 0);
 #pragma unroll
-  for (int it = 0; it < 4 * RT16; ++it) {
-    const int j = it / RT16, rt = it - j * RT16, cur = it & 1;
-    if (it + 1 < 4 * RT16) rd(a[cur ^ 1], it + 1);
+  for (int it = 0; it < X3_DEPTH && it < NI; ++it) rd(a[it % NS], it);
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int j = it / RT16, rt = it - j * RT16, cur = it % NS;
+    if (it + X3_DEPTH < NI) rd(a[(it + X3_DEPTH) % NS], it + X3_DEPTH);
 #ifndef X3_NOFENCE
     __builtin_amdgcn_sched_barrier(0);
 #endif
