@@ -799,54 +799,68 @@ static int launch_encoder_block16(const float *att, const float *x, const vrp_en
 // embedding column (x2) after.
 // `part` of `parts` waves share the embedding rows of one graph (rows part, part + parts, ...);
 // part 0 also commits the mask and the accumulators.
-__device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_encoder_weights &w,
-                                                 int b, int lane, float *orow0, int ld,
-                                                 float *__restrict__ acc_loss,
-                                                 float *__restrict__ acc_logp, int part = 0,
-                                                 int parts = 1) {
+struct SetupLoads {      // everything setup_graph_wave reads from global memory, in registers
+  float fx[2][3], wn[2][3], bnv[2], wd[2][2], bdv[2];
+  int v0, v1, dep, cur0;
+  double load;
+};
+// Phase 1: every global load of graph b, none of its stores (the compiler keeps loads behind
+// stores that may alias them, and a cold round trip is ~2 us) -- callable at the very top of a
+// kernel, ahead of LDS set-up work that needs nothing from memory.
+__device__ __forceinline__ SetupLoads setup_graph_load(const vrp_env &e, const vrp_encoder_weights &w,
+                                                       int b, int lane) {
   const int N = e.N;
-  // every global load of the graph first, ahead of the stores below (the compiler keeps loads
-  // behind stores that may alias them, and a cold round trip is ~2 us)
+  SetupLoads s;
   // ---- features (E3) in registers: lane n holds node n (and n + 64) ------------------------
-  float fx[2][3];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int n = lane + 64 * i;
     const size_t r = (size_t)b * N + (n < N ? n : 0);
-    fx[i][0] = (float)e.pos[2 * r];
-    fx[i][1] = (float)e.pos[2 * r + 1];
-    fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
+    s.fx[i][0] = (float)e.pos[2 * r];
+    s.fx[i][1] = (float)e.pos[2 * r + 1];
+    s.fx[i][2] = (e.kind == VRP_KIND_IRP) ? (float)e.demand[r] : 0.f;
   }
   // ---- embedding: lane owns columns lane and lane + 64 -------------------------------------
-  float wn[2][3], bnv[2], wd[2][2], bdv[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = lane + 64 * j;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
-    bnv[j] = w.node_embed_bias[c];
+    for (int d = 0; d < 3; ++d) s.wn[j][d] = d < w.node_dim ? w.node_embed_weight[c * w.node_dim + d] : 0.f;
+    s.bnv[j] = w.node_embed_bias[c];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
-      wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
-    bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
+      s.wd[j][d] = (w.depot_embed_weight && d < w.depot_dim) ? w.depot_embed_weight[c * w.depot_dim + d] : 0.f;
+    s.bdv[j] = w.depot_embed_weight ? w.depot_embed_bias[c] : 0.f;
   }
-  if (lane == 0 && part == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
-  // ---- generate_mask into mask buffer 0 (same code path as vrp_env_mask) -----------------
   // VRP_ENV_RESET_ON_ROLLOUT: the episode starts here (tsp.py:150-160,172-174; irp.py:47,184):
   // nothing visited, the vehicle on the depot with a full load
   const bool fresh = (e.flags & VRP_ENV_RESET_ON_ROLLOUT) != 0;
   const uint8_t *vis = e.visited + (size_t)b * N;
-  int v0 = (lane < N) ? (fresh ? 0 : vis[lane]) : 1;
-  int v1 = (lane + 64 < N) ? (fresh ? 0 : vis[lane + 64]) : 1;
-  const double load = (e.kind == VRP_KIND_IRP && !fresh) ? e.load[b] : 1.0;
-  const int dep = e.depot[b];
-  const int cur0 = fresh ? dep : e.cur[b];
+  s.v0 = (lane < N) ? (fresh ? 0 : vis[lane]) : 1;
+  s.v1 = (lane + 64 < N) ? (fresh ? 0 : vis[lane + 64]) : 1;
+  s.load = (e.kind == VRP_KIND_IRP && !fresh) ? e.load[b] : 1.0;
+  s.dep = e.depot[b];
+  s.cur0 = fresh ? s.dep : e.cur[b];
+  return s;
+}
+// Phase 2: the stores -- generate_mask into mask buffer 0 (same code path as vrp_env_mask),
+// zeroed accumulators, the embedding rows.
+__device__ __forceinline__ void setup_graph_finish(const vrp_env &e, const vrp_encoder_weights &w,
+                                                   int b, int lane, float *orow0, int ld,
+                                                   float *__restrict__ acc_loss,
+                                                   float *__restrict__ acc_logp, SetupLoads &s,
+                                                   int part, int parts) {
+  const int N = e.N;
+  if (lane == 0 && part == 0) { acc_loss[b] = 0.f; acc_logp[b] = 0.f; }
+  const bool fresh = (e.flags & VRP_ENV_RESET_ON_ROLLOUT) != 0;
+  int v0 = s.v0, v1 = s.v1;
+  const int dep = s.dep, cur0 = s.cur0;
   if (fresh && part == 0 && lane == 0) {
     e.cur[b] = dep;
     if (e.kind == VRP_KIND_IRP) e.load[b] = 1.0;
   }
   if (part == 0) {
-    env_fixups_and_mask(e, b, lane, cur0 == dep, v0, v1, load, e.mask);
+    env_fixups_and_mask(e, b, lane, cur0 == dep, v0, v1, s.load, e.mask, dep);
   } else {  // the same flag fix-ups in registers only (tsp.py:141-146, vrp.py:28-31)
     const int n0 = lane, n1 = lane + 64;
     if (cur0 == dep) { if (n0 == dep) v0 = 1; if (n1 == dep) v1 = 1; }
@@ -865,25 +879,30 @@ __device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_enc
     float x[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[0][d]), src));
-      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx[1][d]), src));
+      const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.fx[0][d]), src));
+      const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s.fx[1][d]), src));
       x[d] = n < 64 ? lo : hi;
     }
     const bool isdep = has_depot && (((n < 64 ? d0 : d1) >> src) & 1ull);
     float *orow = orow0 + (size_t)n * ld;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float v;
-      if (isdep) {
-        v = bdv[j];
-        for (int d = 0; d < w.depot_dim; ++d) v = fmaf(x[d], wd[j][d], v);
-      } else {
-        v = bnv[j];
-        for (int d = 0; d < w.node_dim; ++d) v = fmaf(x[d], wn[j][d], v);
-      }
-      orow[lane + 64 * j] = v;
+      // (static indices: the weights beyond node_dim / depot_dim were loaded as zeros, and
+      // fmaf(x, 0, v) = v exactly for the finite x of a feature row -- a loop bounded by the
+      // runtime dimension indexes the register arrays dynamically and sends them to scratch)
+      float vd = fmaf(x[1], s.wd[j][1], fmaf(x[0], s.wd[j][0], s.bdv[j]));
+      float vn = fmaf(x[2], s.wn[j][2], fmaf(x[1], s.wn[j][1], fmaf(x[0], s.wn[j][0], s.bnv[j])));
+      orow[lane + 64 * j] = isdep ? vd : vn;
     }
   }
+}
+__device__ __forceinline__ void setup_graph_wave(const vrp_env &e, const vrp_encoder_weights &w,
+                                                 int b, int lane, float *orow0, int ld,
+                                                 float *__restrict__ acc_loss,
+                                                 float *__restrict__ acc_logp, int part = 0,
+                                                 int parts = 1) {
+  SetupLoads s = setup_graph_load(e, w, b, lane);
+  setup_graph_finish(e, w, b, lane, orow0, ld, acc_loss, acc_logp, s, part, parts);
 }
 
 // ---- whole encoder in ONE launch (eval mode, small batches) -------------------------------
@@ -2505,7 +2524,8 @@ static void stack_trace_dump() {
           const double mhz = 100.0 * (double)(t[ST_SLOTS - 2] - t[1]) / (double)(t[ST_SLOTS - 1] - t[0]);
           fprintf(stderr, "[stack trace] block %d wave %d: shader clock %.0f MHz, total %llu cyc\n", blk,
                   wv, mhz, t[ST_SLOTS - 2] - t[1]);
-          fprintf(stderr, "  setup %llu\n", t[2] - t[1]);
+          fprintf(stderr, "  setup %llu = stage+zero %llu bar %llu graph %llu affines %llu bar %llu split %llu\n",
+                  t[2] - t[1], t[76] - t[1], t[77] - t[76], t[78] - t[77], t[79] - t[78], t[80] - t[79], t[2] - t[80]);
           for (int l = 0; l < 3; ++l) {
             const unsigned long long *u = t + 4 + 24 * l;
             fprintf(stderr, "  L%d proj %llu bar %llu att %llu bar %llu out %llu bar %llu | up0 %llu bar %llu |", l,
@@ -2590,6 +2610,28 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   const __bf16 *split = reinterpret_cast<const __bf16 *>(w.split);
   Frag3 fa, fb;
   x3_load_frag(fa, split + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);
+  // rollout set-up fused in front: EVERY global load of it first -- the wave's graph (or its
+  // part of one) and the thread's share of the BN statistics -- so that one round trip, not
+  // three in a row, separates the launch from the first MFMA (round 6 trace: 11 k of the set-up's
+  // 17 k cycles sat between the first barrier and the affines)
+  const int su_parts = graphs >= 8 ? 1 : 8 / max(graphs, 1);   // waves per graph
+  SetupLoads sl;
+  float bnraw[2][4];
+  if (su.from_env) {
+    if (wave < graphs * su_parts) sl = setup_graph_load(su.env, w, g0 + wave / su_parts, lane);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + 512 * u;
+      if (i < 2 * w.num_layers * 128) {
+        const int blk = i >> 7, cc = i & 127, l = blk >> 1, second = blk & 1;
+        const vrp_encoder_layer &L = w.layer[l];
+        bnraw[u][0] = (second ? L.bn2_running_mean : L.bn1_running_mean)[cc];
+        bnraw[u][1] = (second ? L.bn2_running_var : L.bn1_running_var)[cc];
+        bnraw[u][2] = (second ? L.bn2_weight : L.bn1_weight)[cc];
+        bnraw[u][3] = (second ? L.bn2_bias : L.bn1_bias)[cc];
+      }
+    }
+  }
   for (int idx = tid; idx < RTW * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2600,28 +2642,42 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   // (they are multiplied by zero weights downstream, and 0 x NaN is NaN)
   for (int i = tid; i < 3 * PE / 8; i += 512)
     reinterpret_cast<float4 *>(AT3)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  ST_MARK(76);
   if (su.from_env) {
     __syncthreads();
+    ST_MARK(77);
     if (blockIdx.x == 0 && tid < su.nflags) su.notdone[tid] = 0;
     {
-      const int parts = graphs >= 8 ? 1 : 8 / graphs;  // waves per graph
+      const int parts = su_parts;
       for (int gw = wave; gw < graphs * parts; gw += 8) {
         const int g = gw / parts, part = gw - g * parts;
-        setup_graph_wave(su.env, w, g0 + g, lane, stage + g * N * EB_LD, EB_LD, su.acc_loss,
-                         su.acc_logp, part, parts);
+        if (gw != wave) sl = setup_graph_load(su.env, w, g0 + g, lane);   // (more than eight graphs)
+        setup_graph_finish(su.env, w, g0 + g, lane, stage + g * N * EB_LD, EB_LD, su.acc_loss,
+                           su.acc_logp, sl, part, parts);
       }
     }
-    for (int i = tid; i < 2 * w.num_layers * 128; i += 512) {
+    ST_MARK(78);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = tid + 512 * u;
+      if (i < 2 * w.num_layers * 128) {
+        float *o = norm_s + (i >> 7) * 384;
+        const int cc = i & 127;
+        o[cc] = bnraw[u][0];
+        o[128 + cc] = bnraw[u][2] / sqrtf(bnraw[u][1] + 1e-5f);
+        o[256 + cc] = bnraw[u][3];
+      }
+    }
+    // (more than four layers: the x3 stack kernel takes at most five -- 1280 statistics, the third
+    // pass over them the old way)
+    for (int i = tid + 1024; i < 2 * w.num_layers * 128; i += 512) {
       const int blk = i >> 7, cc = i & 127, l = blk >> 1, second = blk & 1;
       const vrp_encoder_layer &L = w.layer[l];
-      const float *rm = second ? L.bn2_running_mean : L.bn1_running_mean;
-      const float *rv = second ? L.bn2_running_var : L.bn1_running_var;
-      const float *wt = second ? L.bn2_weight : L.bn1_weight;
-      const float *bs = second ? L.bn2_bias : L.bn1_bias;
       float *o = norm_s + blk * 384;
-      o[cc] = rm[cc];
-      o[128 + cc] = wt[cc] / sqrtf(rv[cc] + 1e-5f);
-      o[256 + cc] = bs[cc];
+      o[cc] = (second ? L.bn2_running_mean : L.bn1_running_mean)[cc];
+      o[128 + cc] = (second ? L.bn2_weight : L.bn1_weight)[cc] /
+                    sqrtf((second ? L.bn2_running_var : L.bn1_running_var)[cc] + 1e-5f);
+      o[256 + cc] = (second ? L.bn2_bias : L.bn1_bias)[cc];
     }
   } else {
     // (the affines always sit in LDS: a pointer that is LDS on one path and global memory on the
@@ -2629,7 +2685,9 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     // of the stage it is issued in into lgkmcnt(0))
     for (int i = tid; i < 2 * w.num_layers * 384; i += 512) norm_s[i] = norms_in[i];
   }
+  ST_MARK(79);
   __syncthreads();
+  ST_MARK(80);
   // the layer input in this lane's accumulator layout (row = 16 rt + i16, columns cq .. cq + 3):
   // kept in registers as the residual, and split into the A-operand planes
   const int cq = wave * 16 + 4 * q;
@@ -2658,22 +2716,21 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     const __bf16 *lf = split + (size_t)l * per_layer * X3_FRAG;
     ST_MARK(4 + 24 * l);
     // ---- in_proj: three 16-column tiles of this wave's 48-column block -> q | k | v (fp32) ----
-    auto proj_tile = [&](int ct, const Frag3 &f) {
+    auto proj_tile = [&](int ct, const Frag3 &f, Frag3 &nf, const __bf16 *nsrc) {
       const int col0 = wave * 48 + ct * 16 + 4 * q;
       const float4 bb = x3_ld4(L.in_proj_bias + col0);
       zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, f, lane);
+      x3_mma<RT16>(acc, XB3, PE, f, lane, X3FragStream(nf, nsrc, lane));
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt)
         *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + col0) =
             make_float4(acc[rt][0] + bb.x, acc[rt][1] + bb.y, acc[rt][2] + bb.z, acc[rt][3] + bb.w);
     };
-    x3_load_frag(B, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG, lane);
-    proj_tile(0, A);
-    x3_load_frag(A, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
-    proj_tile(1, B);
-    x3_load_frag(B, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
-    proj_tile(2, A);
+    // (every fragment but two is requested piecewise under the MFMAs of the stage before the one
+    // that uses it, into the buffer that stage does not read: X3FragStream)
+    proj_tile(0, A, B, lf + (size_t)x3_frag_win(wave * 3 + 1) * X3_FRAG);
+    proj_tile(1, B, A, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG);
+    proj_tile(2, A, B, lf + (size_t)x3_frag_wo(wave) * X3_FRAG);
     x3_load_frag(A, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // arrives during the attention
     ST_MARK(4 + 24 * l + 1);
     __syncthreads();
@@ -2698,7 +2755,6 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
                    mult = x3_ld4(n1 + 128 + cq), beta = x3_ld4(n1 + 256 + cq);
       zero(acc);
       x3_mma<RT16>(acc, AT3, PE, B, lane);
-      x3_load_frag(B, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) {
         xres[rt].x = (acc[rt][0] + bb.x + xres[rt].x - mean.x) * mult.x + beta.x;
@@ -2734,16 +2790,18 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       __bf16 *hcur = (ch & 1) ? H1 : AT3, *hnext = (ch & 1) ? AT3 : H1;
       const float4 b1v = x3_ld4(L.ff0_bias + (ch + 1) * 128 + cq);
       zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, A, lane);                                   // up: slice ch + 1
-      if (ch + 2 < nchunk) x3_load_frag(A, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
-      else x3_load_frag(A, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);   // the last ff.2 slice
+      // up: slice ch + 1 (reads A); B -- free since the out-projection / the last way down -- takes
+      // the ff.2 slice of the way down that follows
+      x3_mma<RT16>(acc, XB3, PE, A, lane,
+                   X3FragStream(B, lf + (size_t)x3_frag_w2(hidden, wave, ch) * X3_FRAG, lane));
+      // A is free: the next ff.0 slice, or the LAST ff.2 slice, travels under the way down
+      const X3FragStream sa(A, (ch + 2 < nchunk) ? lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG
+                                                 : lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
       ST_MARK(4 + 24 * l + 9 + 3 * ch);
       x3_mma<RT16>(gacc, hcur, PE, B, lane, [&](int it) {                    // down: slice ch
+        sa(it);
         if (it < RT16) up_store(it, b1v, hnext);
       });
-      if (ch + 2 < nchunk) x3_load_frag(B, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
-      else if (l + 1 < w.num_layers)
-        x3_load_frag(B, lf + (size_t)(per_layer + x3_frag_win(wave * 3)) * X3_FRAG, lane);   // next layer's first
       ST_MARK(4 + 24 * l + 10 + 3 * ch);
       __syncthreads();
       ST_MARK(4 + 24 * l + 11 + 3 * ch);
@@ -2753,7 +2811,11 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       const float *n2 = norms + (2 * l + 1) * 384;
       const float4 bb = x3_ld4(L.ff2_bias + cq), mean = x3_ld4(n2 + cq),
                    mult = x3_ld4(n2 + 128 + cq), beta = x3_ld4(n2 + 256 + cq);
-      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, A, lane);   // (hidden >= 256: see the loop)
+      // (hidden >= 256: see the loop)  The next layer's first in_proj fragment travels under it
+      // (the last layer requests its own first fragment again: twelve loads nobody uses, cheaper
+      // than a branch inside the MFMA sequence)
+      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, A, lane,
+                   X3FragStream(B, lf + (size_t)(l + 1 < w.num_layers ? per_layer + x3_frag_win(wave * 3) : 0) * X3_FRAG, lane));
       ST_MARK(4 + 24 * l + 21);
       // ---- y = BN2(y1 + g + b2): the next layer's input ----------------------------------------
 #pragma unroll

@@ -66,6 +66,23 @@ __device__ __forceinline__ void x3_load_frag(Frag3 &f, const __bf16 *__restrict_
 }
 
 struct X3NoFill { __device__ __forceinline__ void operator()(int) const {} };
+// The NEXT-BUT-ONE stage's weight fragment, requested one 1 KB piece per item of the running
+// stage (a `fill` for x3_mma) in the order the consuming stage uses the pieces (chunk-major): a
+// fragment is twelve 16-byte loads per lane, and eight waves issuing twelve each at a stage
+// boundary queue up behind the CU's one vector memory pipe (16 cycles per wave instruction: up to
+// 1.5 k cycles before the last wave's last load is accepted, and a wave does not reach its
+// epilogue or the barrier until its own loads are).  Issued between the MFMAs they cost nothing.
+struct X3FragStream {
+  Frag3 *dst; const bf16x8 *src;
+  __device__ __forceinline__ X3FragStream(Frag3 &d, const __bf16 *frag, int lane)
+      : dst(&d), src(reinterpret_cast<const bf16x8 *>(frag) + lane) {}
+  __device__ __forceinline__ void operator()(int it) const {
+    if (it < 12) {
+      const int j = it / 3, p = it - 3 * j;
+      dst->p[p][j] = src[(p * 4 + j) * 64];
+    }
+  }
+};
 // acc[rt] += W(fragment: 16 output columns) A(rows 16 rt .., 128 k; LDS planes)^T, the WEIGHTS as the
 // first operand: D[column][row] puts an activation row on the lane (row = 16 rt + (lane & 15)) and
 // FOUR CONSECUTIVE output columns 4 (lane >> 4) + e in its registers -- an epilogue converts and

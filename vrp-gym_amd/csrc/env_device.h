@@ -24,8 +24,11 @@ __device__ __forceinline__ double edge_length(const double *pos, int N, int b, i
 // for nodes lane and lane+64.  at_depot = (current_location == depot).
 __device__ __forceinline__ void env_fixups_and_mask(const vrp_env &e, int b, int lane,
                                                     int at_depot, int &v0, int &v1,
-                                                    double load, uint8_t *mask_out) {
-  const int N = e.N, dep = e.depot[b];
+                                                    double load, uint8_t *mask_out,
+                                                    int dep_known = -1) {
+  // (a caller that already holds the depot index passes it: read here, behind the caller's
+  // stores, it is a second dependent round trip)
+  const int N = e.N, dep = dep_known >= 0 ? dep_known : e.depot[b];
   const int n0 = lane, n1 = lane + 64;
   // (a) disallow staying on the depot  tsp.py:141-142
   if (at_depot) { if (n0 == dep) v0 = 1; if (n1 == dep) v1 = 1; }
