@@ -2937,25 +2937,28 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
   const int cq = wave * 16 + 4 * q;                  // this lane's four output columns
   const int nchunk = hidden / 128;
   float4 pa[PF];
+  // (UNCONDITIONAL loads, the row index clamped and rows beyond the matrix zeroed on arrival: behind
+  // a branch the compiler cannot count the requests in flight across the join and drains them
+  // all -- round 6 trace: 4 k cycles for this fetch, 3 k for the residual rows below, per tile)
   auto fetch_att = [&](int tile) {
     const int row0 = tile * RTW;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
-      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < rows) pa[u] = *reinterpret_cast<const float4 *>(att + ((row0 + r) * 128 + c4));   // (32-bit offsets: rows * 128 < 2^31)
+      pa[u] = *reinterpret_cast<const float4 *>(att + (min(row0 + r, rows - 1) * 128 + c4));   // (32-bit offsets: rows * 128 < 2^31)
     }
   };
-  auto store_att = [&](__bf16 *dst) {
+  auto store_att = [&](__bf16 *dst, int tile) {
+    const int row0 = tile * RTW;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
-      x3_store4v(dst, PE, r, c4, pa[u]);
+      x3_store4v(dst, PE, r, c4, row0 + r < rows ? pa[u] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
   int tile = blockIdx.x;
   __bf16 *abuf = hb0, *other = hb1;
-  if (tile < ntiles) { fetch_att(tile); store_att(abuf); }
+  if (tile < ntiles) { fetch_att(tile); store_att(abuf, tile); }
   // fragment buffers: fa = out_proj and the ff.2 slices, fb = the ff.0 slices
   Frag3 fa, fb;
   x3_load_frag(fa, lf_ + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
@@ -2984,7 +2987,7 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       const int row = rt * 16 + i16;
-      xr[rt] = row < valid ? x3_ld4(x + ((row0 + row) * 128 + cq)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[rt] = x3_ld4(x + (min(row0 + row, rows - 1) * 128 + cq));   // (rows beyond the matrix: never stored)
     }
     f32x4v acc[RT16], gacc[RT16];
 #pragma unroll
@@ -2992,9 +2995,10 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     // ---- y1 = BN1(x + att Wo^T + bo) ----------------------------------------------------------
     const float4 bb_o = x3_ld4(boz + cq), mean1 = x3_ld4(n1z + cq), mult1 = x3_ld4(n1z + 128 + cq),
                  beta1 = x3_ld4(n1z + 256 + cq);   // (requested ahead of the MFMAs that hide them)
-    x3_mma<RT16>(acc, abuf, PE, fa, lane);
+    // (fb -- ff.0 slice 0 -- travels under the out-projection; every other fragment but one
+    // under the stage before the one that uses it: X3FragStream, encoder_x3.h)
+    x3_mma<RT16>(acc, abuf, PE, fa, lane, X3FragStream(fb, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane));
     B8_MARK(2);
-    x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, 0) * X3_FRAG, lane);
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) {
       xr[rt].x = (acc[rt][0] + bb_o.x + xr[rt].x - mean1.x) * mult1.x + beta1.x;
@@ -3030,19 +3034,20 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
       const float4 b1v = x3_ld4(b1 + (ch + 1) * 128 + cq);
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) acc[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      x3_mma<RT16>(acc, XB3, PE, fb, lane);                                   // up: slice ch + 1
+      // up: slice ch + 1 (reads fb); fa -- free since the out-projection / the last way down --
+      // takes the ff.2 slice of the way down that follows
+      x3_mma<RT16>(acc, XB3, PE, fb, lane,
+                   X3FragStream(fa, lf + (size_t)x3_frag_w2(hidden, wave, ch) * X3_FRAG, lane));
       // fb is free now.  Not the last pair: the next ff.0 slice.  The last pair: the LAST ff.2
       // slice -- the way down that follows the coming barrier has no way up in front of it to
       // hide a fragment requested after this pair's way down (measured: 4-8 k cycles exposed)
-      if (ch + 2 < nchunk) x3_load_frag(fb, lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG, lane);
-      else x3_load_frag(fb, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
+      const X3FragStream sb(fb, (ch + 2 < nchunk) ? lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG
+                                                  : lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
       B8_MARK(8 + 3 * ch);
       x3_mma<RT16>(gacc, hcur, PE, fa, lane, [&](int it) {                    // down: slice ch
+        sb(it);
         if (it < RT16) up_store(it, b1v, hnext);
       });
-      // fa is free: the next ff.2 slice, or (last pair) the next tile's Wo
-      if (ch + 2 < nchunk) x3_load_frag(fa, lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
-      else x3_load_frag(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane);
       B8_MARK(9 + 3 * ch);
       __syncthreads();
       B8_MARK(10 + 3 * ch);
@@ -3050,14 +3055,14 @@ __global__ __launch_bounds__(512) void encoder_block8_x3_kernel(
     // last way down; the next tile's attention rows travel behind it into the free buffer
     __bf16 *hlast = ((nchunk - 1) & 1) ? other : abuf, *hfree = ((nchunk - 1) & 1) ? abuf : other;
     const int next = tile + gridDim.x;
-    if (next < ntiles) fetch_att(next);
+    fetch_att(min(next, ntiles - 1));   // (no branch around the loads; the last tile fetches itself again)
     const float4 bb_2 = x3_ld4(b2z + cq), mean2 = x3_ld4(n2z + cq), mult2 = x3_ld4(n2z + 128 + cq),
                  beta2 = x3_ld4(n2z + 256 + cq);   // (requested ahead of the MFMAs that hide them)
     B8_MARK(20);
-    x3_mma<RT16>(gacc, hlast, PE, fb, lane);   // the last ff.2 slice sits in fb (see the loop; hidden >= 256)
+    // the last ff.2 slice sits in fb (see the loop; hidden >= 256); the next tile's Wo travels under it
+    x3_mma<RT16>(gacc, hlast, PE, fb, lane, X3FragStream(fa, lf + (size_t)x3_frag_wo(wave) * X3_FRAG, lane));
     B8_MARK(21);
-    x3_load_frag(fb, lf + (size_t)x3_frag_w1(wave) * X3_FRAG, lane);   // ff.0 slice 0 of the next tile
-    if (next < ntiles) store_att(hfree);
+    if (next < ntiles) store_att(hfree, next);
     B8_MARK(22);
     // ---- y = BN2(y1 + g + b2) ------------------------------------------------------------------
 #pragma unroll
@@ -3150,8 +3155,9 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
-      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows) pf[u] = *reinterpret_cast<const float4 *>(x + ((row0 + r) * VRP_EMB + c4));
+      // (unconditional, clamped: see encoder_block8_x3_kernel; rows past the tile's graphs are
+      // projected but never read by the attention)
+      pf[u] = *reinterpret_cast<const float4 *>(x + ((row0 + min(r, rows - 1)) * VRP_EMB + c4));
     }
   };
   // fragment buffers: fb holds column tile 1 for good, fa alternates between tiles 0 and 2
@@ -3173,15 +3179,15 @@ __global__ __launch_bounds__(512) void encoder_qkv_attn8_x3_kernel(const float *
       x3_store4v(X3, PE, r, c4, pf[u]);
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    fetch(min(tile + (int)gridDim.x, ntiles - 1));   // (no branch around the loads)
     f32x4v acc[3][RT16];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) acc[ct][rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
     x3_mma<RT16>(acc[0], X3, PE, fa, lane);
-    x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane);
-    x3_mma<RT16>(acc[1], X3, PE, fb, lane);
+    // (column tile 2 travels under tile 1's MFMAs, one 1 KB piece per item: X3FragStream)
+    x3_mma<RT16>(acc[1], X3, PE, fb, lane, X3FragStream(fa, lf + (size_t)x3_frag_win(wave * 3 + 2) * X3_FRAG, lane));
     x3_mma<RT16>(acc[2], X3, PE, fa, lane);
     x3_load_frag(fa, lf + (size_t)x3_frag_win(wave * 3) * X3_FRAG, lane);   // the next tile's first
     __syncthreads();   // every wave is done with the input planes: q|k|v may overlay them
