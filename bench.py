@@ -30,7 +30,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline_north_star the same at 8192 x 40 TSP (the north-star target shape);
   roofline_north_star_vrp / roofline_cfg5: VRP 8192 x 40 greedy, VRP 2048 x 100 sampling
   other_configs       short runs of the training / sampling configs (ms per step; the training
-                      ones carry roofline_train: algorithmic flops per epoch vs the fp32 MFMA peak)
+                      ones carry roofline_train: algorithmic flops per epoch vs the ceiling of the
+                      bf16-plane arithmetic, the fp32-MFMA yardstick kept as vs_fp32_mfma_peak)
   cpu_baseline        the CPU oracle (oracle/, a port of the reference) on this host
 """
 import argparse
@@ -107,6 +108,84 @@ def _die_with_parent():
         pass
 
 
+# ---- N > 1: fail fast and loud (first contact with RCCL happens on the driver's 8-GPU box) ------
+# Every rank keeps RCCL's own warnings in <faildir>/rccl_rank<r>.log (NCCL_DEBUG=WARN) and, when it
+# dies of an exception, leaves <faildir>/rank<r>.json = {"rank", "where", "error", "rccl_tail"}.
+# Whoever owns stdout then prints ONE JSON line with "value": null and an "error" field made of
+# those records: the launcher below, or rank 0 itself under torchrun.  Nothing hangs longer than
+# DIST_TIMEOUT_S in a collective.
+DIST_TIMEOUT_S = 120
+
+
+def fail_dir():
+    d = os.environ.get("VRPGYM_BENCH_FAILDIR")
+    if not d:
+        d = os.path.join("/tmp", "vrpgym_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+        os.environ["VRPGYM_BENCH_FAILDIR"] = d
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _tail(path, nbytes=1500):
+    try:
+        with open(path, "rb") as fh:
+            fh.seek(0, 2)
+            size = fh.tell()
+            fh.seek(max(0, size - nbytes))
+            return fh.read().decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def record_failure(rank, where, exc):
+    """This rank's failure record (never raises)."""
+    import traceback
+    d = fail_dir()
+    rec = {"rank": rank, "where": where,
+           "error": "".join(traceback.format_exception_only(type(exc), exc)).strip()[:800],
+           "rccl_tail": _tail(os.path.join(d, f"rccl_rank{rank}.log"))}
+    try:
+        with open(os.path.join(d, f"rank{rank}.json"), "w") as fh:
+            json.dump(rec, fh)
+    except OSError:
+        pass
+    return rec
+
+
+def failure_line(a, world, extra=None):
+    """The ONE JSON line of a failed N > 1 run: the contract keys with value null + `error`."""
+    import glob
+    recs = [extra] if extra else []
+    d = os.environ.get("VRPGYM_BENCH_FAILDIR")
+    if d:
+        for path in sorted(glob.glob(os.path.join(d, "rank*.json"))):
+            try:
+                with open(path) as fh:
+                    r = json.load(fh)
+                if not extra or r.get("rank") != extra.get("rank"):
+                    recs.append(r)
+            except (OSError, ValueError):
+                continue
+        seen = {r.get("rank") for r in recs if r}
+        for path in sorted(glob.glob(os.path.join(d, "rccl_rank*.log"))):   # warnings of ranks that did not raise
+            r = int(os.path.basename(path)[len("rccl_rank"):-4])
+            t = _tail(path, 600)
+            if r not in seen and t.strip():
+                recs.append({"rank": r, "where": "rccl log", "error": "", "rccl_tail": t})
+    recs = [r for r in recs if r]
+    msg = "; ".join(f"rank {r['rank']} [{r['where']}]: {r['error']}" +
+                    (f" | RCCL: {r['rccl_tail'][-500:].strip()}" if r.get("rccl_tail", "").strip() else "")
+                    for r in recs) or "a rank exited without leaving a record"
+    kind, N, B, mode = WORKLOADS[a.workload]
+    return json.dumps({"metric": "env-steps/sec (batch x nodes), " +
+                       ("REINFORCE training" if mode == "train" else f"{mode} attention rollout"),
+                       "value": None, "unit": "node-steps/s", "n_gpus": world, "steps": a.steps,
+                       "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True,
+                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                       "config": {"workload": a.workload, "name": a.workload},
+                       "error": msg[:4000], "failed_ranks": sorted({r["rank"] for r in recs})})
+
+
 def spawn_ranks(a, argv):
     """--gpus N outside torchrun: start the N ranks as CHILD processes (env-var rendezvous:
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, what torchrun would set) and
@@ -128,6 +207,10 @@ def spawn_ranks(a, argv):
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(a.gpus),
                LOCAL_WORLD_SIZE=str(a.gpus))
     env.setdefault("OMP_NUM_THREADS", "1")      # torchrun's default for its workers
+    import tempfile
+    faildir = tempfile.mkdtemp(prefix="vrpgym_bench_")
+    env.update(VRPGYM_BENCH_FAILDIR=faildir, VRPGYM_BENCH_LAUNCHER="1")   # the launcher owns stdout's error line
+    os.environ["VRPGYM_BENCH_FAILDIR"] = faildir
     procs = []
     for r in range(a.gpus):
         renv = dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
@@ -169,6 +252,10 @@ def spawn_ranks(a, argv):
                 while time.time() < deadline and any(x.poll() is None for x in procs):
                     time.sleep(0.05)
                 stop(signal.SIGKILL)
+    if rc != 0:
+        print(failure_line(a, a.gpus), flush=True)
+    import shutil
+    shutil.rmtree(faildir, ignore_errors=True)
     sys.exit(rc)
 
 
@@ -536,6 +623,20 @@ def training_flops_per_epoch(kind, N, B, T_sampled, T_greedy):
     return sum(parts.values()), parts
 
 
+def training_dense_flops(kind, N, B, T_sampled):
+    """The part of training_flops_per_epoch that is DENSE products with a 128- or 384-long inner
+    dimension (projections, feed-forward, the prologue's stage 1, the decoder backward's
+    projections): what the library issues -- or could issue -- as six bf16 MFMAs per product.
+    Everything else (per-head attention with inner dimension 16 / 48, table steps) is priced at
+    the fp32 rate.  Used for roofline_train's ceiling, so counting a product here that still
+    runs on the fp32 MFMA (gemm_rows_wide_kernel) only LOWERS the reported fraction."""
+    enc_dense = B * N * 1180160
+    pro_dense = B * N * 2 * 4 * 384 * 128
+    dec_dense = (B * T_sampled * (2 * 384 * 384 + 2 * 384 * 384 + 2 * 128 * 384)
+                 + B * N * 2 * 128 * (384 + 384 + 128))
+    return 4 * enc_dense + 2 * enc_dense + 4 * pro_dense + 3 * dec_dense
+
+
 def gemm_kernel_roofline(device, M=81920, N=384, K=128, reps=20):
     """The training path's most frequent tall GEMM (the train-mode in_proj of VRP-40 x 2048:
     M = B N rows, bias only; vrp_gemm_nt -> gemm_rows_wide_kernel: all of W in registers) timed
@@ -642,15 +743,25 @@ def run_workload(name, steps, warmup, device, dist, rank, world, blocks=1):
                                               if p.grad is not None)}
         flops, parts = training_flops_per_epoch(kind, N, B, t_s, t_g)
         tf = flops / (dt / steps) / 1e12
+        # ceiling of the arithmetic an epoch issues: dense products as six bf16 MFMAs (2500 / 6
+        # TFLOP/s), the rest at the fp32 rate -- the same accounting as encoder_roofline
+        dense = training_dense_flops(kind, N, B, t_s)
+        bound_s = 6.0 * dense / (MFMA_BF16_PEAK_TFLOPS * 1e12) + (flops - dense) / (MFMA_F32_PEAK_TFLOPS * 1e12)
+        peak_mixed = flops / bound_s / 1e12
         extra["roofline_train"] = {
-            "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak_mixed, 1),
+            "unit": "TFLOP/s", "frac": round(tf / peak_mixed, 4),
+            "peak_is": "algorithmic flops / (6 x dense flops / 2500 TFLOP/s bf16 + other flops / "
+                       "157.3 TFLOP/s fp32): the ceiling of the bf16-plane arithmetic "
+                       "(bench.training_dense_flops)",
+            "vs_fp32_mfma_peak": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+            "dense_share_of_flops": round(dense / flops, 3),
             "algorithmic_gflop_per_epoch": round(flops / 1e9, 2),
             "gflop_by_part": {k: round(v / 1e9, 2) for k, v in parts.items()},
             "steps_per_rollout": {"sampled": round(t_s, 1), "greedy": round(t_g, 1)},
             "ms_per_epoch": round(dt / steps * 1e3, 3),
             "note": "whole epoch (rollouts incl. their HBM-bound decode loops, backward, Adam, "
-                    "t-test) against the fp32 matrix peak; flop model: "
+                    "t-test) against the ceiling of the matrix arithmetic it issues; flop model: "
                     "bench.training_flops_per_epoch"}
     else:
         dts, T, cost = timed_rollouts(env, agent, mode == "greedy", steps, warmup, dist,
@@ -726,6 +837,29 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(a, sys.argv[1:])  # does not return
 
+    if a.gpus == 1:
+        return rank_main(a)          # (the N = 1 path: nothing between the driver and the run)
+    rank = int(os.environ.get("RANK", "0"))
+    stage = ["start-up"]
+    try:
+        return rank_main(a, stage)
+    except BaseException as exc:     # SystemExit included: a refused start-up is a failure too
+        if isinstance(exc, SystemExit) and exc.code in (0, None):
+            raise
+        rec = record_failure(rank, stage[0], exc)
+        sys.stderr.write(f"bench.py rank {rank} failed in [{stage[0]}]: {rec['error']}\n")
+        if rank == 0 and os.environ.get("VRPGYM_BENCH_LAUNCHER") != "1":
+            time.sleep(1.0)          # torchrun: give the rank that failed first a moment to write its record
+            print(failure_line(a, int(os.environ.get("WORLD_SIZE", a.gpus)), rec), flush=True)
+        if isinstance(exc, (SystemExit, KeyboardInterrupt)):
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.exit(1)
+
+
+def rank_main(a, stage=None):
+    stage = stage if stage is not None else ["run"]
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -740,15 +874,33 @@ def main():
     if world > 1 and not one_gpu and torch.cuda.device_count() < world:
         # (the parent counted in sysfs; a rank sees what the runtime really offers)
         sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
+    if world > 1 and os.environ.get("VRPGYM_BENCH_TEST_FAIL") == f"startup:{rank}":
+        raise RuntimeError("injected start-up failure (VRPGYM_BENCH_TEST_FAIL)")   # CPU test of the failure path
+    stage[0] = "bind device"
     device = bind_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's own diagnostics, per rank, where the failure line can find them
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(fail_dir(), f"rccl_rank{rank}.log"))
+        stage[0] = "init_process_group"
+        tmo = datetime.timedelta(seconds=DIST_TIMEOUT_S)
         if one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)  # nccl == RCCL on ROCm
+        # first contact: one tiny all-reduce on the device (RCCL builds its rings / xGMI links
+        # here, not in init_process_group), checked, before anything is timed
+        stage[0] = "first all-reduce"
+        one = torch.ones(1, device=device if not one_gpu else "cpu")
+        dist.all_reduce(one)
+        if not one_gpu:
+            torch.cuda.synchronize()
+        assert int(one.item()) == world, f"all-reduce of ones over {world} ranks gave {one.item()}"
+        stage[0] = "device identities"
 
     # every rank on its own GPU: gather what identifies the device and insist on N distinct ones
     backend, idents = None, [device_identity(device)]
@@ -762,8 +914,10 @@ def main():
             assert len(keys) == world, f"{world} ranks but {len(keys)} distinct GPUs: {idents}"
 
     kind, N, B, mode = WORKLOADS[a.workload]
+    stage[0] = "timed workload " + a.workload
     r, env, agent = run_workload(a.workload, a.steps, a.warmup, device, dist, rank, world,
                                  blocks=max(a.blocks, 1))
+    stage[0] = "report"
     T = r["T"]
     out = {
         "metric": "env-steps/sec (batch x nodes), " + ("REINFORCE training" if mode == "train"

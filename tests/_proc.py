@@ -49,19 +49,44 @@ class Result:
 def run(cmd, env=None, timeout=SUBPROCESS_TIMEOUT, cwd=None, merge_stderr=False):
     """subprocess.run(capture_output, text) for a child that may start processes of its own.
     On timeout the whole group is killed and `timed_out` is set (returncode -9); the output so
-    far is returned either way."""
+    far is returned either way.
+
+    The group is swept BEFORE the child is reaped: while the leader is still a zombie its pid --
+    and with it the process-group id -- cannot be handed to anybody else, so the SIGKILL can only
+    reach our own stragglers (swept after the reap, a recycled id could belong to a stranger)."""
+    import threading
     p = subprocess.Popen(cmd, env=env, cwd=cwd, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT if merge_stderr else subprocess.PIPE, text=True,
                          start_new_session=True, preexec_fn=die_with_parent)
-    timed_out = False
-    try:
-        out, err = p.communicate(timeout=timeout)
-    except subprocess.TimeoutExpired:
-        timed_out = True
-        _sweep(p.pid)
-        out, err = p.communicate()
-    finally:
-        _sweep(p.pid)   # stragglers of a child that exited by itself
+    bufs = {}
+
+    def reader(name, fh):
+        try:
+            bufs[name] = fh.read()
+        except (OSError, ValueError):
+            bufs.setdefault(name, "")
+
+    threads = [threading.Thread(target=reader, args=("out", p.stdout), daemon=True)]
+    if not merge_stderr:
+        threads.append(threading.Thread(target=reader, args=("err", p.stderr), daemon=True))
+    for t in threads:
+        t.start()
+    deadline = time.time() + timeout
+    timed_out = True
+    while time.time() < deadline:
+        try:   # has it exited?  (WNOWAIT: look, do not reap)
+            info = os.waitid(os.P_PID, p.pid, os.WEXITED | os.WNOWAIT | os.WNOHANG)
+        except ChildProcessError:
+            info = True
+        if info is not None:
+            timed_out = False
+            break
+        time.sleep(0.02)
+    _sweep(p.pid)        # stragglers of a child that exited by itself, or everything on a timeout
+    p.wait()             # only now is the id free for reuse
+    for t in threads:    # every writer of the pipes is dead: EOF
+        t.join(timeout=10)
+    out, err = bufs.get("out", ""), bufs.get("err", "")
     err = err or ""
     if timed_out:
         err += f"\n[tests/_proc.py] killed the process group after {timeout} s\n"

@@ -81,6 +81,52 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert "--gpus 2" in p.stderr and "{" not in p.stdout
 
 
+def test_bench_multirank_failure_is_one_loud_json_line():
+    """N > 1, a rank dies during start-up (injected; first contact with RCCL will happen on the
+    driver's 8-GPU node, never here): the launcher takes the other ranks down, exits non-zero and
+    prints ONE JSON line with value null and an `error` field that names the rank, the stage and
+    the exception (plus the tail of that rank's NCCL_DEBUG=WARN log when there is one)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(VRPGYM_BENCH_ONE_GPU="1", VRPGYM_BENCH_TEST_FAIL="startup:1")
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                   "--warmup", "1", "--no-cpu-baseline", "--no-north-star", "--no-extras"],
+                  env=env, timeout=240)
+    assert p.returncode != 0
+    out = _json_line(p.stdout)
+    assert out["value"] is None and out["n_gpus"] == 2 and out["ms_per_step"] is None
+    assert "injected start-up failure" in out["error"] and "rank 1 [start-up]" in out["error"]
+    assert 1 in out["failed_ranks"]
+    assert "rank 1 failed in [start-up]" in p.stderr
+
+
+def test_bench_rank0_reports_failure_under_torchrun():
+    """Started the way the driver starts it (RANK / WORLD_SIZE already set: no launcher of ours),
+    rank 0 itself owns the error line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), VRPGYM_BENCH_ONE_GPU="1", VRPGYM_BENCH_TEST_FAIL="startup:0")
+    env.pop("VRPGYM_BENCH_LAUNCHER", None)
+    env.pop("VRPGYM_BENCH_FAILDIR", None)
+    p = _proc.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                   "--warmup", "1", "--no-cpu-baseline"], env=env, timeout=240)
+    assert p.returncode != 0
+    out = _json_line(p.stdout)
+    assert out["value"] is None and "injected start-up failure" in out["error"]
+    assert out["failed_ranks"] == [0]
+
+
+def test_bench_distributed_timeout_is_bounded():
+    """No collective of the bench waits longer than two minutes for a peer that is not there."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert 0 < bench.DIST_TIMEOUT_S <= 120
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("init_process_group(") == src.count("timeout=tmo")
+
+
 @pytest.mark.gpu
 def test_bench_spawns_two_ranks_rollout():
     p = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",

@@ -833,6 +833,50 @@ def test_graph_replay_equals_eager():
     assert nb1 - nb0 == 3
 
 
+@pytest.mark.parametrize("hidden", [512, 200])
+def test_graph_replay_after_sync_weights(hidden):
+    """A captured rollout keeps reading the encoder's device-side weight shadows (the bf16
+    planes of vrp_encoder_prepare; the zero-padded feed-forward copies at hidden = 200) at the
+    addresses baked into its kernel arguments.  `agent.sync_weights()` -> `runtime.invalidate`
+    must therefore refresh those buffers IN PLACE: a rebuilt struct with a fresh allocation
+    would leave the graph replaying against freed memory (round-5 advisor finding).  Weights
+    written through `.data` (no version bump), sync_weights, then replay == eager."""
+    import agents
+    from gym_vrp.envs import TSPEnv
+    from agents import runtime
+    env = TSPEnv(20, 64, 1, 69)
+    agent = agents.TSPAgent(seed=69, hidden_dim=hidden) if hidden != 512 else agents.TSPAgent(seed=69)
+    agent.model.eval()
+
+    def fresh():
+        env._visited.zero_(); env._cur.copy_(env._depot); env._mask_fresh = False
+
+    with torch.no_grad():
+        for _ in range(3):   # second sighting captures, the third replays
+            fresh()
+            got0 = runtime.rollout(agent.model, env, True, use_graph=True)
+        before = runtime.shadow_pointers(agent.model.encoder)
+        fresh()
+        base = runtime.rollout(agent.model, deepcopy(env), True, use_graph=False).acc_loss.clone()
+        assert torch.equal(got0.acc_loss, base)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        for prm in agent.model.encoder.parameters():
+            prm.data.add_(0.05 * torch.randn(prm.shape, generator=g).to(prm.device))
+        for prm in agent.model.decoder.parameters():
+            prm.data.add_(0.05 * torch.randn(prm.shape, generator=g).to(prm.device))
+        # churn the caching allocator: a freed shadow must not come back by luck
+        junk = [torch.empty(1 << 20, dtype=torch.uint8, device=env._device) for _ in range(8)]
+        agent.sync_weights()
+        del junk
+        assert runtime.shadow_pointers(agent.model.encoder) == before
+        fresh()
+        want = runtime.rollout(agent.model, deepcopy(env), True, use_graph=False).acc_loss.clone()
+        assert not torch.equal(want, base)          # the weights did change
+        fresh()
+        got = runtime.rollout(agent.model, env, True, use_graph=True)
+        assert torch.equal(got.acc_loss, want)
+
+
 @pytest.mark.parametrize("name,path", _load("trainstep_*.npz") + _load("archstep_*.npz"))
 def test_training_step_against_reference(name, path):
     """One REINFORCE step (agent.step(env,(False,True)) + backward) on the reference's

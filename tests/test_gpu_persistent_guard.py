@@ -28,12 +28,12 @@ import torch
 import agents, vrpgym_hip as hip
 from copy import deepcopy
 from agents import runtime
-from gym_vrp.envs import VRPEnv, IRPEnv
+from gym_vrp.envs import TSPEnv, VRPEnv, IRPEnv
 cap = hip.lib().vrp_persistent_capacity()
-B, N = 2048, 20
+B, N = int(os.environ.get("GUARD_B", "2048")), 20
 KIND = int(os.environ.get("GUARD_KIND", "1"))
-env = (VRPEnv if KIND == 1 else IRPEnv)(N, B, 1, 13)
-agent = (agents.VRPAgent if KIND == 1 else agents.IRPAgent)(seed=69)
+env = (TSPEnv, VRPEnv, IRPEnv)[KIND](N, B, 1, 13)
+agent = (agents.TSPAgent, agents.VRPAgent, agents.IRPAgent)[KIND](seed=69)
 agent.model.eval()
 steps = runtime.max_steps_for(KIND, N)
 noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
@@ -114,16 +114,26 @@ def test_cu_mask_falls_back_before_the_episode():
     assert r["equal"] and not r["nan"] and r["failures"] == 0, r
 
 
-@pytest.mark.parametrize("kind", [1, 2])
-def test_forced_non_resident_grid_falls_back_transparently(kind):
-    """B = 2048 single-wave workgroups forced onto 32 compute units: most of the grid waits for
-    words of workgroups that have no slot.  The waits give up after 20 ms, the grid drains, and the
+@pytest.mark.parametrize("kind,batch,waves", [
+    (1, 2048, None), (2, 2048, None),      # one wave per graph, VRP / IRP
+    (0, 2046, None),                       # TSP; a batch that is not a multiple of four: the
+                                           # fallback walks four graphs at a time, two idle at the end
+    (1, 1022, 2), (2, 510, 4),             # the several-waves-per-graph kernels: their own
+                                           # state-save code (wave 0) and finalize path
+])
+def test_forced_non_resident_grid_falls_back_transparently(kind, batch, waves):
+    """Workgroups forced onto 32 compute units that cannot hold them all: most of the grid waits
+    for words of workgroups that have no slot.  The waits give up (20 ms by default; 5 ms here), the grid drains, and the
     finalize kernel reruns the steps: exactly the per-step path's results, in seconds."""
     probe = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff"})
     if probe["capacity"] >= 2048:
         pytest.skip("this runtime ignores ROC_GLOBAL_CU_MASK")
-    r = _child({"ROC_GLOBAL_CU_MASK": "0xffffffff", "VRP_PERSISTENT_FORCE": "1",
-                "VRP_PERSISTENT_LEASE": "0", "GUARD_KIND": str(kind)}, timeout=120)
+    extra = {"ROC_GLOBAL_CU_MASK": "0xffffffff", "VRP_PERSISTENT_FORCE": "1",
+             "VRP_PERSISTENT_LEASE": "0", "GUARD_KIND": str(kind), "GUARD_B": str(batch),
+             "VRP_PERSISTENT_SPIN_MS": "5"}
+    if waves:
+        extra["VRP_PERSISTENT_WAVES"] = str(waves)
+    r = _child(extra, timeout=120)
     print("forced non-resident episodes:", r)
     assert r["equal"] and not r["nan"] and r["T"][0] == r["T"][1], r
     assert r["traces_equal"] and r["env_state_equal"], r

@@ -440,3 +440,61 @@ def test_three_bf16_planes_carry_an_fp32_product():
     rms = lambda v: float(np.sqrt(np.mean((v.astype(np.float64) - ref) ** 2)))
     assert rms(six) <= 1.5 * rms(chain)          # fp32 accuracy
     assert rms(three) > 5 * rms(six)             # two planes are not enough
+
+
+# ---- spill audit (round 6): registers / scratch of the kernels the BASELINE shapes dispatch, read
+# from the shipped library's code objects (AMDGPU metadata notes; tools/kernel_resources.py) ----------
+# name (demangled, without the argument list) -> largest .vgpr_spill_count this instance may have.
+# 0 everywhere except where a comment says why: a spill reload is a scratch (vector-memory) load
+# whose s_waitcnt also waits for every prefetched operand and table store issued before it.
+HOT_KERNEL_SPILL_BUDGET = {
+    # headline: TSP-20 x 512 greedy rollout
+    # (four dwords -- two addresses and an index of the final store and of the per-layer BN
+    #  constants -- stored once before the layer loop and read back once per layer / at the end:
+    #  outside every MFMA stage; the kernel sits at exactly 256 registers with two weight
+    #  fragments of 48 live across the attention)
+    "encoder_stack_x3_kernel<3>": 4,
+    "gemm_nt_m16_k128_kernel": 0,
+    # (eight waves per workgroup on one LDS copy of the head's weight fragments: 23 registers over
+    #  the 256 a wave may address, and still 7 % faster than four unspilled waves -- DESIGN.md 3.2;
+    #  the reloads sit at pack boundaries, not inside stage 1)
+    "prologue_tables_kernel<3, true, false, true>": 23,
+    "decode_step_rt_kernel<1, 1>": 0,
+    "score_base_kernel<2>": 0,
+    "decode_persistent4_kernel<4>": 0,
+    "persistent_finalize_kernel": 0,
+    # north star: TSP / VRP-40 x 8192
+    "encoder_qkv_attn8_x3_kernel<5>": 0,
+    "encoder_block8_x3_kernel<4>": 0,
+    "decode_step_tile_zmfma_kernel<40, 2, false>": 0,
+    "decode_step_rt_kernel<1, 4>": 0,
+    "score_base_kernel<4>": 0,
+    "rollout_setup_kernel": 0,
+    "graph_mean_cvec_kernel": 0,
+    # config 5: VRP-100 x 2048 sampling
+    "prologue_tables_kernel<7, true, true, false>": 0,
+    "decode_step_tile_zmfma_kernel<100, 1, false>": 0,
+    "decode_step_rt_kernel<2, 1>": 0,
+    # configs 3 / 4: training epochs
+    "gemm_rows_x3_kernel<4>": 0,
+    "gemm_tn_x3_kernel": 0,
+    "decode_persistent_kernel": 0,
+}
+
+
+def test_hot_kernels_do_not_spill():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    table = {name.split("(")[0].replace("void ", "").strip(): r
+             for name, r in kernel_resources.resources().items()}
+    missing = [k for k in HOT_KERNEL_SPILL_BUDGET if k not in table]
+    assert not missing, f"hot kernels not found in the library (renamed?): {missing}"
+    over = {k: (table[k]["vgpr_spill"], table[k]["scratch"]) for k, budget in HOT_KERNEL_SPILL_BUDGET.items()
+            if table[k]["vgpr_spill"] > budget}
+    assert not over, f"(spilled registers, scratch bytes) above the audited budget: {over}"
+    # an instance with no spilled register has no scratch at all
+    for k, budget in HOT_KERNEL_SPILL_BUDGET.items():
+        if budget == 0:
+            assert table[k]["scratch"] == 0, (k, table[k])
+    # every kernel fits the register file of its launch bounds (a sanity check of the reader)
+    assert all(0 < r["vgpr"] <= 512 and r["agpr"] <= r["vgpr"] for r in table.values())   # (.vgpr_count includes the AGPRs)

@@ -17,6 +17,11 @@ EMB, HEADS = 128, 8
 _struct_cache = weakref.WeakKeyDictionary()  # module -> (struct, keepalive tensors)
 _derived_cache = weakref.WeakKeyDictionary()  # decoder -> (version key, device buffer)
 _scratch = weakref.WeakKeyDictionary()  # owner (model / module) -> {tag: scratch tensor}
+# encoder -> {"split": tensor, "pad": [_PaddedFF, ...]}: the device-side SHADOWS of an encoder's
+# weights (bf16 planes, zero-padded feed-forward copies).  They outlive invalidate(): a captured
+# hipGraph has their addresses baked into its kernel arguments, so a rebuilt struct must find
+# the same buffers again (refreshed in place), not fresh allocations next to freed ones.
+_shadows = weakref.WeakKeyDictionary()
 ROLLOUT_LOG = None    # bench.py: a list collecting a RolloutSteps per rollout (step accounting)
 
 
@@ -54,6 +59,11 @@ class _PaddedFF:
         self.g_w2 = torch.zeros((EMB, hp), dtype=torch.float32, device=dev)
         self.version = None
 
+    def matches(self, layer, hp):
+        return (self.ff0 is layer.ff[0] and self.ff2 is layer.ff[2] and self.hp == hp
+                and self.h == layer.ff[0].weight.shape[0]
+                and self.w0.device == layer.ff[0].weight.device)
+
     def sync(self):
         ver = (self.ff0.weight._version, self.ff0.bias._version, self.ff2.weight._version,
                self.ff0.weight.data_ptr(), self.ff2.weight.data_ptr())
@@ -72,12 +82,15 @@ class _SplitWeights:
     weight's version counter moves (optimizer step, load_state_dict, the zero-padded feed-forward
     shadows being re-synced), so captured hipGraphs keep pointing at it."""
 
-    def __init__(self, w, mats, dev):
+    def __init__(self, w, mats, dev, reuse=None):
         lib = hip.lib()
         self.mats = mats
-        self.buf = torch.empty(int(lib.vrp_encoder_split_bytes(w.hidden, w.num_layers)),
-                               dtype=torch.uint8, device=dev)
-        self.version = None
+        nbytes = int(lib.vrp_encoder_split_bytes(w.hidden, w.num_layers))
+        if reuse is not None and reuse.numel() == nbytes and reuse.device == torch.device(dev):
+            self.buf = reuse       # same address as before invalidate(): see _shadows
+        else:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.version = None        # forces a re-prepare into the (possibly reused) buffer
         w.split = self.buf.data_ptr()
 
     def sync(self, w):
@@ -90,8 +103,14 @@ class _SplitWeights:
 
 
 def invalidate(module):
+    """Forget the cached pointer structs of a module (its parameters were re-created or moved).
+    The device-side shadows stay (`_shadows`, and `decoder_derived` keeps its buffer through
+    `_derived_cache` being refreshed in place): the next `encoder_struct` re-fills them at the
+    same addresses, which is what a captured hipGraph replays against."""
     _struct_cache.pop(module, None)
-    _derived_cache.pop(module, None)
+    state = _derived_cache.get(module)
+    if state is not None:
+        _derived_cache[module] = (None, state[1])   # version key dropped, buffer kept
 
 
 def _dev(module):
@@ -184,7 +203,13 @@ def encoder_struct(enc):
             setattr(L, tag + "_running_var", P(bn.running_var))
             setattr(L, tag + "_num_batches_tracked", P(bn.num_batches_tracked))
         if hp != hidden:
-            pad = _PaddedFF(layer, hp, layer.ff[0].weight.device)
+            old_pads = _shadows.get(enc, {}).get("pad", [])
+            pad = None
+            if i < len(old_pads) and old_pads[i].matches(layer, hp):
+                pad = old_pads[i]          # same shadow tensors as before invalidate()
+                pad.version = None
+            if pad is None:
+                pad = _PaddedFF(layer, hp, layer.ff[0].weight.device)
             pad.sync()
             padded.append(pad)
             L.ff0_weight, L.ff0_bias, L.ff2_weight = P(pad.w0), P(pad.b0), P(pad.w2)
@@ -200,10 +225,22 @@ def encoder_struct(enc):
             pad = padded[i] if padded else None
             mats += [att.in_proj_weight, att.out_proj.weight,
                      pad.w0 if pad else layer.ff[0].weight, pad.w2 if pad else layer.ff[2].weight]
-        split = _SplitWeights(w, mats, enc.node_embed.weight.device)
+        split = _SplitWeights(w, mats, enc.node_embed.weight.device,
+                              reuse=_shadows.get(enc, {}).get("split"))
         split.sync(w)
+    _shadows[enc] = {"split": split.buf if split is not None else None, "pad": padded}
     _struct_cache[enc] = (w, keep, padded, split)
     return w
+
+
+def shadow_pointers(enc):
+    """Addresses of the encoder's device-side shadows (part of a captured graph's identity)."""
+    encoder_struct(enc)
+    sh = _shadows.get(enc, {})
+    ptrs = [sh["split"].data_ptr() if sh.get("split") is not None else 0]
+    for pad in sh.get("pad", []):
+        ptrs += [pad.w0.data_ptr(), pad.b0.data_ptr(), pad.w2.data_ptr()]
+    return tuple(ptrs)
 
 
 def padded_ff(enc):
@@ -450,12 +487,22 @@ class _CapturedRollout:
         with torch.cuda.graph(self.graph):
             launch()
         # capture only records; state is untouched
+        # The choice between the persistent step grid and one launch per step
+        # (vrp_persistent_width: residency, failure back-off, cross-process lease) was made ONCE,
+        # during the capture, and is frozen into the graph.  The failure counter at that moment:
+        # if it has moved by the time of a replay, somebody else is on this device and the frozen
+        # grid would pay the bounded spin + in-kernel fallback on every episode -- _graph_rollout
+        # then drops the graph and the episode runs eagerly (where the library decides afresh).
+        self.failures0 = int(lib.vrp_persistent_failures())
 
     @staticmethod
     def _pointer_key(model, env):
+        # (the shadows keep their addresses across invalidate(); should one ever move -- another
+        # device, another hidden width -- the key changes and the rollout is captured again)
         return (env._pos.data_ptr(), env._visited.data_ptr(), env._mask.data_ptr(),
                 model.encoder.node_embed.weight.data_ptr(),
-                model.decoder.attention.q_proj_weight.data_ptr())
+                model.decoder.attention.q_proj_weight.data_ptr(),
+                decoder_derived(model.decoder, env.KIND).data_ptr()) + shadow_pointers(model.encoder)
 
     def valid_for(self, model, env):
         return self.ptrs == self._pointer_key(model, env)
@@ -483,6 +530,10 @@ def _graph_rollout(model, env, greedy, train, tile_kernel, dev):
     elif cap.model_ref() is not model or cap.env_ref() is not env:
         _graphs.pop(key)  # id() reuse after garbage collection
         return _graph_rollout(model, env, greedy, train, tile_kernel, dev)
+    if int(hip.lib().vrp_persistent_failures()) != cap.failures0:
+        _graphs.pop(key, None)   # the device is shared (see _CapturedRollout): eager from here,
+        env.__dict__.get("_graph_sightings", set()).discard(key)   # captured again on a later sighting
+        return None
     decoder_derived(model.decoder, env.KIND)  # in-place refresh if the weights changed
     encoder_struct(model.encoder)             # likewise the zero-padded feed-forward shadows
     if cap.noise is not None:

@@ -861,10 +861,15 @@ static void device_lease_open(PersistDevice &pd, int dev) {
     if (*c == '/' || *c == ' ') *c = '_';
   char path[160];
   snprintf(path, sizeof(path), "/dev/shm/vrpgym_hip.%u.%s", (unsigned)getuid(), bus);
-  const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0600);
+  // /dev/shm is world-writable and the name is predictable: never follow a link somebody planted
+  // there, accept only a plain file of our own with one name, and grow it -- never shrink it
+  const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC | O_NOFOLLOW, 0600);
   if (fd < 0) return;
+  struct stat sb;
   void *m = MAP_FAILED;
-  if (ftruncate(fd, 8) == 0) m = mmap(nullptr, 8, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_uid == getuid() && sb.st_nlink == 1 &&
+      (sb.st_size >= 8 || ftruncate(fd, 8) == 0))
+    m = mmap(nullptr, 8, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   close(fd);
   if (m == MAP_FAILED) return;
   pd.lease = reinterpret_cast<std::atomic<unsigned long long> *>(m);

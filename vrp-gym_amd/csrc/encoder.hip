@@ -1373,6 +1373,11 @@ __device__ __forceinline__ void qa8_stage_attention_valu(const float *Q_s, int N
     for (int i = 0; i < 4; ++i) {
       const float *vr = kbase + 128 + min(n0 + i, N - 1) * QA_QLD;
       const f32x2 p2 = {pw[i], pw[i]};                     // 0 for a key past the graph's last
+#ifndef VRP_ATT_NOFENCE
+      // (two keys' value rows in flight, not four: the kernel around this stage keeps two weight
+      // fragments -- 96 registers -- alive across it)
+      if (i == 2) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 t = *reinterpret_cast<const float4 *>(vr + 4 * j);
