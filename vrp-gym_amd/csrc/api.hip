@@ -160,6 +160,7 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
                                  int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
                                  float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
                                  const float *dec_warm, int dec_warm_floats,
+                                 const float *dec_wqgT, const float *dec_bq, float *dec_QG,
                                  int *decoder_constants_done, hipStream_t st);
 int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
                            void *workspace, int constants_done, void *stream);
@@ -188,7 +189,8 @@ static int rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived
   return vrp_encoder_forward_from_env(ew, train, env, emb, enc_workspace, io->acc_loss,
                                       io->acc_logp, io->notdone, max_steps + 1, d.mb, w.g, w.cvec,
                                       w.hist, w.err, use_fused_prologue(N) ? d.Wproj : nullptr,
-                                      1536 * 128, constants_done, (hipStream_t)stream);
+                                      1536 * 128, d.WqgT, d.bq, w.QG, constants_done,
+                                      (hipStream_t)stream);
 }
 
 extern "C" int vrp_rollout_encode(int kind, const vrp_encoder_weights *ew, void *derived,

@@ -830,8 +830,8 @@ extern "C" int vrp_decode_prologue(int kind, const void *derived, int B, int N, 
   return vrp_decode_prologue_ex(kind, derived, B, N, emb, workspace, 0, stream);
 }
 
-// constants_done: the graph mean, cvec and the cleared hand-off words were already produced by
-// the encoder's stack kernel (vrp_rollout, small batches)
+// constants_done: bit 0: the graph mean, cvec and the cleared hand-off words were already produced
+// by the encoder's stack kernel (vrp_rollout, small batches); bit 1: QG as well
 int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const float *emb,
                            void *workspace, int constants_done, void *stream) {
   VRP_REQUIRE(derived && emb && workspace, "decode_prologue: NULL argument");
@@ -840,13 +840,14 @@ int vrp_decode_prologue_ex(int kind, const void *derived, int B, int N, const fl
   hipStream_t st = (hipStream_t)stream;
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs w = carve_decws(workspace, B, N);
-  if (!constants_done) {
+  if (!(constants_done & 1)) {
     hipLaunchKernelGGL(graph_mean_cvec_kernel, dim3(B), dim3(256), 0, st, emb, d.mb, N, w.g, w.cvec,
                        w.hist, w.err);
     VRP_CHECK_LAUNCH("graph_mean_cvec");
   }
-  if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
-                                 st)) return r;
+  if (!(constants_done & 2))   // (the x3 stack kernel's epilogue leaves QG too)
+    if (int r = vrp_launch_gemm_nt(w.g, 128, d.Wqg, 128, d.bq, nullptr, 0, w.QG, 384, B, 384, 128, 0,
+                                   st)) return r;
   if (use_fused_prologue(N)) {
     const PrologueParams p = prologue_params(kind, B, N, emb, d, w);
     if (int r = (N & 3) == 0 ? launch_prologue_vec<true>(p, st) : launch_prologue_vec<false>(p, st))

@@ -31,6 +31,8 @@ struct Derived {
                    // (x3_common.h): [head 8][X 4][column tile 3] fragments of X3_FRAG bf16 = three
                    // planes x four k-chunks x 64 lanes x 8; lane (j16, q), chunk j holds row
                    // X*384 + 48 head + 16 tile + j16, k = 64 (q & 1) + 32 (q >> 1) + 8 j .. + 7
+  float *WqgT;     // (128,384)  Wqg transposed: the stack kernel's epilogue computes QG = Wq_g g + bq
+                   // for its own graphs, lane = output column (coalesced), instead of a GEMM launch
 };
 
 static inline Derived carve_derived(void *base) {
@@ -54,12 +56,14 @@ static inline Derived carve_derived(void *base) {
   d.WvP = p;   p += 384 * 128;
   d.MP = p;    p += 128 * 384;
   d.WprojX3 = p; p += VRP_WPROJ_X3_FLOATS;
+  d.WqgT = p;  p += 128 * 384;
   return d;
 }
 
 static inline int64_t derived_floats() {
   return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
-         128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384 + VRP_WPROJ_X3_FLOATS;
+         128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384 + VRP_WPROJ_X3_FLOATS +
+         128 * 384;
 }
 
 // ------------------------------------------------------------------ per-episode workspace

@@ -2365,7 +2365,29 @@ struct StackEpilogue {
   const float *warm;           // the decoder prologue's projection weights (786 KB): touched here,
   int warm_floats;             // one share per workgroup, so that they wait in every XCD's L2
                                // when the prologue starts (58 -> 55 us at 512 x 20)
+  const float *wqgT, *bq;      // (128,384), (384): graph-embedding block of the glimpse query, and
+  float *QG;                   // (B,384) = Wq_g g + bq of this workgroup's graphs (round 6: was a
+                               // GEMM launch of its own between the encoder and the prologue)
 };
+// QG rows of the workgroup's graphs from their means in LDS (`gs`: [graphs][128]): thread = output
+// column (coalesced reads of WqgT rows), four graphs per pass over the weights, fmaf in k order.
+__device__ __forceinline__ void stack_epilogue_qg(const StackEpilogue &ep, const float *gs, int g0,
+                                                  int graphs, int tid) {
+  if (tid >= 384) return;
+  const float bias = ep.bq[tid];
+  for (int gb = 0; gb < graphs; gb += 4) {
+    float acc[4] = {bias, bias, bias, bias};
+#pragma unroll 8
+    for (int k = 0; k < 128; ++k) {
+      const float wv = ep.wqgT[k * 384 + tid];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = fmaf(gs[min(gb + u, graphs - 1) * 128 + k], wv, acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (gb + u < graphs) ep.QG[(size_t)(g0 + gb + u) * 384 + tid] = acc[u];
+  }
+}
 struct StackSetup {            // rollout set-up fused in front (vrp_rollout): env may be null
   vrp_env env;
   float *acc_loss, *acc_logp;
@@ -2852,11 +2874,13 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
         *reinterpret_cast<const float4 *>(stage + r * EB_LD + c4);
   }
   if (ep.g) {
+    float *gs = reinterpret_cast<float *>(XB3);   // [graphs][128]: the means once more, for QG below
     for (int i = tid; i < graphs * 128; i += 512) {
       const int g = i >> 7, cc = i & 127;
       float s = 0.f;
       for (int n = 0; n < N; ++n) s += stage[(g * N + n) * EB_LD + cc];
       ep.g[(size_t)(g0 + g) * VRP_EMB + cc] = s / (float)N;
+      gs[i] = s / (float)N;
     }
     const float2 m = reinterpret_cast<const float2 *>(ep.mb)[lane];
     for (int r = wave; r < rows; r += 8) {
@@ -2869,6 +2893,10 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       ep.hist[(size_t)t * B + g0 + g] = 0ull;
     }
     if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
+    if (ep.QG) {
+      __syncthreads();
+      stack_epilogue_qg(ep, gs, g0, graphs, tid);
+    }
     if (ep.warm) {
       const int per_xcd = (gridDim.x + 7) >> 3, slot = blockIdx.x >> 3;
       const int lines = ep.warm_floats >> 5;
@@ -3370,6 +3398,7 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
                                  int32_t *notdone, int nflags, const float *dec_mb, float *dec_g,
                                  float *dec_cvec, unsigned long long *dec_hist, int32_t *dec_err,
                                  const float *dec_warm, int dec_warm_floats,
+                                 const float *dec_wqgT, const float *dec_bq, float *dec_QG,
                                  int *decoder_constants_done, hipStream_t st) {
   const int B = env->B, N = env->N;
   if (int r = encoder_check(w, B, N)) return r;
@@ -3385,9 +3414,16 @@ int vrp_encoder_forward_from_env(const vrp_encoder_weights *w, int train, const 
     su.nflags = nflags; su.from_env = 1;
     static const bool no_warm = getenv("VRP_NO_WARM") != nullptr;  // A/B aid
     StackEpilogue ep = {dec_mb, dec_g, dec_cvec, dec_hist, dec_err, no_warm ? nullptr : dec_warm,
-                        dec_warm_floats};
-    *decoder_constants_done = dec_g != nullptr;
-    if (encoder_stack_x3_applies(w)) return launch_encoder_stack_x3<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
+                        dec_warm_floats, nullptr, nullptr, nullptr};
+    *decoder_constants_done = dec_g != nullptr;   // bit 0: graph mean, cvec, cleared hand-off words
+    if (encoder_stack_x3_applies(w)) {
+      static const bool no_qg = getenv("VRP_NO_STACK_QG") != nullptr;   // A/B aid
+      if (dec_g && dec_QG && !no_qg) {
+        ep.wqgT = dec_wqgT; ep.bq = dec_bq; ep.QG = dec_QG;
+        *decoder_constants_done |= 2;             // bit 1: QG = Wq_g g + bq
+      }
+      return launch_encoder_stack_x3<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
+    }
     return launch_encoder_stack<3>(w, nullptr, nullptr, emb, B, N, su, ep, st);
   }
   float *cur = (w->num_layers % 2 == 0) ? emb : ws.h0;
