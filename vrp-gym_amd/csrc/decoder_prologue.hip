@@ -572,16 +572,22 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   p.kind = kind; p.B = B; p.N = N;
   int G = fused_max_rows(N) / N;
   if (G > 4) G = 4;
-  // The x3 stage 1 holds the rows' fp32 values AND a chunk's planes: at five row tiles that is 81
-  // registers more than the VALU-addressable 256, the spill reloads drain the table stores
-  // (vmcnt(0)) and the kernel waits 36 % of its time (profiles/r05_x3_pmc.txt).  Packs of at most
-  // four tiles: N = 20: three graphs (60 rows), N = 40: one (48-row tiles, 40 used).
-  // Among those, the pack size with the fewest (rounds of the 1024 wave slots) x (row tiles per
-  // unit) -- stage 1 is the bulk of a unit: TSP-20 x 512: G = 2 (2048 units, two per wave: 51 us;
-  // G = 3: 1368 units, a third of the waves run twice: 65 us; G = 4 at five tiles: 54 us).
-  static const int max_tiles = getenv("VRP_PRO_X3_TILES") ? atoi(getenv("VRP_PRO_X3_TILES")) : 4;
+  // The x3 stage 1 holds the rows' fp32 values AND a chunk's planes.  Eight waves per workgroup
+  // leave a wave 256 registers: three row tiles fit with 23 of them spilled at pack boundaries,
+  // FOUR spill 250 and FIVE 543 inside the products, and their reloads drain the table stores.
+  // Measured (round 6, tools/prologue_sizes.py, profiles/r06_prologue_sizes.txt; B = 8192):
+  //   N = 20 / 30 / 32 in packs of <= 3 tiles: 576 / 719 / 634 us, in packs of <= 4: 671 / 1225 / 922;
+  //   ONE graph of four tiles (N = 50 / 64): bf16 planes 2620 / 2054 us, fp32 MFMA 2679 / 2306;
+  //   ONE graph of five tiles (N = 72 / 80): bf16 planes 4136 / 4544 us, fp32 MFMA 3017 / 3058.
+  // So: packs of at most three tiles; a single graph may take four; five-tile graphs stay on the
+  // fp32 MFMA instances (p.WprojX3 = nullptr below).  Among the admissible pack sizes the one with
+  // the fewest (rounds of the 2048 wave slots) x (row tiles per unit) -- stage 1 is the bulk of a
+  // unit: TSP-20 x 512: G = 2 (2048 units, one per wave).
+  static const int max_tiles = getenv("VRP_PRO_X3_TILES") ? atoi(getenv("VRP_PRO_X3_TILES")) : 3;
   if (G > B) G = B;
-  if (prologue_x3_enabled() && fused_max_rows(N) <= 80) {
+  bool x3 = prologue_x3_enabled() && fused_max_rows(N) <= 80;
+  if (x3 && (N + 15) / 16 >= 5) x3 = false;            // one graph = five tiles: fp32 is faster
+  if (x3) {
     int best = 0;
     long best_cost = 0;
     for (int g = G; g >= 1; --g) {
@@ -596,7 +602,7 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   p.G = G;
   p.npacks = (B + G - 1) / G;
   p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
-  p.WprojX3 = reinterpret_cast<const __bf16 *>(d.WprojX3);
+  p.WprojX3 = x3 ? reinterpret_cast<const __bf16 *>(d.WprojX3) : nullptr;
   p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.SL = w.SL; p.RT = w.RT;
   return p;
 }
