@@ -2369,23 +2369,45 @@ struct StackEpilogue {
   float *QG;                   // (B,384) = Wq_g g + bq of this workgroup's graphs (round 6: was a
                                // GEMM launch of its own between the encoder and the prologue)
 };
-// QG rows of the workgroup's graphs from their means in LDS (`gs`: [graphs][128]): thread = output
-// column (coalesced reads of WqgT rows), four graphs per pass over the weights, fmaf in k order.
-__device__ __forceinline__ void stack_epilogue_qg(const StackEpilogue &ep, const float *gs, int g0,
-                                                  int graphs, int tid) {
-  if (tid >= 384) return;
-  const float bias = ep.bq[tid];
+// QG rows of the workgroup's graphs from their means in LDS (`gs`: [graphs][128]; `part`: scratch
+// of 4 x 4 x 384 floats).  384 threads: thread = (four consecutive output columns c4, one quarter
+// kg of the 128-long inner dimension): 32 coalesced 16-byte loads of WqgT, all in flight at once --
+// the first version walked k = 0..127 per column with eight loads in flight and spent 13.5 k cycles
+// (16 dependent L2 round trips) in a kernel whose whole epilogue was 4 k.  The four partial sums
+// of a column are added in kg order, then the bias.  Four graphs per pass.
+__device__ __forceinline__ void stack_epilogue_qg(const StackEpilogue &ep, const float *gs,
+                                                  float *part, int g0, int graphs, int tid) {
+  const int c4 = (tid % 96) * 4, kg = tid / 96;      // tid < 384: 96 column quads x 4 k-quarters
   for (int gb = 0; gb < graphs; gb += 4) {
-    float acc[4] = {bias, bias, bias, bias};
-#pragma unroll 8
-    for (int k = 0; k < 128; ++k) {
-      const float wv = ep.wqgT[k * 384 + tid];
+    if (tid < 384) {
+      float4 acc[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] = fmaf(gs[min(gb + u, graphs - 1) * 128 + k], wv, acc[u]);
+      for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float *wp = ep.wqgT + (size_t)(32 * kg) * 384 + c4;
+#pragma unroll 16
+      for (int k = 0; k < 32; ++k) {
+        const float4 wv = *reinterpret_cast<const float4 *>(wp + (size_t)k * 384);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float gv = gs[min(gb + u, graphs - 1) * 128 + 32 * kg + k];
+          acc[u].x = fmaf(gv, wv.x, acc[u].x); acc[u].y = fmaf(gv, wv.y, acc[u].y);
+          acc[u].z = fmaf(gv, wv.z, acc[u].z); acc[u].w = fmaf(gv, wv.w, acc[u].w);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(part + (kg * 4 + u) * 384 + c4) = acc[u];
     }
+    __syncthreads();
+    if (tid < 384) {
+      const float bias = ep.bq[tid];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (gb + u < graphs) ep.QG[(size_t)(g0 + gb + u) * 384 + tid] = acc[u];
+      for (int u = 0; u < 4; ++u)
+        if (gb + u < graphs)
+          ep.QG[(size_t)(g0 + gb + u) * 384 + tid] =
+              bias + (((part[(0 * 4 + u) * 384 + tid] + part[(1 * 4 + u) * 384 + tid]) +
+                       part[(2 * 4 + u) * 384 + tid]) + part[(3 * 4 + u) * 384 + tid]);
+    }
+    __syncthreads();
   }
 }
 struct StackSetup {            // rollout set-up fused in front (vrp_rollout): env may be null
@@ -2732,12 +2754,14 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
 #pragma unroll
     for (int rt = 0; rt < RT16; ++rt) a[rt] = f32x4v{0.f, 0.f, 0.f, 0.f};
   };
-  // One layer.  Two fragment buffers: on entry A holds the layer's first in_proj fragment; A then
-  // carries in_proj tile 2 and the ff.0 slices, B in_proj tile 1, out_proj and the ff.2 slices --
-  // except at the layer's tail: the LAST ff.2 slice goes into A (free after the last way up, so
-  // the request has the way down of the slice before to hide behind; requested into B it would
-  // follow that way down and be needed right after the barrier), and the NEXT layer's first
-  // in_proj fragment into B.  The buffers therefore swap roles from layer to layer.
+  // One layer.  Two fragment buffers with FIXED roles (round 6): on entry A holds the layer's first
+  // in_proj fragment.  Stage -> buffer it reads / fragment requested piecewise under it:
+  //   in_proj 0: A / B <- in_proj 1      in_proj 1: B / A <- in_proj 2     in_proj 2: A / B <- Wo
+  //   attention: (A <- ff.0 slice 0, twelve loads at once: the vector memory pipe is idle here)
+  //   out-proj: B / -      up 0: A / B <- ff.0 slice 1
+  //   up ch+1: B / A <- ff.2 slice ch    down ch: A / B <- ff.0 slice ch+2 (last pass: the LAST ff.2 slice)
+  //   last down: B / A <- the next layer's first in_proj fragment
+  // Every fragment travels under the stage right before the one that uses it, none at a boundary.
   auto layer = [&](int l, Frag3 &A, Frag3 &B) {
     const vrp_encoder_layer &L = w.layer[l];
     const __bf16 *lf = split + (size_t)l * per_layer * X3_FRAG;
@@ -2805,8 +2829,10 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     {
       const float4 b1v = x3_ld4(L.ff0_bias + cq);
       zero(acc);
-      x3_mma<RT16>(acc, XB3, PE, A, lane);
-      if (nchunk > 1) x3_load_frag(A, lf + (size_t)x3_frag_w1(8 + wave) * X3_FRAG, lane);
+      // (slice 0 goes up on A; B -- free since the out-projection -- takes ff.0 slice 1 under it, so
+      // that NO fragment of the feed-forward is requested at a stage boundary: round 6)
+      x3_mma<RT16>(acc, XB3, PE, A, lane,
+                   X3FragStream(B, lf + (size_t)x3_frag_w1((nchunk > 1 ? 8 : 0) + wave) * X3_FRAG, lane));
 #pragma unroll
       for (int rt = 0; rt < RT16; ++rt) up_store(rt, b1v, AT3);
     }
@@ -2817,15 +2843,15 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       __bf16 *hcur = (ch & 1) ? H1 : AT3, *hnext = (ch & 1) ? AT3 : H1;
       const float4 b1v = x3_ld4(L.ff0_bias + (ch + 1) * 128 + cq);
       zero(acc);
-      // up: slice ch + 1 (reads A); B -- free since the out-projection / the last way down -- takes
-      // the ff.2 slice of the way down that follows
-      x3_mma<RT16>(acc, XB3, PE, A, lane,
-                   X3FragStream(B, lf + (size_t)x3_frag_w2(hidden, wave, ch) * X3_FRAG, lane));
-      // A is free: the next ff.0 slice, or the LAST ff.2 slice, travels under the way down
-      const X3FragStream sa(A, (ch + 2 < nchunk) ? lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG
+      // up: slice ch + 1 (reads B); A -- free since the way up before -- takes the ff.2 slice of the
+      // way down that follows
+      x3_mma<RT16>(acc, XB3, PE, B, lane,
+                   X3FragStream(A, lf + (size_t)x3_frag_w2(hidden, wave, ch) * X3_FRAG, lane));
+      // B is free: the next ff.0 slice, or the LAST ff.2 slice, travels under the way down
+      const X3FragStream sa(B, (ch + 2 < nchunk) ? lf + (size_t)x3_frag_w1((ch + 2) * 8 + wave) * X3_FRAG
                                                  : lf + (size_t)x3_frag_w2(hidden, wave, ch + 1) * X3_FRAG, lane);
       ST_MARK(4 + 24 * l + 9 + 3 * ch);
-      x3_mma<RT16>(gacc, hcur, PE, B, lane, [&](int it) {                    // down: slice ch
+      x3_mma<RT16>(gacc, hcur, PE, A, lane, [&](int it) {                    // down: slice ch
         sa(it);
         if (it < RT16) up_store(it, b1v, hnext);
       });
@@ -2841,8 +2867,8 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       // (hidden >= 256: see the loop)  The next layer's first in_proj fragment travels under it
       // (the last layer requests its own first fragment again: twelve loads nobody uses, cheaper
       // than a branch inside the MFMA sequence)
-      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, A, lane,
-                   X3FragStream(B, lf + (size_t)(l + 1 < w.num_layers ? per_layer + x3_frag_win(wave * 3) : 0) * X3_FRAG, lane));
+      x3_mma<RT16>(gacc, ((nchunk - 1) & 1) ? H1 : AT3, PE, B, lane,
+                   X3FragStream(A, lf + (size_t)(l + 1 < w.num_layers ? per_layer + x3_frag_win(wave * 3) : 0) * X3_FRAG, lane));
       ST_MARK(4 + 24 * l + 21);
       // ---- y = BN2(y1 + g + b2): the next layer's input ----------------------------------------
 #pragma unroll
@@ -2857,10 +2883,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
     ST_MARK(4 + 24 * l + 23);
     __syncthreads();
   };
-  for (int l = 0; l < w.num_layers; l += 2) {
-    layer(l, fa, fb);
-    if (l + 1 < w.num_layers) layer(l + 1, fb, fa);
-  }
+  for (int l = 0; l < w.num_layers; ++l) layer(l, fa, fb);   // (one copy of the layer's code: 41 -> 25 KB)
   ST_MARK(ST_SLOTS - 3);
   // ---- result: through the fp32 staging rows, coalesced 16-byte stores; the decoder's per-graph
   // constants on the way
@@ -2893,9 +2916,9 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
       ep.hist[(size_t)t * B + g0 + g] = 0ull;
     }
     if (blockIdx.x == 0 && tid == 0) *ep.err = 0;
-    if (ep.QG) {
+    if (ep.QG) {   // (workgroup-uniform)
       __syncthreads();
-      stack_epilogue_qg(ep, gs, g0, graphs, tid);
+      stack_epilogue_qg(ep, gs, gs + 16 * 128, g0, graphs, tid);   // (XB3's 36 KB: means, then 24 KB of partials)
     }
     if (ep.warm) {
       const int per_xcd = (gridDim.x + 7) >> 3, slot = blockIdx.x >> 3;
