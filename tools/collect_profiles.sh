@@ -3,9 +3,9 @@
 #   kernel stats of the default bench command, per-shape kernel stats (TSP / VRP 8192x40,
 #   VRP 2048x100 sampling, TSP 512x20), training epochs of configs 3 and 4, and the PMC passes
 #   (FETCH_SIZE / WRITE_SIZE in separate runs, --kernel-trace only) behind roofline.traffic.
-# usage: bash tools/collect_profiles.sh r04
+# usage: bash tools/collect_profiles.sh r06
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -42,4 +42,8 @@ rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_
 { echo "== bias + residual + ReLU (gemm_rows_kernel)"; VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only (N = 384 / 256, K = 128: gemm_rows_wide_kernel)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; echo "== bias only, VRP_GEMM_ROWS_NARROW=1 (gemm_rows_kernel everywhere)"; GEMM_PROBE_PLAIN=1 VRP_GEMM_ROWS_NARROW=1 VRP_GEMM_VARIANT=rows python3 tools/gemm_rows_probe.py run 2>/dev/null | grep "M="; } > $OUT/gemm_rows_probe.txt
 { echo "== gemm_tn_x3_kernel (bf16 planes, the default)"; python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R="; echo "== VRP_GEMM_FP32=1: gemm_tn_kernel (fp32 MFMA), same box"; VRP_GEMM_FP32=1 python3 tools/gemm_tn_probe.py 2>/dev/null | grep "R="; } > $OUT/gemm_tn_probe.txt
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc/lds_gemm_tn -o p -- python3 tools/gemm_tn_probe.py > $OUT/pmc_lds_gemm_tn.log 2>&1
+# round 6: whole-rollout wall clock against the round-5 library on THIS box (libvar_r05.so = the library
+# of commit 8d3e66b, built by the caller), and the stack kernel's per-phase shader-clock trace
+[ -f vrp-gym_amd/vrpgym_hip/libvar_r05.so ] && bash tools/gpu_r6_wall3.sh 2>&1 | grep "kind=" > $OUT/wall_vs_r05.txt
+[ -f vrp-gym_amd/vrpgym_hip/libvar_trace.so ] && VRPGYM_HIP_LIB=$PWD/vrp-gym_amd/vrpgym_hip/libvar_trace.so python3 tools/rollout_loop.py 0 20 512 10 > $OUT/stack_trace.txt 2>&1
 ls $OUT

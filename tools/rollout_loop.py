@@ -18,7 +18,7 @@ dev = torch.device("cuda", 0)
 env, agent = bench.make(kind, N, B, 69, dev)
 with torch.no_grad():
     for _ in range(K):
-        bench.rewind(env)
-        res = runtime.rollout(agent.model, env, greedy)
+        # the way bench.py runs it: the episode reset is part of the rollout's own set-up kernel
+        res = runtime.rollout(agent.model, env, greedy, reset_env=True)
     torch.cuda.synchronize()
 print("T", res.T, "cost", float(-res.acc_loss.mean()))

@@ -1365,10 +1365,15 @@ __device__ __forceinline__ void qa8_stage_attention_valu(const float *Q_s, int N
 #pragma unroll
     for (int i = 0; i < 4; ++i) pw[i] = __builtin_amdgcn_exp2f((sc[i] - mn) * l2e);
     l = fmaf(l, corr, (pw[0] + pw[1]) + (pw[2] + pw[3]));
-    m = mn;
-    const f32x2 c2 = {corr, corr};
+    // (a lane whose maximum did not move has corr = exp2(0) = 1 exactly: when that holds for the
+    // whole wave -- usual after the first block or two -- the eight packed multiplies are skipped,
+    // bit for bit the same result)
+    if (__builtin_amdgcn_ballot_w64(mn != m) != 0ull) {
+      const f32x2 c2 = {corr, corr};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o2[j] *= c2;
+      for (int j = 0; j < 8; ++j) o2[j] *= c2;
+    }
+    m = mn;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float *vr = kbase + 128 + min(n0 + i, N - 1) * QA_QLD;
