@@ -127,36 +127,6 @@ __global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_table
   const int first = (xcd * nsub + sub) * NWV + wave;
   const bool fold = p.kind == VRP_KIND_IRP;
 
-  if constexpr (X3) {
-    const float4 *src = reinterpret_cast<const float4 *>(p.WprojX3 + (size_t)h * 12 * X3_FRAG);
-    for (int i = tid; i < 12 * X3_FRAG / 8; i += NTH) reinterpret_cast<float4 *>(lds)[i] = src[i];
-  } else {
-    for (int i = tid; i < 4 * 48 * 32; i += NTH) {
-      const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
-      const float4 v = *reinterpret_cast<const float4 *>(
-          p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
-      *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
-    }
-  }
-  if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
-  if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
-  // tile pairs (tm, tn) that contain two nodes of one graph (wave-uniform bit mask)
-  unsigned long long needmask = 0;
-  {
-    const int rows = G * N;
-#pragma unroll
-    for (int tm = 0; tm < RT_; ++tm) {
-      const int lo_m = (16 * tm) / N, hi_m = min(16 * tm + 15, rows - 1) / N;
-#pragma unroll
-      for (int tn = 0; tn < RT_; ++tn) {
-        const int lo_n = (16 * tn) / N, hi_n = min(16 * tn + 15, rows - 1) / N;
-        if (16 * tm < rows && 16 * tn < rows && lo_m <= hi_n && lo_n <= hi_m)
-          needmask |= 1ull << (tm * RT_ + tn);
-      }
-    }
-  }
-  __syncthreads();
-
   const int koff = 64 * (q & 1) + 32 * (q >> 1);
   const float c48 = 0.14433756729740643f;  // 1/sqrt(48)
   float eq[RING ? 2 : 1][RT_][8];
@@ -196,7 +166,40 @@ __global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_table
       }
     }
   };
+  // (round 6: the first pack's rows are requested BEFORE the head's weights are staged into LDS --
+  // one round trip instead of two in a row at kernel start; a small-batch launch runs one pack per wave)
   if (first < p.npacks) load_pack(first);
+
+  if constexpr (X3) {
+    const float4 *src = reinterpret_cast<const float4 *>(p.WprojX3 + (size_t)h * 12 * X3_FRAG);
+    for (int i = tid; i < 12 * X3_FRAG / 8; i += NTH) reinterpret_cast<float4 *>(lds)[i] = src[i];
+  } else {
+    for (int i = tid; i < 4 * 48 * 32; i += NTH) {
+      const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
+      const float4 v = *reinterpret_cast<const float4 *>(
+          p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
+      *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
+    }
+  }
+  if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
+  if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
+  // tile pairs (tm, tn) that contain two nodes of one graph (wave-uniform bit mask)
+  unsigned long long needmask = 0;
+  {
+    const int rows = G * N;
+#pragma unroll
+    for (int tm = 0; tm < RT_; ++tm) {
+      const int lo_m = (16 * tm) / N, hi_m = min(16 * tm + 15, rows - 1) / N;
+#pragma unroll
+      for (int tn = 0; tn < RT_; ++tn) {
+        const int lo_n = (16 * tn) / N, hi_n = min(16 * tn + 15, rows - 1) / N;
+        if (16 * tm < rows && 16 * tn < rows && lo_m <= hi_n && lo_n <= hi_m)
+          needmask |= 1ull << (tm * RT_ + tn);
+      }
+    }
+  }
+  __syncthreads();
+
 
   for (int pack = first; pack < p.npacks; pack += stride) {
     // (the weight slices are re-read from LDS for every pack: keeping them in registers
