@@ -29,12 +29,12 @@ done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp40 -o p -- python3 tools/rollout_loop.py 0 40 8192 3 > $OUT/pmc_mfma.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_tsp20 -o p -- python3 tools/rollout_loop.py 0 20 512 10 > $OUT/pmc_mfma20.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/mfma_vrp100 -o p -- python3 tools/rollout_loop.py 1 100 2048 3 0 > $OUT/pmc_mfma100.log 2>&1
-# round 4: the tall GEMM of the training path, the raw-tile kernel's phases and
-# the per-CU streaming rate behind DESIGN.md 3.5.1
+# round 4: the tall GEMM of the training path (docs/rounds/DESIGN_rounds_1-5.md 3.4.1), the raw-tile kernel's phases and
+# the per-CU streaming rate behind docs/rounds/DESIGN_rounds_1-5.md 3.5.1
 VRP_GEMM_VARIANT=rows rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/gemm_rows -o p -- python3 tools/gemm_one.py 81920 384 128 > $OUT/pmc_gemm_rows.log 2>&1
 { python3 tools/tile_phase_probe.py 1 100 2048 3 1; python3 tools/tile_phase_probe.py 0 40 8192 3 0; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 1 100 2048 3 1; VRP_TILE_V1=1 python3 tools/tile_phase_probe.py 0 40 8192 3 0; } 2>/dev/null | grep "us through phase" > $OUT/tile_phases.txt
 [ -x tools/micro/stream_rate ] && tools/micro/stream_rate > $OUT/stream_rate.txt 2>&1
-# round 5: fp32 products on the bf16 matrix cores (DESIGN.md 3.11): accuracy / rate probe, and the
+# round 5: fp32 products on the bf16 matrix cores (DESIGN.md 3.4): accuracy / rate probe, and the
 # LDS counters of the bf16-plane kernels (bank conflicts of the swizzled operand images)
 [ -x tools/micro/bf16x3_probe ] && tools/micro/bf16x3_probe > $OUT/bf16x3_probe.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc/lds_tsp40 -o p -- python3 tools/rollout_loop.py 0 40 8192 3 > $OUT/pmc_lds.log 2>&1

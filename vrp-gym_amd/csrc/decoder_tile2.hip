@@ -603,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void decode_step_tile_zmfma_kernel(StepPara
 // (Round 4, measured and removed: the tile RESIDENT for a whole episode -- steps 1..T-1 of VRP-100 x
 // 2048 in ONE launch, the tile in registers across steps, masks exchanged as hand-off words as in
 // decoder_persistent.hip: 3.52 ms for 111 steps = 31.7 us per step against 31.5 for the per-step
-// schedule; hipcc spilled 92 registers inside the step loop.  DESIGN.md 3.5.1; the kernel is in the
+// schedule; hipcc spilled 92 registers inside the step loop.  docs/rounds/DESIGN_rounds_1-5.md 3.5.1; the kernel is in the
 // history of this file, commit 2458ff7.)
 
 template <int NMAX, int GPW, bool IRP>

@@ -1861,7 +1861,7 @@ __global__ __launch_bounds__(512) void gemm_rows_x3_kernel(
   }
 }
 
-// (Round 4, measured and NOT kept -- DESIGN.md 3.5: the pass epilogue spread over the next pass's
+// (Round 4, measured and NOT kept -- docs/rounds/DESIGN_rounds_1-5.md 3.5: the pass epilogue spread over the next pass's
 // k-step groups, 127 vs 117 us at 81920 x 384 x 128; two four-wave workgroups of 48-row tiles per
 // CU instead of one eight-wave workgroup of 80 rows, 187 vs 120 us.  PMC on this kernel: matrix
 // pipe busy 52 % of the cycles, waves parked 27 % -- its eight waves reach the two barriers of a
