@@ -106,9 +106,11 @@ struct PrologueParams {
 #define PT_X3_WAVES 8
 #endif
 template <int RT_, bool VEC, bool RING = (RT_ > 5), bool X3 = false>
-__global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_tables_kernel(PrologueParams p) {
-  constexpr int NWV = X3 ? PT_X3_WAVES : 4, NTH = 64 * NWV;
-  static_assert(!(X3 && RING), "the x3 stage 1 serves the whole-pack (non-ring) instances");
+__global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void prologue_tables_kernel(PrologueParams p) {
+  // (RING + X3, round 6: the six / seven-tile graphs' projections on the bf16 matrix cores too -- a
+  // ring quarter IS one 32-deep bf16 k-chunk of the fragment order; one wave per SIMD, as the fp32
+  // RING instances: 7 x 24 accumulator registers + the rows' ring leave no room for a second)
+  constexpr int NWV = (X3 && !RING) ? PT_X3_WAVES : 4, NTH = 64 * NWV;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *wl = lds;                              // [4][48][PT_LD] weight slices of this head, or
   const __bf16 *wl3 = reinterpret_cast<const __bf16 *>(lds);   // X3: [4][3] fragments of X3_FRAG bf16
@@ -257,6 +259,31 @@ __global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_table
         for (int qi = 0; qi < 4; ++qi) {
           if (qi + 1 < 4) load_quarter(pack, qi + 1, (qi + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (X3) {
+            // quarter qi = k-chunk qi of the weight fragments: split the quarter's rows once, run the
+            // three key-side column tiles against them (six MFMAs per product, small terms first)
+            bf16x8 ep[RT_][3];
+#pragma unroll
+            for (int r = 0; r < RT_; ++r) x3_split8(eq[qi & 1][r], ep[r][0], ep[r][1], ep[r][2]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const bf16x8 *wf =
+                  reinterpret_cast<const bf16x8 *>(wl3 + (size_t)((2 * H + 1) * 3 + c) * X3_FRAG) + lane;
+              const bf16x8 wh = wf[(0 * 4 + qi) * 64], wm = wf[(1 * 4 + qi) * 64], wlo = wf[(2 * 4 + qi) * 64];
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wm, ep[r][1], acc[1][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wh, ep[r][2], acc[1][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wlo, ep[r][0], acc[1][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wh, ep[r][1], acc[1][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wm, ep[r][0], acc[1][c][r]);
+#pragma unroll
+              for (int r = 0; r < RT_; ++r) acc[1][c][r] = X3_MFMA(wh, ep[r][0], acc[1][c][r]);
+            }
+          } else
 #pragma unroll
           for (int Y = 1; Y < 2; ++Y)
 #pragma unroll
@@ -465,6 +492,36 @@ __global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_table
             const float4 bb = *reinterpret_cast<const float4 *>(bl + (2 * H) * 48 + 16 * c + 4 * q);
             acc[0][c][0] = f32x4{bb.x, bb.y, bb.z, bb.w};
           }
+          if constexpr (X3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float x8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) x8[e] = et[tm & 1][8 * j + e];
+              bf16x8 eh, em, el;
+              x3_split8(x8, eh, em, el);
+              bf16x8 wh[3], wm[3], wlo[3];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const bf16x8 *wf =
+                    reinterpret_cast<const bf16x8 *>(wl3 + (size_t)((2 * H) * 3 + c) * X3_FRAG) + lane;
+                wh[c] = wf[(0 * 4 + j) * 64]; wm[c] = wf[(1 * 4 + j) * 64]; wlo[c] = wf[(2 * 4 + j) * 64];
+              }
+              // the three column tiles take turns: consecutive MFMAs never share an accumulator
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wm[c], em, acc[0][c][0]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wh[c], el, acc[0][c][0]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wlo[c], eh, acc[0][c][0]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wh[c], em, acc[0][c][0]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wm[c], eh, acc[0][c][0]);
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc[0][c][0] = X3_MFMA(wh[c], eh, acc[0][c][0]);
+            }
+          } else {
           // the three column tiles take turns: consecutive MFMAs never share an accumulator
           const float *wrow = wl + ((2 * H) * 48 + j16) * PT_LD + koff;
           float4 a[3], an[3];
@@ -487,6 +544,7 @@ __global__ __launch_bounds__(X3 ? 64 * PT_X3_WAVES : 256, 1) void prologue_table
                                                                    acc[0][c][0], 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < 3; ++c) a[c] = an[c];
+          }
           }
         }
 #pragma unroll
@@ -541,7 +599,7 @@ static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
   }
   // one workgroup per CU (100 - 150 KB of LDS each): 8 heads x nsub x 8 XCD slots; fewer when the
   // batch has fewer packs than wave slots
-  constexpr int NWV = X3 ? PT_X3_WAVES : 4;
+  constexpr int NWV = (X3 && RT_ <= 5) ? PT_X3_WAVES : 4;
   int nsub = 4;
   while (nsub > 1 && 8 * (nsub / 2) * NWV >= p.npacks) nsub /= 2;
   hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>), dim3(64 * nsub), dim3(64 * NWV), lds, st, p);
@@ -550,9 +608,7 @@ static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
 }
 template <int RT_, bool VEC>
 static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
-  if constexpr (RT_ <= 5) {
-    if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true>(p, st);
-  }
+  if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true>(p, st);
   return launch_prologue_tables_as<RT_, VEC, false>(p, st);
 }
 
@@ -605,7 +661,11 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   p.G = G;
   p.npacks = (B + G - 1) / G;
   p.emb = emb; p.Wproj = d.Wproj; p.bproj = d.bproj; p.QG = w.QG; p.qc0 = d.qc0; p.wload = d.wload;
-  p.WprojX3 = x3 ? reinterpret_cast<const __bf16 *>(d.WprojX3) : nullptr;
+  // (one graph of six / seven tiles, 80 < N <= 112: the RING instances, on bf16 planes since round 6;
+  // VRP_PROLOGUE_RING_FP32=1 keeps them on the fp32 MFMA: A/B aid)
+  static const bool ring_fp32 = getenv("VRP_PROLOGUE_RING_FP32") != nullptr;
+  const bool ring_x3 = prologue_x3_enabled() && fused_max_rows(N) > 80 && !ring_fp32;
+  p.WprojX3 = (x3 || ring_x3) ? reinterpret_cast<const __bf16 *>(d.WprojX3) : nullptr;
   p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.SL = w.SL; p.RT = w.RT;
   return p;
 }
