@@ -474,6 +474,9 @@ HOT_KERNEL_SPILL_BUDGET = {
     # config 5: VRP-100 x 2048 sampling
     "prologue_tables_kernel<7, true, true, false>": 0,
     "decode_step_tile_zmfma_kernel<100, 1, false>": 0,
+    # (19 registers around the attention phase, as the fp32 kernel it replaces (26); the next
+    #  graph's prefetched rows additionally wait in scratch across the attention, once per graph)
+    "encoder_qkv_attn_graph_x3_kernel<7>": 19,
     "decode_step_rt_kernel<2, 1>": 0,
     # configs 3 / 4: training epochs
     "gemm_rows_x3_kernel<4>": 0,

@@ -3293,6 +3293,148 @@ static int launch_qkv_attn8_x3(const float *x, const vrp_encoder_weights *w, int
   return 0;
 }
 
+// ---- 64 < N <= 102, eval mode: encoder_qkv_attn_graph_kernel with the projection on the bf16 planes
+// (round 6).  The q|k|v rows of one graph fill the LDS (155 KB at N = 100), so there is no room for
+// a plane image of the input tile: the fp32 tile sits where q|k|v rows 64.. go (as in the fp32
+// kernel, projection in two row halves) and a lane splits ITS OWN operand -- the 8 values of row
+// i16, k = 32 j + 8 q .. + 7 -- in registers, once per (row tile, chunk), for the wave's three
+// column tiles.  The three weight fragments (144 registers) are reloaded per graph: they are dead
+// during the attention, which needs the registers.  Same products, k order and accumulators as
+// x3_mma; six MFMAs per 32 k instead of eight fp32 MFMAs at a sixteenth of the rate.
+// HOLD: rows whose q|k|v would land on input rows other waves still read (rows >= 64) keep their
+// results in registers until a barrier; the others are stored row tile by row tile.
+template <int RTN, bool HOLD>
+__device__ __forceinline__ void qag_project_x3(const float *X_s, float *Q_s, const Frag3 (&f)[3],
+                                               const float4 (&bb)[3], int lane, int wave, int vrows) {
+  const int i16 = lane & 15, q = lane >> 4;
+  f32x4v acc[HOLD ? RTN : 1][3];
+  auto store = [&](int rt, const f32x4v (&a)[3]) {
+    if (rt * 16 + i16 < vrows) {
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)   // D[column][row]: four consecutive columns of row i16
+        *reinterpret_cast<float4 *>(Q_s + (rt * 16 + i16) * QA_QLD + wave * 48 + ct * 16 + 4 * q) =
+            make_float4(a[ct][0] + bb[ct].x, a[ct][1] + bb[ct].y, a[ct][2] + bb[ct].z, a[ct][3] + bb[ct].w);
+    }
+  };
+  // the lane's operand of item (rt, j), one item ahead of the MFMAs that consume it
+  const float *xp = X_s + i16 * QA_XLD + 8 * q;
+  float4 a0 = *reinterpret_cast<const float4 *>(xp), a1 = *reinterpret_cast<const float4 *>(xp + 4);
+#pragma unroll
+  for (int rt = 0; rt < RTN; ++rt) {
+    f32x4v (&d)[3] = acc[HOLD ? rt : 0];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) d[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x8[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const int nit = rt * 4 + j + 1;
+      if (nit < 4 * RTN) {
+        const float *np = xp + (nit >> 2) * 16 * QA_XLD + 32 * (nit & 3);
+        a0 = *reinterpret_cast<const float4 *>(np);
+        a1 = *reinterpret_cast<const float4 *>(np + 4);
+      }
+      bf16x8 h, m, l;
+      x3_split8(x8, h, m, l);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[1][j], m, d[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[2][j], h, d[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[0][j], l, d[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[1][j], h, d[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[0][j], m, d[ct]);
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) d[ct] = X3_MFMA(f[ct].p[0][j], h, d[ct]);
+    }
+    if (!HOLD) store(rt, d);
+  }
+  if (HOLD) {
+    __syncthreads();   // every wave has read its rows: q|k|v may land on the input tile
+#pragma unroll
+    for (int rt = 0; rt < RTN; ++rt) store(rt, acc[HOLD ? rt : 0]);
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(512) void encoder_qkv_attn_graph_x3_kernel(const float *__restrict__ x,
+                                                                         const __bf16 *__restrict__ lf_,
+                                                                         const float *__restrict__ bin,
+                                                                         float *__restrict__ att, int B,
+                                                                         int N) {
+  constexpr int RTW = 16 * NT, PF = RTW * 32 / 512;
+  static_assert(NT >= 5 && NT <= 7, "64 < N <= 102");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Q_s = smem;
+  float *X_s = smem + 64 * QA_QLD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4;
+  float4 pf[PF];
+  auto fetch = [&](int g) {
+    const int row0 = g * N;   // (32-bit offsets: B N 128 < 2^31, checked by the launcher)
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      pf[u] = *reinterpret_cast<const float4 *>(x + ((row0 + min(r, N - 1)) * VRP_EMB + c4));   // (clamped, no branch)
+    }
+  };
+  int g = blockIdx.x;
+  if (g < B) fetch(g);
+  for (; g < B; g += gridDim.x) {
+    int zero;   // (keeps the fragment loads inside the loop: see encoder_block8_x3_kernel)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const __bf16 *lf = lf_ + zero;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = tid + 512 * u, r = idx >> 5, c4 = (idx & 31) * 4;
+      *reinterpret_cast<float4 *>(X_s + r * QA_XLD + c4) = pf[u];   // rows >= N: copies of the last row, never read back
+    }
+    {
+      Frag3 f[3];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) x3_load_frag(f[ct], lf + (size_t)x3_frag_win(wave * 3 + ct) * X3_FRAG, lane);
+      float4 bb[3];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) bb[ct] = x3_ld4(bin + wave * 48 + ct * 16 + 4 * q);
+      __syncthreads();
+      qag_project_x3<4, false>(X_s, Q_s, f, bb, lane, wave, 64);
+      qag_project_x3<NT - 4, true>(X_s + 64 * QA_XLD, Q_s + 64 * QA_QLD, f, bb, lane, wave, N - 64);
+    }
+    __syncthreads();
+    fetch(min(g + (int)gridDim.x, B - 1));   // (after the projection: its registers are free now; no branch around the loads)
+    attention_rows_mfma<NT, QA_QLD, false>(Q_s, att + (size_t)g * N * VRP_EMB, N, lane, wave);
+    __syncthreads();   // everybody done with Q_s before the next graph lands in X_s
+  }
+}
+static int launch_qkv_attn_graph_x3(const float *x, const vrp_encoder_weights *w, int l, float *att,
+                                    int B, int N, hipStream_t st) {
+  const int NT = (N + 15) / 16;
+  const size_t fl = (size_t)N * QA_QLD > (size_t)64 * QA_QLD + (size_t)16 * NT * QA_XLD
+                        ? (size_t)N * QA_QLD : (size_t)64 * QA_QLD + (size_t)16 * NT * QA_XLD;
+  const size_t lds = fl * sizeof(float);
+  const void *fn = NT == 5 ? reinterpret_cast<const void *>(&encoder_qkv_attn_graph_x3_kernel<5>)
+                 : NT == 6 ? reinterpret_cast<const void *>(&encoder_qkv_attn_graph_x3_kernel<6>)
+                           : reinterpret_cast<const void *>(&encoder_qkv_attn_graph_x3_kernel<7>);
+  static VrpAttrOnce attr_set[3];
+  if (!attr_set[NT - 5].done()) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      vrp_set_error("qkv_attn_graph_x3: cannot raise dynamic LDS to 160 KB");
+      return 1;
+    }
+    attr_set[NT - 5].mark();
+  }
+  const __bf16 *lf = reinterpret_cast<const __bf16 *>(w->split) +
+                     (size_t)l * x3_layer_frags(w->hidden) * X3_FRAG;
+  const float *bin = w->layer[l].in_proj_bias;
+  const dim3 grid(min(B, 256)), block(512);
+  if (NT == 5) hipLaunchKernelGGL(encoder_qkv_attn_graph_x3_kernel<5>, grid, block, lds, st, x, lf, bin, att, B, N);
+  else if (NT == 6) hipLaunchKernelGGL(encoder_qkv_attn_graph_x3_kernel<6>, grid, block, lds, st, x, lf, bin, att, B, N);
+  else hipLaunchKernelGGL(encoder_qkv_attn_graph_x3_kernel<7>, grid, block, lds, st, x, lf, bin, att, B, N);
+  VRP_CHECK_LAUNCH("encoder_qkv_attn_graph_x3");
+  return 0;
+}
+
 // small batches, eval mode: all layers in one launch, G = 48 / N whole graphs per workgroup
 static bool encoder_stack_applies(const vrp_encoder_weights *w, int train, int B, int N) {
   static const char *stack_off = getenv("VRP_ENCODER_NO_STACK");  // A/B aid
@@ -3508,7 +3650,10 @@ static int encoder_layers(const vrp_encoder_weights *w, int train, int B, int N,
         return r;
     } else if (heads == 8 && qkv_attn_graph_applies(train, B, N)) {
       // 64 < N <= 102, eval mode: in_proj + attention of one graph per workgroup pass, q|k|v in LDS
-      if (int r = launch_qkv_attn_graph(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
+      static const bool qag_fp32 = getenv("VRP_QAG_FP32") != nullptr;   // A/B aid
+      if (int r = encoder_x3_enabled(w) && encoder_x3_rows_ok((long)B * N) && !qag_fp32
+                      ? launch_qkv_attn_graph_x3(cur, w, l, ws.att, B, N, st)
+                      : launch_qkv_attn_graph(cur, L.in_proj_weight, L.in_proj_bias, ws.att, B, N, st)) return r;
     } else {
       if (int r = vrp_launch_gemm_nt(cur, 128, L.in_proj_weight, 128, L.in_proj_bias, nullptr, 0,
                                      ws.qkv, 384, R, 384, 128, 0, st)) return r;
