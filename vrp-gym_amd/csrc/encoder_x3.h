@@ -44,14 +44,20 @@ __device__ __forceinline__ void x3_store(__bf16 *tile, int plane_elems, int row,
   p[plane_elems] = s.m;
   p[2 * plane_elems] = s.l;
 }
-// four consecutive columns
+// four consecutive columns: two values per conversion instruction (v_cvt_pk_bf16_f32) and per
+// subtraction (v_pk_add_f32), as x3_split8 -- the same roundings as x3_split, element by element
 __device__ __forceinline__ void x3_store4(__bf16 *tile, int plane_elems, int row, int col,
                                           float v0, float v1, float v2, float v3) {
-  const Bf3 a = x3_split(v0), b = x3_split(v1), c = x3_split(v2), d = x3_split(v3);
+  const x3_f32x2 a = {v0, v1}, b = {v2, v3};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const x3_f32x2 ra = a - __builtin_convertvector(ha, x3_f32x2), rb = b - __builtin_convertvector(hb, x3_f32x2);
+  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+  const x3_f32x2 sa = ra - __builtin_convertvector(ma, x3_f32x2), sb = rb - __builtin_convertvector(mb, x3_f32x2);
+  const bf16x2 la = __builtin_convertvector(sa, bf16x2), lb = __builtin_convertvector(sb, bf16x2);
   __bf16 *p = tile + x3_off(row, col);   // col % 4 == 0: the four stay inside one chunk
-  *reinterpret_cast<bf16x4 *>(p) = bf16x4{a.h, b.h, c.h, d.h};
-  *reinterpret_cast<bf16x4 *>(p + plane_elems) = bf16x4{a.m, b.m, c.m, d.m};
-  *reinterpret_cast<bf16x4 *>(p + 2 * plane_elems) = bf16x4{a.l, b.l, c.l, d.l};
+  *reinterpret_cast<bf16x4 *>(p) = __builtin_shufflevector(ha, hb, 0, 1, 2, 3);
+  *reinterpret_cast<bf16x4 *>(p + plane_elems) = __builtin_shufflevector(ma, mb, 0, 1, 2, 3);
+  *reinterpret_cast<bf16x4 *>(p + 2 * plane_elems) = __builtin_shufflevector(la, lb, 0, 1, 2, 3);
 }
 
 // A weight fragment: 16 weight rows (= output columns) x 128 k, three planes, in registers.
