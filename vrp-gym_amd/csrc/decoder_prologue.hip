@@ -168,13 +168,22 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       }
     }
   };
-  // (round 6: the first pack's rows are requested BEFORE the head's weights are staged into LDS --
-  // one round trip instead of two in a row at kernel start; a small-batch launch runs one pack per wave)
-  if (first < p.npacks) load_pack(first);
 
   if constexpr (X3) {
+    // (nine 16-byte loads in flight per thread, then their LDS stores: written as a plain loop the
+    // compiler kept ONE load in flight -- load, s_waitcnt vmcnt(0), ds_write, 18 times: eighteen L2
+    // round trips in a row, ~10 us at the head of every launch; round 6, found in the ISA)
     const float4 *src = reinterpret_cast<const float4 *>(p.WprojX3 + (size_t)h * 12 * X3_FRAG);
-    for (int i = tid; i < 12 * X3_FRAG / 8; i += NTH) reinterpret_cast<float4 *>(lds)[i] = src[i];
+    constexpr int NV = 12 * X3_FRAG / 8 / NTH;   // 18 (eight waves) or 36 (four)
+    static_assert(NV % 9 == 0 && NV * NTH * 8 == 12 * X3_FRAG, "staging loop geometry");
+#pragma unroll
+    for (int b0 = 0; b0 < NV; b0 += 9) {
+      float4 t[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) t[u] = src[tid + (b0 + u) * NTH];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) reinterpret_cast<float4 *>(lds)[tid + (b0 + u) * NTH] = t[u];
+    }
   } else {
     for (int i = tid; i < 4 * 48 * 32; i += NTH) {
       const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
@@ -183,6 +192,10 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
     }
   }
+  // the first pack's rows: requested right behind the weights' loads (their LDS stores above have
+  // retired the registers; hoisted in front of the staging the 96 row registers made the compiler
+  // serialise the staging loads again)
+  if (first < p.npacks) load_pack(first);
   if (tid < 4 * 48) bl[tid] = p.bproj[(tid / 48) * 384 + h * 48 + tid % 48];
   if (tid < PT_MAXROWS) rowinfo[tid] = ((tid / N) << 8) | (tid % N);
   // tile pairs (tm, tn) that contain two nodes of one graph (wave-uniform bit mask)
