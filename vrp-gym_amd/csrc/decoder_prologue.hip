@@ -185,11 +185,22 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       for (int u = 0; u < 9; ++u) reinterpret_cast<float4 *>(lds)[tid + (b0 + u) * NTH] = t[u];
     }
   } else {
-    for (int i = tid; i < 4 * 48 * 32; i += NTH) {
-      const int c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
-      const float4 v = *reinterpret_cast<const float4 *>(
-          p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
-      *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = v;
+    // (eight loads in flight per thread: see the bf16-plane branch above)
+    constexpr int NV = 4 * 48 * 32 / NTH;   // 24
+    static_assert(NV % 8 == 0, "staging loop geometry");
+#pragma unroll
+    for (int b0 = 0; b0 < NV; b0 += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid + (b0 + u) * NTH, c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
+        t[u] = *reinterpret_cast<const float4 *>(p.Wproj + ((size_t)(X * 384 + h * 48 + row)) * 128 + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid + (b0 + u) * NTH, c4 = i & 31, row = (i >> 5) % 48, X = i / (48 * 32);
+        *reinterpret_cast<float4 *>(wl + (X * 48 + row) * PT_LD + 4 * c4) = t[u];
+      }
     }
   }
   // the first pack's rows: requested right behind the weights' loads (their LDS stores above have
