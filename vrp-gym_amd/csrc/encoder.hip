@@ -2672,12 +2672,16 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
   SetupLoads sl;
   float bnraw[2][4];
   if (su.from_env) {
-    if (wave < graphs * su_parts) sl = setup_graph_load(su.env, w, g0 + wave / su_parts, lane);
+    // the BN statistics FIRST: which layer a thread's element belongs to is wave-uniform (64
+    // consecutive threads share i >> 7), so the four array pointers are scalar loads from the
+    // kernel arguments -- indexed per thread, the compiler fetched the pointers themselves with
+    // vector loads and the values behind them: two dependent round trips behind the graph's
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = tid + 512 * u;
-      if (i < 2 * w.num_layers * 128) {
-        const int blk = i >> 7, cc = i & 127, l = blk >> 1, second = blk & 1;
+      const int blk = __builtin_amdgcn_readfirstlane(i >> 7);
+      if (blk < 2 * w.num_layers) {
+        const int cc = i & 127, l = blk >> 1, second = blk & 1;
         const vrp_encoder_layer &L = w.layer[l];
         bnraw[u][0] = (second ? L.bn2_running_mean : L.bn1_running_mean)[cc];
         bnraw[u][1] = (second ? L.bn2_running_var : L.bn1_running_var)[cc];
@@ -2685,6 +2689,7 @@ __global__ __launch_bounds__(512) void encoder_stack_x3_kernel(vrp_encoder_weigh
         bnraw[u][3] = (second ? L.bn2_bias : L.bn1_bias)[cc];
       }
     }
+    if (wave < graphs * su_parts) sl = setup_graph_load(su.env, w, g0 + wave / su_parts, lane);
   }
   for (int idx = tid; idx < RTW * 32; idx += 512) {
     const int r = idx >> 5, c4 = (idx & 31) * 4;
