@@ -19,6 +19,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5          # north_star tolerance on cost / log-prob
+
+
+def _margin(site, err, tol):
+    """With VRPGYM_PARITY_MARGINS=<file> every eval-mode comparison appends `site err tol`: what
+    profiles/r06_parity_margins.txt (the measured distance to each tolerance) was made from."""
+    path = os.environ.get("VRPGYM_PARITY_MARGINS")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(f"{site} {err:.3e} {tol:.3e}\n")
 TIE_GAP = 5e-5      # near-tie exemption threshold on the oracle's top-2 logit gap: twice the
                     # 2e-5 the logits may differ by; the largest slack seen over the 150-case
                     # GPU suite is 2.7e-7 (profiles/r03_parity_tie_statistics.csv, VRPGYM_PARITY_LOG)
@@ -209,7 +218,11 @@ def test_encoder_large_against_oracle():
             want = opol.encoder_forward(sd, x[:, :, :2] if kind != 2 else x,
                                         None if kind == 0 else dm, train=train)
             err = (emb.cpu() - want).abs().max().item()
-            assert err < 2e-5, (kind, B, N, train, err)
+            # eval mode: north_star's 1e-5 (measured over the 15 shapes: 1.4e-6 at most); batch-
+            # statistics BatchNorm amplifies fp32 re-association noise: 2e-5 (measured 1.2e-5)
+            tol = 2e-5 if train else TOL
+            _margin("encoder_large_train" if train else "encoder_large_eval", err, tol)
+            assert err < tol, (kind, B, N, train, err)
 
 
 def test_gemm_mfma_against_torch():
@@ -510,6 +523,7 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
     exempt = np.zeros(B, bool)
     exempt[list(div_ref)] = True
     loss, logp = res.acc_loss.cpu(), res.acc_logp.cpu()
+    _margin("rollout_cost_train" if train else "rollout_cost_eval", (loss - ol).abs().max().item(), TOL)
     assert (loss - ol).abs().max().item() < TOL, (loss - ol).abs().max().item()
     acc_tol = TOL * (1 if greedy else max(1, T / 4))
     if train:
@@ -525,6 +539,8 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         assert acc_err < (TOL if greedy else acc_bound), (acc_err, acc_bound)
         # two fp32 evaluations may sit on opposite sides of the exact value
         acc_tol = max(acc_tol, 0.0 if greedy else acc_bound + o32[2])
+    if not greedy:
+        _margin("rollout_acc_logp_train" if train else "rollout_acc_logp_eval", (logp - olp).abs().max().item(), acc_tol)
     assert (logp - olp).abs().max().item() < acc_tol, (logp - olp).abs().max().item()
     if ref_loss is not None:
         ok = ~exempt
@@ -544,6 +560,8 @@ def _compare_rollout(kind, B, N, greedy, env_seed, agent_seed, torch_seed, ref_a
         worst_du = max(worst_du, err)
         sum_du += d.sum().item()
         n_du += d.numel()
+        if not train:
+            _margin("step_logits_eval", err, 2e-5)
         assert err < (du_bound if train else 2e-5), (t, err, du_bound)
     if train and n_du:
         mean_bound = _train_mean_bound(o32_mean)
@@ -634,7 +652,10 @@ def test_non_default_architecture_encoder_large(hidden, layers, B, N, heads):
         # two fp32 evaluations drift apart layer by layer (every layer renormalises and adds its own
         # rounding): 2e-5 up to five layers, proportionally more beyond (ten layers, train mode:
         # 2.1e-5 with the fp32-MFMA kernels and with the bf16-plane ones alike)
-        assert err < 2e-5 * max(1.0, layers / 5), (hidden, layers, B, N, heads, train, err)
+        # (eval mode: 1e-5 whatever the depth -- measured 3.3e-6 at most, profiles/r06_parity_margins.txt)
+        tol = 2e-5 * max(1.0, layers / 5) if train else TOL
+        _margin("encoder_arch_train" if train else "encoder_arch_eval", err, tol)
+        assert err < tol, (hidden, layers, B, N, heads, train, err)
 
 
 @pytest.mark.parametrize("mode", ["default", "table", "tile"])
