@@ -922,7 +922,9 @@ def test_training_step_against_reference(name, path):
     assert env.step_count == int(z["T"])
     assert np.max(np.abs(loss_m.detach().cpu().numpy() - z["loss_m"])) < TOL
     assert np.max(np.abs(loss_b.cpu().numpy() - z["loss_b"])) < TOL
-    assert np.max(np.abs(logp.detach().cpu().numpy() - z["logp"])) < 5 * TOL
+    # (a sum of T sampled log-probs, |sum| up to 160 on the untrained fixtures: one ulp of the fp32
+    # accumulator is 1.5e-5 there and every step rounds it once -- the rule of the rollout tests)
+    assert np.max(np.abs(logp.detach().cpu().numpy() - z["logp"])) < TOL * max(5, int(z["T"]) / 4)
     adv = (loss_m - loss_b) * -1
     loss = (adv * logp).mean()
     assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))

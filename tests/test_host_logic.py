@@ -458,7 +458,10 @@ HOT_KERNEL_SPILL_BUDGET = {
     # (eight waves per workgroup on one LDS copy of the head's weight fragments: 23 registers over
     #  the 256 a wave may address, and still 7 % faster than four unspilled waves -- DESIGN.md 3.2;
     #  the reloads sit at pack boundaries, not inside stage 1)
-    "prologue_tables_kernel<3, true, false, true>": 23,
+    "prologue_tables_kernel<3, true, false, true, false>": 23,
+    # (the small-batch instance, which also leaves the glimpse keys in memory: two more)
+    "prologue_tables_kernel<3, true, false, true, true>": 25,
+    "first_base_kernel": 0,
     "decode_step_rt_kernel<1, 1>": 0,
     "score_base_kernel<2>": 0,
     "decode_persistent4_kernel<4>": 0,
@@ -472,7 +475,9 @@ HOT_KERNEL_SPILL_BUDGET = {
     "rollout_setup_kernel": 0,
     "graph_mean_cvec_kernel": 0,
     # config 5: VRP-100 x 2048 sampling
-    "prologue_tables_kernel<7, true, true, false>": 0,
+    # (the seven-tile RING instance on bf16 planes: 18 values parked in accumulator registers --
+    #  the code object counts them as spills -- and no scratch)
+    "prologue_tables_kernel<7, true, true, true, false>": 18,
     "decode_step_tile_zmfma_kernel<100, 1, false>": 0,
     # (19 registers around the attention phase, as the fp32 kernel it replaces (26); the next
     #  graph's prefetched rows additionally wait in scratch across the attention, once per graph)

@@ -80,9 +80,13 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
     // latency-bound regime: step 0 as its own launch (the first-node fold follows it), every
     // later step inside ONE persistent launch (decoder_persistent.hip), one, two or four waves
     // per graph
+    // (two- and four-wave grids compute the first node's part of the score rows themselves:
+    // no first-node GEMM, no score_base launch)
+    bool fold_first = false;
     if (t_begin == 0) {
+      fold_first = vrp_persistent_folds_first(kind, env->B, env->N, pwaves, flags);
       if (int r = vrp_decode_step(kind, derived, dw, env, emb, dec_workspace, io, 0, max_steps,
-                                  flags, stream)) return r;
+                                  flags | (fold_first ? VRP_STEP_NO_FIRST_ROW : 0), stream)) return r;
       t_begin = 1;
     }
     VRP_REQUIRE(env->kind == kind && io->acc_loss && io->acc_logp && io->notdone,
@@ -91,7 +95,8 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                 "rollout_steps_range: sampling needs io.noise or io.noise_seed");
     const StepParams sp = vrp_make_step_params(kind, derived, env, emb, dec_workspace, io, t_begin,
                                                 max_steps, flags);
-    return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream, pwaves);
+    return vrp_launch_persistent_steps(sp, dec_workspace, (hipStream_t)stream, pwaves,
+                                       fold_first ? derived : nullptr);
   }
   // One launch per step.  A VRP / IRP episode is over after anything between N - 1 and 2 (N - 1)
   // steps (tsp.py:95: the batch-wide done flag), and a launch queued behind the end leaves at its

@@ -195,6 +195,7 @@ extern "C" int vrp_decoder_prepare(int kind, const vrp_decoder_weights *w, void 
   b.mm(d.M, 384, 1, w->kp_weight, 1, 128, d.tmpA, 384, 1, 128, 384, 128, s);
   b.mm(d.mb, 1, 0, w->kp_weight, 1, 128, d.tmpv, 1, 0, 128, 1, 128, s);
   b.cp(d.WqgT, 1, 384, d.Wqg, 128, 1, 384, 128);   // WqgT[k][j] = Wqg[j][k] (Wqg: launch 1)
+  b.cp(d.WqfT, 1, 384, d.Wqf, 128, 1, 384, 128);   // WqfT[k][j] = Wqf[j][k]
   if (int r = a.launch(st)) return r;
   if (int r = b.launch(st)) return r;
   hipLaunchKernelGGL(pack_fold_weights_kernel, dim3(96), dim3(256), 0, st,

@@ -59,6 +59,12 @@ struct PersistParams {
   int32_t *census;            // residency census mode (vrp_persistent_capacity): {arrived, saw all}
   long long spin_ticks;       // longest wait for a hand-off word, in wall_clock64() ticks
   int32_t *fail_host;         // pinned host counter: episodes of this device that fell back
+  // the first chosen node's part of the score rows, computed by the grid itself (persist_first_base)
+  int fold_first;             // 1: base is not there yet (vrp_decode_first_row was skipped)
+  const float *WqfT;          // (128,384)  Derived::WqfT
+  const float *KK4;           // (B,8,12,N,4)  DecWs::KK4
+  const float *SG;            // (B,8,N)
+  float *base_out;            // (B,8,N)  = StepParams::base, writable
   // the state this launch started from (saved by every graph before it overwrites anything)
   uint8_t *sv_visited;        // (B,N)
   int32_t *sv_cur, *sv_last;  // (B)
@@ -76,6 +82,11 @@ struct PersistParams {
     __builtin_amdgcn_wave_barrier();                         \
   } while (0)
 #define PERSIST_VALID (1ull << 63)
+
+// number of set bits of a wave-wide ballot below this lane (v_mbcnt: no lane-mask pair to keep alive)
+__device__ __forceinline__ int lanes_below(unsigned long long bits) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+}
 
 // One hand-off wait.  Lanes 0..7 poll the mask word of "their" graph until bit 63 shows; lane 8
 // reads the error flag in the same round trip (and reports "not valid" when it is raised), so a
@@ -388,6 +399,122 @@ __global__ __launch_bounds__(64, 3) void decode_persistent_kernel(PersistParams 
   }
 }
 
+// ---- the first chosen node's constant part of every later score row, per graph ----------------
+// base[b][h][n] = SG[b][h][n] + (Wq_first e_first)_h . (Wk e_n + bk)_h / sqrt(48)
+// (graph_decoder.py:88-92: the first-node block of the context projection times the glimpse keys).
+// Until round 6 two launches after step 0 -- a (B x 1024 x 128) GEMM with a row gather (the query
+// folded through the keys: sixteen graphs per workgroup) and score_base_kernel -- 12.7 us at
+// 512 x 20 for a few hundred thousand MACs per graph.  For the small-batch shapes (kk_floats) the
+// graph's own workgroup does it: the query part first (work item = four of the 384 columns x one of
+// TWO halves of k, WqfT rows coalesced, two batches of eight loads in flight: 192 KB through the
+// CU's L1 per graph), then lane n takes the 48-long dot products of its wave's heads against the
+// keys the prologue left in KK4 (coalesced 16-byte loads).  Called by the two- and four-wave
+// persistent kernels ahead of their first step (no launch at all) and by first_base_kernel (the
+// per-step path, the one-wave kernel): one function, one operation order -- `base` does not depend
+// on the path an episode takes.  Also stored to memory: the in-kernel fallback reads it from there.
+template <int NW, int HPW>
+__device__ __forceinline__ void persist_first_base(const PersistParams &pp, int b, int h0, float (&bs)[HPW],
+                                                   float *e_s, float *qp_s, float *curs_out) {
+  constexpr int NTH = 64 * NW;
+  const StepParams &p = pp.s;
+  const int tid = threadIdx.x, lane = tid & 63, N = p.N;
+  const int fb = p.first[b];
+  // (the weights do not depend on the node: their first batch is in flight while the node's
+  // embedding row makes its two round trips; then always one batch ahead of the one consumed)
+  // work item w < 192: column quad w % 96, k half w / 96; NPASS items per thread
+  constexpr int NPASS = (192 + NTH - 1) / NTH;
+  const bool on0 = tid < 192;
+  const int cq0 = on0 ? tid % 96 : 0, kp0 = on0 ? tid / 96 : 0;
+  const float4 *wsrc0 = reinterpret_cast<const float4 *>(pp.WqfT + (size_t)(kp0 * 64) * 384) + cq0;
+  float4 wv[2][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wv[0][u] = wsrc0[(size_t)u * 96];
+  if (tid < 32)
+    reinterpret_cast<float4 *>(e_s)[tid] =
+        reinterpret_cast<const float4 *>(p.emb + ((size_t)b * N + fb) * VRP_EMB)[tid];
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int w = tid + ps * NTH;
+    const bool on = w < 192;
+    const int cq = on ? w % 96 : 0, kp = on ? w / 96 : 0;
+    const float4 *wsrc = ps == 0 ? wsrc0 : reinterpret_cast<const float4 *>(pp.WqfT + (size_t)(kp * 64) * 384) + cq;
+    if (ps > 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wv[0][u] = wsrc[(size_t)u * 96];
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i + 1 < 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[(i + 1) & 1][u] = wsrc[(size_t)(8 * (i + 1) + u) * 96];
+      }
+      const float4 ea = *reinterpret_cast<const float4 *>(e_s + kp * 64 + 8 * i);
+      const float4 eb = *reinterpret_cast<const float4 *>(e_s + kp * 64 + 8 * i + 4);
+      const float ev[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 wq = wv[i & 1][u];
+        acc.x = fmaf(ev[u], wq.x, acc.x); acc.y = fmaf(ev[u], wq.y, acc.y);
+        acc.z = fmaf(ev[u], wq.z, acc.z); acc.w = fmaf(ev[u], wq.w, acc.w);
+      }
+    }
+    if (on) reinterpret_cast<float4 *>(qp_s)[kp * 96 + cq] = acc;   // [half][column quad]
+  }
+  // the keys of this wave's heads: requested before the barrier the query part ends with
+  const bool inN = lane < N;
+  const int ln = inN ? lane : 0;
+  const float c48 = 0.14433756729740643f;  // 1/sqrt(48)
+  float4 kv[2][6];
+  auto load_keys = [&](float4 (&dst)[6], int item) {   // item = 2 * head + half
+    const float4 *kk = reinterpret_cast<const float4 *>(pp.KK4) +
+                       (((size_t)b * 8 + h0 + (item >> 1)) * 12 + 6 * (item & 1)) * N + ln;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) dst[d] = kk[(size_t)d * N];
+  };
+  load_keys(kv[0], 0);
+  float sg[HPW], sl[HPW];
+#pragma unroll
+  for (int j = 0; j < HPW; ++j) {
+    sg[j] = pp.SG[((size_t)b * 8 + h0 + j) * N + ln];
+    sl[j] = curs_out ? p.SL[(((size_t)b * N + fb) * 8 + h0 + j) * N + ln] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < HPW; ++j) {
+    const int h = h0 + j;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int item = 2 * j + half;
+      if (item + 1 < 2 * HPW) load_keys(kv[(item + 1) & 1], item + 1);
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const float4 q0 = reinterpret_cast<const float4 *>(qp_s)[h * 12 + 6 * half + d];
+        const float4 q1 = reinterpret_cast<const float4 *>(qp_s)[96 + h * 12 + 6 * half + d];
+        const float4 k4 = kv[item & 1][d];
+        float &a = (d & 1) ? a1 : a0;
+        a = fmaf(q0.x + q1.x, k4.x, a); a = fmaf(q0.y + q1.y, k4.y, a);
+        a = fmaf(q0.z + q1.z, k4.z, a); a = fmaf(q0.w + q1.w, k4.w, a);
+      }
+    }
+    const float v = fmaf(a0 + a1, c48, sg[j]);
+    bs[j] = v;
+    const size_t o = ((size_t)b * 8 + h) * N + ln;
+    if (inN) pp.base_out[o] = v;
+    if (inN && curs_out) curs_out[o] = sl[j] + v;   // step 1's complete row (last = first), latency mode
+  }
+}
+
+// the same for the paths that do not run it inside a persistent grid: one workgroup per graph
+__global__ __launch_bounds__(256) void first_base_kernel(PersistParams pp) {
+  __shared__ __attribute__((aligned(16))) float fe_s[128];
+  __shared__ __attribute__((aligned(16))) float fq_s[2 * 384];
+  float bs[2];
+  persist_first_base<4, 2>(pp, blockIdx.x, 2 * (threadIdx.x >> 6), bs, fe_s, fq_s, pp.s.curs);
+}
+
 // ---- the same episode loop with FOUR waves per graph (round 4) -----------------------------
 // At B = 512 the kernel above puts two lone waves on every CU: a wave that has a SIMD to itself
 // issues one vector instruction per ~4 cycles, and a step is ~635 of them (2 us) + the hand-off
@@ -418,6 +545,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
   __shared__ float mx_s[NW];
   __shared__ int ctl_s[4];                  // [0] chosen node, [1] 1 = finished / gave up, [2] nsel,
                                             // [3] bits of the vehicle load as fp32 (IRP)
+  __shared__ __attribute__((aligned(16))) float fe_s[128];          // persist_first_base: e_first,
+  __shared__ __attribute__((aligned(16))) float fq_s[2 * 384];      // the query part's two k halves
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -447,17 +576,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
   const size_t row = (size_t)b * 8 * N;
   const int h0 = HPW * wave;   // this wave's heads
 
+  // (first, with nothing else alive: its 40 registers of operands in flight would push the
+  // per-graph state below into scratch for the whole episode)
+  float bs[HPW];
+  if (pp.fold_first) persist_first_base<NW, HPW>(pp, b, h0, bs, fe_s, fq_s, nullptr);   // (uniform over the grid)
   // ---- per-graph state.  Wave 0: the env row (lane = node); every wave: its heads' constants
   const uint8_t *mask0 = p.env.mask + (size_t)(t0 & 1) * B * N;
   int own_mask = mask0[(size_t)b * N + ln];
   int msk[HPW];
 #pragma unroll
   for (int j = 0; j < HPW; ++j) msk[j] = mask0[(size_t)((b * 8 + h0 + j) % B) * N + ln];  // QUIRK D3
-  float sld[HPW], bs[HPW];
+  float sld[HPW];
 #pragma unroll
   for (int j = 0; j < HPW; ++j) {
     sld[j] = (p.kind == VRP_KIND_IRP) ? p.SLD[row + (h0 + j) * N + ln] : 0.f;
-    bs[j] = p.base ? p.base[row + (h0 + j) * N + ln] : 0.f;
+    if (!pp.fold_first) bs[j] = p.base ? p.base[row + (h0 + j) * N + ln] : 0.f;
   }
   const float cv = p.cvec[(size_t)b * N + ln];
   const double2 xy = reinterpret_cast<const double2 *>(p.env.pos)[(size_t)b * N + ln];
@@ -500,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
     const bool s_i = inN && !own_mask;
     const unsigned long long sel = __ballot(s_i);
     if (wave == 0) {
-      if (s_i) sel_s[__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+      if (s_i) sel_s[lanes_below(sel)] = lane;
       if (lane == 0) { ctl_s[1] = 0; ctl_s[2] = __popcll(sel); }
     }
   }
@@ -655,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
       // what the other waves need for the next step
       const bool s_i = inN && !mk;
       const unsigned long long sel = __ballot(s_i);
-      if (s_i) sel_s[__popcll(sel & ((1ull << lane) - 1ull))] = lane;
+      if (s_i) sel_s[lanes_below(sel)] = lane;
       if (lane == 0) {
         ctl_s[0] = idx; ctl_s[1] = finish ? 1 : 0; ctl_s[2] = __popcll(sel);
         ctl_s[3] = __builtin_bit_cast(int, (float)load);
@@ -1221,6 +1354,8 @@ static PersistParams make_persist_params(const StepParams &sp, void *workspace) 
   pp.sv_accp = ws.sv_accp;
   pp.spin_ticks = 2000000;   // 20 ms at 100 MHz
   pp.fail_host = nullptr;
+  pp.fold_first = 0;
+  pp.WqfT = nullptr; pp.KK4 = ws.KK4; pp.SG = ws.SG; pp.base_out = ws.base;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < VRP_MAX_DEVICES) {
     std::lock_guard<std::mutex> guard(g_pdev_lock);
@@ -1237,9 +1372,41 @@ static PersistParams make_persist_params(const StepParams &sp, void *workspace) 
 }
 
 // steps sp.t .. max_steps-1 (sp.t >= 1: step 0 and the first-node fold have run)
+// vrp_decode_first_row for the shapes whose keys the prologue kept (kk_floats): one launch
+int vrp_launch_first_base(int kind, const void *derived, int B, int N, const float *emb,
+                          void *workspace, hipStream_t st) {
+  DecWs ws = carve_decws(workspace, B, N);
+  StepParams sp = {};
+  sp.kind = kind; sp.B = B; sp.N = N; sp.emb = emb;
+  sp.SL = ws.SL; sp.curs = ws.curs; sp.first = ws.first; sp.last = ws.last;
+  PersistParams pp = make_persist_params(sp, workspace);
+  if (!pp.KK4) { vrp_set_error("first_base: no keys kept for B=%d N=%d", B, N); return 1; }
+  pp.fold_first = 1;
+  pp.WqfT = carve_derived(const_cast<void *>(derived)).WqfT;
+  hipLaunchKernelGGL(first_base_kernel, dim3(sp.B), dim3(256), 0, st, pp);
+  VRP_CHECK_LAUNCH("first_base");
+  return 0;
+}
+
+// may the persistent launch that follows step 0 fold the first node into the score rows itself
+// (then step 0 runs with VRP_STEP_NO_FIRST_ROW)?  Two- and four-wave grids, TSP / VRP.
+bool vrp_persistent_folds_first(int kind, int B, int N, int waves, int flags) {
+  static const bool off = getenv("VRP_NO_FOLD_FIRST") != nullptr;   // A/B aid
+  return !off && waves >= 2 && kind != VRP_KIND_IRP && kk_floats(B, N) > 0 &&
+         !(flags & VRP_STEP_NO_FIRST_ROW);
+}
+
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
-                                int waves) {
-  const PersistParams pp = make_persist_params(sp, workspace);
+                                int waves, const void *derived_for_first) {
+  PersistParams pp = make_persist_params(sp, workspace);
+  if (derived_for_first) {
+    if (waves < 2 || !pp.KK4 || sp.t != 1) {
+      vrp_set_error("persistent_steps: first-node fold asked for waves=%d t=%d", waves, sp.t);
+      return 1;
+    }
+    pp.fold_first = 1;
+    pp.WqfT = carve_derived(const_cast<void *>(derived_for_first)).WqfT;
+  }
   // (the hand-off words and the error flag were cleared by vrp_decode_prologue: one persistent
   // launch per episode)
   void *token = nullptr;

@@ -81,6 +81,7 @@ struct PrologueParams {
   const float *emb, *Wproj, *bproj, *QG, *qc0, *wload;
   const __bf16 *WprojX3;   // Derived::WprojX3 (the X3 instances' stage-1 weights)
   float *SG, *C0, *SLD, *row0, *SL, *RT;
+  float *KK4;              // DecWs::KK4 or NULL
 };
 
 // RING (more than five row tiles: one graph of 80 < N <= 112 rows): the rows' inner dimension
@@ -105,7 +106,11 @@ struct PrologueParams {
 #ifndef PT_X3_WAVES
 #define PT_X3_WAVES 8
 #endif
-template <int RT_, bool VEC, bool RING = (RT_ > 5), bool X3 = false>
+// KEEPK (round 6): the small-batch instances also leave the glimpse keys in memory (DecWs::KK4,
+// decoder_persistent.hip: persist_first_base).  A template parameter, not a run-time branch: the
+// store's address arithmetic costs the three-tile bf16 instance eleven more spilled registers,
+// which the large-batch launches (no keys kept) should not pay.
+template <int RT_, bool VEC, bool RING = (RT_ > 5), bool X3 = false, bool KEEPK = false>
 __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void prologue_tables_kernel(PrologueParams p) {
   // (RING + X3, round 6: the six / seven-tile graphs' projections on the bf16 matrix cores too -- a
   // ring quarter IS one 32-deep bf16 k-chunk of the fragment order; one wave per SIMD, as the fp32
@@ -412,6 +417,21 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
         const int nxt = pack + stride;
         if (nxt < p.npacks) load_pack(nxt);
       }
+      if (KEEPK && H == 0) {
+        // the keys of this head leave as they sit in the accumulators: lane (node j, q), column
+        // tile c = columns 16 c + 4 q .. + 3 of the 48 -> element (4 c + q) of KK4[graph][h]
+#pragma unroll
+        for (int r = 0; r < RT_; ++r) {
+          // (row 16 r + j of the pack = node (row - graph N) of graph mg[r]; 32-bit offsets inside the
+          // pack's slice, as for the tables)
+          const int off = ((mg[r] * 8 + h) * 12 + q) * N + (16 * r + j16 - mg[r] * N);
+          float4 *dst = reinterpret_cast<float4 *>(p.KK4) + (size_t)g0 * 96 * N + off;
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            if (mg[r] >= 0)
+              dst[4 * c * N] = make_float4(acc[1][c][r][0], acc[1][c][r][1], acc[1][c][r][2], acc[1][c][r][3]);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
 
       // constant part of the score rows for this lane's four columns of every tile (IRP)
@@ -609,12 +629,12 @@ static bool prologue_x3_enabled() {
   static const bool off = getenv("VRP_PROLOGUE_FP32") != nullptr;
   return !off;
 }
-template <int RT_, bool VEC, bool X3>
+template <int RT_, bool VEC, bool X3, bool KEEPK>
 static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
   const size_t lds = sizeof(float) * ((X3 ? 12 * X3_FRAG / 2 : 4 * 48 * PT_LD) + 4 * 48) + sizeof(int) * PT_MAXROWS;
   static VrpAttrOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3, KEEPK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       vrp_set_error("prologue_tables: cannot raise dynamic LDS to %zu bytes", lds);
       return 1;
@@ -626,14 +646,20 @@ static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
   constexpr int NWV = (X3 && RT_ <= 5) ? PT_X3_WAVES : 4;
   int nsub = 4;
   while (nsub > 1 && 8 * (nsub / 2) * NWV >= p.npacks) nsub /= 2;
-  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3>), dim3(64 * nsub), dim3(64 * NWV), lds, st, p);
+  hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3, KEEPK>), dim3(64 * nsub), dim3(64 * NWV), lds, st, p);
   VRP_CHECK_LAUNCH("prologue_tables");
   return 0;
 }
 template <int RT_, bool VEC>
 static int launch_prologue_tables(const PrologueParams &p, hipStream_t st) {
-  if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true>(p, st);
-  return launch_prologue_tables_as<RT_, VEC, false>(p, st);
+  if constexpr (RT_ <= 5) {   // (keys are kept for N <= 63 only: never a RING instance)
+    if (p.KK4) {
+      if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true, true>(p, st);
+      return launch_prologue_tables_as<RT_, VEC, false, true>(p, st);
+    }
+  }
+  if (prologue_x3_enabled() && p.WprojX3) return launch_prologue_tables_as<RT_, VEC, true, false>(p, st);
+  return launch_prologue_tables_as<RT_, VEC, false, false>(p, st);
 }
 
 template <bool VEC>
@@ -691,6 +717,7 @@ static PrologueParams prologue_params(int kind, int B, int N, const float *emb, 
   const bool ring_x3 = prologue_x3_enabled() && fused_max_rows(N) > 80 && !ring_fp32;
   p.WprojX3 = (x3 || ring_x3) ? reinterpret_cast<const __bf16 *>(d.WprojX3) : nullptr;
   p.SG = w.SG; p.C0 = w.C0; p.SLD = w.SLD; p.row0 = w.row0; p.SL = w.SL; p.RT = w.RT;
+  p.KK4 = (kind != VRP_KIND_IRP) ? w.KK4 : nullptr;
   return p;
 }
 
@@ -972,6 +999,9 @@ extern "C" int vrp_decode_first_row(int kind, const void *derived, int B, int N,
   VRP_REQUIRE(derived && emb && workspace, "decode_first_row: NULL argument");
   if (kind == VRP_KIND_IRP) return 0;  // no first-node term: the prologue folded SG into SL
   hipStream_t st = (hipStream_t)stream;
+  // small batches: the prologue kept the keys, one workgroup per graph does it in one launch
+  // (the arithmetic the wider persistent kernels run ahead of their first step)
+  if (kk_floats(B, N) > 0) return vrp_launch_first_base(kind, derived, B, N, emb, workspace, st);
   Derived d = carve_derived(const_cast<void *>(derived));
   DecWs ws = carve_decws(workspace, B, N);
   // base = SG + FK . e_n with FK = e_first AfT^T, read by the steps as a second row

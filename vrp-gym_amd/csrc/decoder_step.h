@@ -75,7 +75,9 @@ StepParams vrp_make_step_params(int kind, const void *derived, const vrp_env *en
 bool vrp_persistent_eligible(int kind, int B, int N, int max_steps, int flags,
                              const vrp_rollout_io *io, hipStream_t st);
 int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream_t st,
-                                int waves = 1);
+                                int waves = 1, const void *derived_for_first = nullptr);
+bool vrp_persistent_folds_first(int kind, int B, int N, int waves, int flags);
+
 int vrp_persistent_width(int kind, int B, int N, int max_steps, int flags, const vrp_rollout_io *io,
                          hipStream_t st);
 void vrp_persistent_serialize_begin(hipStream_t st, void **token);

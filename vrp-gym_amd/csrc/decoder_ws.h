@@ -33,6 +33,8 @@ struct Derived {
                    // X*384 + 48 head + 16 tile + j16, k = 64 (q & 1) + 32 (q >> 1) + 8 j .. + 7
   float *WqgT;     // (128,384)  Wqg transposed: the stack kernel's epilogue computes QG = Wq_g g + bq
                    // for its own graphs, lane = output column (coalesced), instead of a GEMM launch
+  float *WqfT;     // (128,384)  Wqf transposed: the persistent kernels project the first chosen node
+                   // themselves (decoder_persistent.hip: persist_first_base)
 };
 
 static inline Derived carve_derived(void *base) {
@@ -57,13 +59,14 @@ static inline Derived carve_derived(void *base) {
   d.MP = p;    p += 128 * 384;
   d.WprojX3 = p; p += VRP_WPROJ_X3_FLOATS;
   d.WqgT = p;  p += 128 * 384;
+  d.WqfT = p;  p += 128 * 384;
   return d;
 }
 
 static inline int64_t derived_floats() {
   return 1536 * 128 + 1536 + 384 * 128 + 384 * 128 + 384 * 3 + 128 * 384 + 384 + 384 * 128 + 128 +
          128 * 384 + 128 + 128 * 384 + 1024 * 128 + 384 * 128 + 128 * 384 + VRP_WPROJ_X3_FLOATS +
-         128 * 384;
+         128 * 384 + 128 * 384;
 }
 
 // ------------------------------------------------------------------ per-episode workspace
@@ -85,6 +88,9 @@ struct DecWs {
                                  // raw-tile kernel's register layout as ONE 16-byte load per lane and
                                  // row pair (only for the shapes that kernel serves by default)
   float *RT;                     // (B,N,8,N)  pointer-logit table, row m = RT[b][m][:][:]
+  float *KK4;                    // (B,8,12,N,4)  the glimpse keys Wk e_n + bk of head h, four of the 48
+                                 // columns per element: written by the fused prologue for the shapes the
+                                 // persistent kernels serve (kk_floats), read once, after step 0
   float *cvec;                   // (B,N)                e_m . mb
   int32_t *last, *first;         // (B)
   // persistent multi-step kernel (decoder_persistent.hip)
@@ -148,6 +154,15 @@ static inline size_t proj_floats(int B, int N) {
 static inline size_t rtable_floats(int B, int N) {
   return use_rtable(N) ? (size_t)B * N * 8 * N : 0;
 }
+// (the shapes vrp_persistent_eligible admits: the persistent kernels fold the first chosen node
+// into the score rows themselves and need the keys for it)
+// (B <= 1024: where the four-wave grid is resident on a whole MI355X.  For these shapes EVERY
+// path takes the first node's part of the score rows from persist_first_base -- `base` is a
+// function of the shape, not of the path; beyond, the keys' stores cost the prologue more than
+// the two launches they replace: +5..9 % at 2048 x 40)
+static inline size_t kk_floats(int B, int N) {
+  return (N <= 63 && B <= 1024 && use_fused_prologue(N)) ? (size_t)B * 8 * N * 48 : 0;
+}
 
 static inline DecWs carve_decws(void *ws, int B, int N) {
   char *p = (char *)ws;
@@ -166,6 +181,7 @@ static inline DecWs carve_decws(void *ws, int B, int N) {
   w.FK = (float *)p;     p += vrp_align_up((size_t)B * 1024 * 4);
   w.SL = (float *)p;    p += vrp_align_up(tb);
   w.RT = (float *)p;    p += vrp_align_up(rtable_floats(B, N) * 4);
+  w.KK4 = kk_floats(B, N) ? (float *)p : nullptr; p += vrp_align_up(kk_floats(B, N) * 4);
   w.embP = (float *)p;  p += vrp_align_up(pairs_floats(B, N) * 4);
   w.cvec = (float *)p;  p += vrp_align_up(R * 4);
   w.last = (int32_t *)p;  p += vrp_align_up((size_t)B * 4);
@@ -192,6 +208,7 @@ static inline int64_t decws_bytes(int B, int N) {
                    vrp_align_up(proj_floats(B, N) * 4) + 6 * vrp_align_up(hn) +
                    vrp_align_up((size_t)B * 128 * 4) + vrp_align_up((size_t)B * 1024 * 4) +
                    vrp_align_up(tb) + vrp_align_up(rtable_floats(B, N) * 4) +
+                   vrp_align_up(kk_floats(B, N) * 4) +
                    vrp_align_up(pairs_floats(B, N) * 4) +
                    vrp_align_up(R * 4) + 5 * vrp_align_up((size_t)B * 4) +
                    vrp_align_up((size_t)B * 8) +
@@ -204,6 +221,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 int vrp_launch_gemm_nt(const float *A, int lda, const float *W, int ldw, const float *bias,
                        const float *R, int ldr, float *C, int ldc, int M, int N, int K,
                        int relu, hipStream_t stream);
+int vrp_launch_first_base(int kind, const void *derived, int B, int N, const float *emb,
+                          void *workspace, hipStream_t st);   // decoder_persistent.hip
 int vrp_launch_gemm_gather_k128(const float *A, int lda, const int32_t *gidx, int gstride,
                                 const float *W, int ldw, float *C, int ldc, int M, int N,
                                 hipStream_t stream);
