@@ -1395,6 +1395,69 @@ def test_persistent_steps_equal_per_step_launches(kind, B, N, greedy, train):
         assert last_move.min() < last_move.max()
 
 
+_FIRST_FOLD_CHILD = r"""
+import hashlib, os, sys
+sys.path[:0] = [os.path.join(sys.argv[1], "vrp-gym_amd"), sys.argv[1]]
+import numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from agents import runtime
+import agents
+from gym_vrp.envs import TSPEnv, VRPEnv
+out = {}
+for kind, B, N, greedy in ((0, 512, 20, True), (1, 100, 21, False), (0, 33, 5, True), (1, 1024, 40, True), (1, 7, 63, False)):
+    env = (TSPEnv, VRPEnv)[kind](num_nodes=N, batch_size=B, num_draw=1, seed=13)
+    agent = (agents.TSPAgent, agents.VRPAgent)[kind](seed=69)
+    agent.model.eval()
+    steps = runtime.max_steps_for(kind, N)
+    noise = torch.empty((steps, B, N)).exponential_(1, generator=torch.Generator().manual_seed(2))
+    for persistent in (True, False):
+        e = __import__("copy").deepcopy(env)
+        with torch.no_grad():
+            r = runtime.rollout(agent.model, e, greedy, noise=None if greedy else noise, record=True,
+                                persistent=persistent)
+        T = r.T
+        out[f"{kind}_{B}_{N}_{int(persistent)}_loss"] = r.acc_loss.cpu().numpy()
+        out[f"{kind}_{B}_{N}_{int(persistent)}_logp"] = r.acc_logp.cpu().numpy()
+        out[f"{kind}_{B}_{N}_{int(persistent)}_act"] = r.actions[:T].cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_first_node_fold_against_gemm_route(tmp_path):
+    """Small batches (B <= 1024, N <= 63, TSP / VRP) take the first chosen node's part of the score
+    rows from persist_first_base -- inside the persistent grid or as first_base_kernel -- instead of
+    the first-node GEMM + score_base_kernel (graph_decoder.py:88-92).  Same rollouts with
+    VRP_NO_KEEP_KEYS=1 (the GEMM route at every shape): costs and log-probs within the eval
+    tolerance, the same tours except on near-ties; and within ONE build the persistent and the
+    per-step path stay bit-identical (base is a function of the shape, not of the path)."""
+    import sys
+    import _proc
+    res = {}
+    for tag, extra in (("keys", {}), ("gemm", {"VRP_NO_KEEP_KEYS": "1"})):
+        env = {k: v for k, v in os.environ.items() if k != "VRP_NO_KEEP_KEYS"}
+        env.update(extra)
+        out = str(tmp_path / f"{tag}.npz")
+        r = _proc.run([sys.executable, "-c", _FIRST_FOLD_CHILD, ROOT, out], env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    a, g = res["keys"], res["gemm"]
+    for key in a.files:
+        if key.endswith("_1_loss") or key.endswith("_1_logp") or key.endswith("_1_act"):
+            # persistent == per-step, bit for bit, in both builds
+            other = key.replace("_1_", "_0_")
+            assert np.array_equal(a[key], a[other]), key
+            assert np.array_equal(g[key], g[other]), key
+    for key in a.files:
+        if key.endswith("_act"):
+            same = (a[key] == g[key]).all(axis=0)     # graphs whose whole tour agrees
+            assert same.mean() >= 0.97, (key, same.mean())
+            stem = key[:-4]
+            T = a[key].shape[0]
+            assert np.max(np.abs(a[stem + "_loss"][same] - g[stem + "_loss"][same])) < TOL
+            assert np.max(np.abs(a[stem + "_logp"][same] - g[stem + "_logp"][same])) < TOL * max(1, T / 4)
+
+
 @pytest.mark.parametrize("kind,B,N,greedy", [(1, 64, 100, False), (2, 3000, 40, False),
                                              (1, 3000, 40, True), (2, 16, 30, False)])
 def test_paced_step_loop_equals_fixed_length_loop(kind, B, N, greedy):

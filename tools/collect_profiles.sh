@@ -46,4 +46,6 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_
 # of commit 8d3e66b, built by the caller), and the stack kernel's per-phase shader-clock trace
 [ -f vrp-gym_amd/vrpgym_hip/libvar_r05.so ] && bash tools/gpu_r6_wall3.sh 2>&1 | grep "kind=" > $OUT/wall_vs_r05.txt
 [ -f vrp-gym_amd/vrpgym_hip/libvar_trace.so ] && VRPGYM_HIP_LIB=$PWD/vrp-gym_amd/vrpgym_hip/libvar_trace.so python3 tools/rollout_loop.py 0 20 512 10 > $OUT/stack_trace.txt 2>&1
+# ... and the fused prologue kernel's (make EXTRA=-DVRP_PRO_TRACE build of decoder_prologue.hip)
+[ -f vrp-gym_amd/vrpgym_hip/libvar_ptrace.so ] && { VRPGYM_HIP_LIB=$PWD/vrp-gym_amd/vrpgym_hip/libvar_ptrace.so python3 tools/prologue_sizes.py 0 8192 40; VRPGYM_HIP_LIB=$PWD/vrp-gym_amd/vrpgym_hip/libvar_ptrace.so python3 tools/prologue_sizes.py 0 512 20; } > $OUT/prologue_trace.txt 2>&1
 ls $OUT

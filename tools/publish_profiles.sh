@@ -17,7 +17,7 @@ python3 tools/timeline.py "$(trace $S/shape_0_20_512)" encoder_stack > $D/${R}_t
 python3 tools/timeline.py "$(trace $S/shape_0_40_8192)" > $D/${R}_timeline_tsp40_b8192.txt
 python3 tools/timeline.py "$(trace $S/shape_1_40_8192)" > $D/${R}_timeline_vrp40_b8192.txt
 python3 tools/timeline.py "$(trace $S/shape_1_100_2048_0_1)" > $D/${R}_timeline_vrp100_b2048.txt
-for f in tile_phases.txt stream_rate.txt gemm_rows_probe.txt gemm_tn_probe.txt bf16x3_probe.txt wall_vs_r05.txt stack_trace.txt source_hash.txt; do [ -f $S/$f ] && cp $S/$f $D/${R}_$f; done
+for f in tile_phases.txt stream_rate.txt gemm_rows_probe.txt gemm_tn_probe.txt bf16x3_probe.txt wall_vs_r05.txt stack_trace.txt prologue_trace.txt source_hash.txt; do [ -f $S/$f ] && cp $S/$f $D/${R}_$f; done
 for t in vrp40_b2048 irp40_b1024 tsp20_b512; do
   cp "$(stats $S/train_$t)" $D/${R}_train_${t}_kernel_stats.csv
 done

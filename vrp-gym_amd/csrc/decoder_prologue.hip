@@ -106,6 +106,17 @@ struct PrologueParams {
 #ifndef PT_X3_WAVES
 #define PT_X3_WAVES 8
 #endif
+// Developer aid (make EXTRA=-DVRP_PRO_TRACE): shader-clock stamps of one workgroup's waves at the
+// phase boundaries of their first six packs, printed after the sixth launch of an instance
+// (profiles/r06_prologue_trace.txt).
+#ifdef VRP_PRO_TRACE
+#define PTT_SLOTS 64
+__device__ unsigned long long g_pro_trace[8 * PTT_SLOTS];
+#define PT_MARK(i)                                                                         \
+  if (blockIdx.x == 100 && lane == 0 && (i) < PTT_SLOTS) g_pro_trace[wave * PTT_SLOTS + (i)] = __builtin_amdgcn_s_memtime()
+#else
+#define PT_MARK(i)
+#endif
 // KEEPK (round 6): the small-batch instances also leave the glimpse keys in memory (DecWs::KK4,
 // decoder_persistent.hip: persist_first_base).  A template parameter, not a run-time branch: the
 // store's address arithmetic costs the three-tile bf16 instance eleven more spilled registers,
@@ -230,9 +241,11 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
     }
   }
   __syncthreads();
+  PT_MARK(0);
+  [[maybe_unused]] int pk_ = 0;
 
-
-  for (int pack = first; pack < p.npacks; pack += stride) {
+  for (int pack = first; pack < p.npacks; pack += stride, ++pk_) {
+    PT_MARK(8 * pk_ + 1);
     // (the weight slices are re-read from LDS for every pack: keeping them in registers
     // across the loop would cost up to 384 VGPRs)
     asm volatile("" ::: "memory");
@@ -269,6 +282,7 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    PT_MARK(8 * pk_ + 2);
 #pragma unroll
     for (int H = 0; H < 2; ++H) {
       // ---- stage 1: transposed projections ----------------------------------------------
@@ -434,6 +448,7 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       }
       __builtin_amdgcn_sched_barrier(0);
 
+      PT_MARK(8 * pk_ + (H ? 6 : 3));
       // constant part of the score rows for this lane's four columns of every tile (IRP)
       float bcol[RT_][4];
 #pragma unroll
@@ -491,6 +506,7 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
           }
         }
       }
+      PT_MARK(8 * pk_ + (H ? 8 * PTT_SLOTS : 4));
       // ---- stage 2: table tiles straight from the accumulators ---------------------------
       // Addresses: one 64-bit base per pack, 32-bit element offsets inside it (a pack's
       // slice of a table is at most 4 x 80 x 8 x 80 floats).
@@ -620,6 +636,7 @@ __global__ __launch_bounds__((X3 && !RING) ? 64 * PT_X3_WAVES : 256, 1) void pro
       }
       flush();
       __builtin_amdgcn_sched_barrier(0);
+      PT_MARK(8 * pk_ + (H ? 7 : 5));
     }
   }
 }
@@ -648,6 +665,27 @@ static int launch_prologue_tables_as(const PrologueParams &p, hipStream_t st) {
   while (nsub > 1 && 8 * (nsub / 2) * NWV >= p.npacks) nsub /= 2;
   hipLaunchKernelGGL((prologue_tables_kernel<RT_, VEC, (RT_ > 5), X3, KEEPK>), dim3(64 * nsub), dim3(64 * NWV), lds, st, p);
   VRP_CHECK_LAUNCH("prologue_tables");
+#ifdef VRP_PRO_TRACE
+  {
+    static int calls = 0;
+    if (++calls == 6) {
+      (void)hipDeviceSynchronize();
+      static unsigned long long h[8 * PTT_SLOTS];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pro_trace), sizeof(h));
+      for (int wv = 0; wv < NWV; ++wv) {
+        const unsigned long long *t = h + wv * PTT_SLOTS;
+        fprintf(stderr, "[prologue trace] wave %d:", wv);
+        for (int pk = 0; pk < 6; ++pk) {
+          const unsigned long long *u = t + 8 * pk;
+          fprintf(stderr, " | top+%llu setup %llu s1a %llu extra %llu s2a %llu s1b %llu s2b %llu = %llu",
+                  u[1] - t[0], u[2] - u[1], u[3] - u[2], u[4] - u[3], u[5] - u[4], u[6] - u[5], u[7] - u[6],
+                  u[7] - u[1]);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
   return 0;
 }
 template <int RT_, bool VEC>

@@ -160,8 +160,13 @@ static inline size_t rtable_floats(int B, int N) {
 // path takes the first node's part of the score rows from persist_first_base -- `base` is a
 // function of the shape, not of the path; beyond, the keys' stores cost the prologue more than
 // the two launches they replace: +5..9 % at 2048 x 40)
+// A/B aid and the parity test: VRP_NO_KEEP_KEYS=1 sends every shape through the GEMM + score_base route
+static inline bool keep_keys_off() {
+  static const bool v = getenv("VRP_NO_KEEP_KEYS") != nullptr;
+  return v;
+}
 static inline size_t kk_floats(int B, int N) {
-  return (N <= 63 && B <= 1024 && use_fused_prologue(N)) ? (size_t)B * 8 * N * 48 : 0;
+  return (N <= 63 && B <= 1024 && use_fused_prologue(N) && !keep_keys_off()) ? (size_t)B * 8 * N * 48 : 0;
 }
 
 static inline DecWs carve_decws(void *ws, int B, int N) {
