@@ -120,6 +120,9 @@ def test_cu_mask_falls_back_before_the_episode():
                                            # fallback walks four graphs at a time, two idle at the end
     (1, 1022, 2), (2, 510, 4),             # the several-waves-per-graph kernels: their own
                                            # state-save code (wave 0) and finalize path
+    (0, 510, 4), (0, 766, 4),              # a four-wave TSP grid finalizes itself: the workgroup that
+                                           # raised the flag first waits for the others and runs the
+                                           # fallback inside the grid (no finalize launch)
 ])
 def test_forced_non_resident_grid_falls_back_transparently(kind, batch, waves):
     """Workgroups forced onto 32 compute units that cannot hold them all: most of the grid waits

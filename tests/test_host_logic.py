@@ -490,6 +490,13 @@ HOT_KERNEL_SPILL_BUDGET = {
 }
 
 
+# decode_persistent4_kernel<4>: no spilled register in the kernel's own code (the episode loop has no
+# scratch instruction: checked in the ISA); the private segment is the stack of
+# persistent_fallback_call, the out-of-line fallback a self-finalizing TSP grid runs after a failed
+# hand-off -- a real call precisely so that its 200 registers stay out of the loop's allocation.
+HOT_KERNEL_CALL_STACK = {"decode_persistent4_kernel<4>": 640}
+
+
 def test_hot_kernels_do_not_spill():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
@@ -500,9 +507,10 @@ def test_hot_kernels_do_not_spill():
     over = {k: (table[k]["vgpr_spill"], table[k]["scratch"]) for k, budget in HOT_KERNEL_SPILL_BUDGET.items()
             if table[k]["vgpr_spill"] > budget}
     assert not over, f"(spilled registers, scratch bytes) above the audited budget: {over}"
-    # an instance with no spilled register has no scratch at all
+    # an instance with no spilled register has no scratch at all -- except the stack of a function
+    # it CALLS on a path that never runs in a healthy episode
     for k, budget in HOT_KERNEL_SPILL_BUDGET.items():
         if budget == 0:
-            assert table[k]["scratch"] == 0, (k, table[k])
+            assert table[k]["scratch"] <= HOT_KERNEL_CALL_STACK.get(k, 0), (k, table[k])
     # every kernel fits the register file of its launch bounds (a sanity check of the reader)
     assert all(0 < r["vgpr"] <= 512 and r["agpr"] <= r["vgpr"] for r in table.values())   # (.vgpr_count includes the AGPRs)

@@ -60,6 +60,8 @@ struct PersistParams {
   long long spin_ticks;       // longest wait for a hand-off word, in wall_clock64() ticks
   int32_t *fail_host;         // pinned host counter: episodes of this device that fell back
   // the first chosen node's part of the score rows, computed by the grid itself (persist_first_base)
+  int fold_final;             // four-wave TSP grid: no persistent_finalize_kernel behind it (see the
+                              // end of decode_persistent4_kernel); hist row 0 = per-graph "left" flags
   int fold_first;             // 1: base is not there yet (vrp_decode_first_row was skipped)
   const float *WqfT;          // (128,384)  Derived::WqfT
   const float *KK4;           // (B,8,12,N,4)  DecWs::KK4
@@ -86,6 +88,13 @@ struct PersistParams {
 // number of set bits of a wave-wide ballot below this lane (v_mbcnt: no lane-mask pair to keep alive)
 __device__ __forceinline__ int lanes_below(unsigned long long bits) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bits, 0u));
+}
+
+// agent-scope (write-through) store: what a four-wave grid that finalizes itself writes must not
+// linger dirty in one XCD's L2 (see the end of decode_persistent4_kernel)
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One hand-off wait.  Lanes 0..7 poll the mask word of "their" graph until bit 63 shows; lane 8
@@ -502,7 +511,7 @@ __device__ __forceinline__ void persist_first_base(const PersistParams &pp, int 
     const float v = fmaf(a0 + a1, c48, sg[j]);
     bs[j] = v;
     const size_t o = ((size_t)b * 8 + h) * N + ln;
-    if (inN) pp.base_out[o] = v;
+    if (inN) st_agent(&pp.base_out[o], v);
     if (inN && curs_out) curs_out[o] = sl[j] + v;   // step 1's complete row (last = first), latency mode
   }
 }
@@ -534,17 +543,28 @@ __global__ __launch_bounds__(256) void first_base_kernel(PersistParams pp) {
 #ifndef P2_NB
 #define P2_NB 2      // its table-row work items in flight
 #endif
+// (a real call: the fallback -- 200 registers wide -- must not take part in the episode loop's
+// register allocation; it reads the parameters from the kernel argument segment)
+__device__ __attribute__((noinline)) void persistent_fallback_call(const PersistParams *pp,
+                                                                   float (*a_s)[8 * 64], float (*u_s)[64],
+                                                                   int (*sel_s)[64]);
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persistent4_kernel(PersistParams pp) {
   constexpr int HPW = 8 / NW;   // heads per wave
+  constexpr bool FOLD = NW == 4;   // a 256-thread workgroup: can run the fallback itself (fold_final)
   const StepParams &p = pp.s;
-  __shared__ __attribute__((aligned(16))) float a_s[8 * 64];  // a[h][n], hn order
-  __shared__ __attribute__((aligned(16))) float u_s[64];
-  __shared__ int sel_s[64];                 // compacted list of selectable nodes of the step
+  // (FOLD: four times the rows the episode loop needs -- the fallback walks four graphs at a time)
+  __shared__ __attribute__((aligned(16))) float fa_s[FOLD ? 4 : 1][8 * 64];
+  __shared__ __attribute__((aligned(16))) float fu_s[FOLD ? 4 : 1][64];
+  __shared__ int fsel_s[FOLD ? 4 : 1][64];
+  float (&a_s)[8 * 64] = fa_s[0];           // a[h][n], hn order
+  float (&u_s)[64] = fu_s[0];
+  int (&sel_s)[64] = fsel_s[0];             // compacted list of selectable nodes of the step
   __shared__ unsigned long long wrd_s[8];   // the eight other graphs' mask words of the step
   __shared__ float mx_s[NW];
-  __shared__ int ctl_s[4];                  // [0] chosen node, [1] 1 = finished / gave up, [2] nsel,
-                                            // [3] bits of the vehicle load as fp32 (IRP)
+  __shared__ int ctl_s[6];                  // [0] chosen node, [1] 1 = finished / gave up, [2] nsel,
+                                            // [3] bits of the vehicle load as fp32 (IRP), [4] 1 = this
+                                            // workgroup raised `err` first, [5] 1 = it left on `err`
   __shared__ __attribute__((aligned(16))) float fe_s[128];          // persist_first_base: e_first,
   __shared__ __attribute__((aligned(16))) float fq_s[2 * 384];      // the query part's two k halves
 
@@ -619,13 +639,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
   float loadf = (float)load0;   // the softmax's load factor (IRP); later steps: from wave 0
   // what the fallback (persistent_finalize_kernel) restarts from, should this launch fail
   if (wave == 0) {
-    if (inN) pp.sv_visited[(size_t)b * N + lane] = (uint8_t)vis;
+    if (inN) st_agent(&pp.sv_visited[(size_t)b * N + lane], (uint8_t)vis);
     if (lane == 0) {
-      pp.sv_cur[b] = cur;
-      pp.sv_last[b] = last;
-      pp.sv_load[b] = load0;
-      pp.sv_accl[b] = accl;
-      pp.sv_accp[b] = accp;
+      st_agent(&pp.sv_cur[b], cur);
+      st_agent(&pp.sv_last[b], last);
+      st_agent(&pp.sv_load[b], load0);
+      st_agent(&pp.sv_accl[b], accl);
+      st_agent(&pp.sv_accp[b], accp);
     }
   }
   // the selectable list of the first step
@@ -634,7 +654,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
     const unsigned long long sel = __ballot(s_i);
     if (wave == 0) {
       if (s_i) sel_s[lanes_below(sel)] = lane;
-      if (lane == 0) { ctl_s[1] = 0; ctl_s[2] = __popcll(sel); }
+      if (lane == 0) { ctl_s[1] = 0; ctl_s[2] = __popcll(sel); ctl_s[4] = 0; ctl_s[5] = 0; }
     }
   }
   P4_BARRIER();
@@ -673,8 +693,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
         if (__any(!(w & PERSIST_VALID))) {
           // gave up, or somebody else did: raise the flag and leave (see the one-wave kernel)
           if (lane == 0) {
-            __hip_atomic_store(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (whoever raises it FIRST also runs the fallback when the grid finalizes itself)
+            ctl_s[4] = __hip_atomic_exchange(pp.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
             ctl_s[1] = 1;
+            ctl_s[5] = 1;
           }
         }
       }
@@ -750,8 +772,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
     if (wave == 0) {
       float u = -INFINITY;
       if (inN && !own_mask) u = p.clip * tanhf(u_s[lane] + cv);  // graph_decoder.py:97-98
-      if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)t * B + b) * N + lane] = (uint8_t)own_mask;
-      if (p.io.load_trace && lane == 0) p.io.load_trace[(size_t)t * B + b] = (float)load0;
+      if (p.io.mask_trace && inN) st_agent(&p.io.mask_trace[((size_t)t * B + b) * N + lane], (uint8_t)own_mask);
+      if (p.io.load_trace && lane == 0) st_agent(&p.io.load_trace[(size_t)t * B + b], (float)load0);
       if (!p.sample) {
         idx = wave_argmax_lane(u);
       } else {
@@ -811,8 +833,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
       const double dy = readlane_f64(xy.y, cur) - readlane_f64(xy.y, idx);
       const double dist = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
       if (lane == 0) {
-        if (p.io.actions) p.io.actions[(size_t)t * B + b] = idx;
-        if (p.io.step_logp) p.io.step_logp[(size_t)t * B + b] = logp;
+        if (p.io.actions) st_agent(&p.io.actions[(size_t)t * B + b], (int64_t)idx);
+        if (p.io.step_logp) st_agent(&p.io.step_logp[(size_t)t * B + b], logp);
       }
       if (ta >= 0) {           // this step was the forced return after `done`
         ret = (float)(-dist);
@@ -833,11 +855,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
           __hip_atomic_store(pp.hist + (size_t)tt * B + b, word, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
         for (int tt = t + 1; tt < p.max_steps; ++tt) {
-          if (p.io.mask_trace && inN) p.io.mask_trace[((size_t)tt * B + b) * N + lane] = (uint8_t)mk;
+          if (p.io.mask_trace && inN) st_agent(&p.io.mask_trace[((size_t)tt * B + b) * N + lane], (uint8_t)mk);
           if (lane == 0) {
-            if (p.io.load_trace) p.io.load_trace[(size_t)tt * B + b] = (float)load;
-            if (p.io.actions) p.io.actions[(size_t)tt * B + b] = idx;
-            if (p.io.step_logp) p.io.step_logp[(size_t)tt * B + b] = 0.f;
+            if (p.io.load_trace) st_agent(&p.io.load_trace[(size_t)tt * B + b], (float)load);
+            if (p.io.actions) st_agent(&p.io.actions[(size_t)tt * B + b], (int64_t)idx);
+            if (p.io.step_logp) st_agent(&p.io.step_logp[(size_t)tt * B + b], 0.f);
           }
         }
       }
@@ -846,17 +868,57 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
   }
   // ---- state back to memory (wave 0 holds it) ------------------------------------------------
   if (wave == 0) {
-    if (inN) p.env.visited[(size_t)b * N + lane] = (uint8_t)vis;
+    if (inN) st_agent(&p.env.visited[(size_t)b * N + lane], (uint8_t)vis);
     if (lane == 0) {
-      p.env.cur[b] = cur;
-      if (p.kind == VRP_KIND_IRP) p.env.load[b] = load0;
-      p.io.acc_loss[b] = accl;
-      p.io.acc_logp[b] = accp;
-      p.last[b] = cur;
-      pp.ta[b] = ta < 0 ? p.max_steps - 1 : ta;
-      pp.ret[b] = ret;
-      pp.wb_cur[b] = wb_cur;
-      pp.wb_load[b] = wb_load;
+      st_agent(&p.env.cur[b], cur);
+      if (p.kind == VRP_KIND_IRP) st_agent(&p.env.load[b], load0);
+      st_agent(&p.io.acc_loss[b], accl);
+      st_agent(&p.io.acc_logp[b], accp);
+      st_agent(&p.last[b], cur);
+      st_agent(&pp.ta[b], ta < 0 ? p.max_steps - 1 : ta);
+      st_agent(&pp.ret[b], ret);
+      st_agent(&pp.wb_cur[b], wb_cur);
+      st_agent(&pp.wb_load[b], wb_load);
+    }
+  }
+  // ---- a four-wave TSP grid finalizes itself: no launch behind it --------------------------------
+  // What persistent_finalize_kernel does for a TSP batch that ran through is nothing but the
+  // notdone flags (every graph finishes at the same step, there is no way back to add or take
+  // back): graph 0's workgroup writes them.  What it does for a FAILED episode -- the fallback --
+  // needs every workgroup of the grid to have left: each one raises its "left" word (hist row 0,
+  // unused otherwise) once its stores are through, and the workgroup that raised `err` FIRST
+  // waits for all of them and then walks the episode itself, exactly as the finalize kernel would.
+  // Everything this kernel writes to memory is written by wave 0 with agent-scope (write-through)
+  // stores: nothing of a workgroup that left stays dirty in its XCD's L2 to land on top of what
+  // the fallback writes later from another one.  (Folding the normal path of VRP / IRP as well
+  // -- "the last workgroup to leave takes the maximum" -- was measured: a release / acquire
+  // fence per workgroup costs the grid 11 / 45 us, a same-address atomic with return per
+  // workgroup 5.6 us at the end of an episode whose graphs finish together.)
+  if constexpr (FOLD) {
+    if (pp.fold_final) {
+      if (wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);   // the stores above are through
+        if (lane == 0) st_agent(pp.hist + b, 1ull);
+        if (b == 0 && !ctl_s[5]) {       // ran through: T - 1 = ta (the same for every TSP graph)
+          const int last_step = ta < 0 ? p.max_steps - 1 : ta;
+          for (int tt = t0 + lane; tt < p.max_steps; tt += 64) st_agent(&p.io.notdone[tt], tt < last_step ? 1 : 0);
+        }
+      }
+      if (ctl_s[4]) {   // (uniform: written before the barrier the loop was left behind)
+        // bounded like every other wait of this kernel: 64 x the hand-off limit
+        const long long start = wall_clock64();
+        for (int g = tid; g < B; g += 64 * NW)
+          while (__hip_atomic_load(pp.hist + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull &&
+                 wall_clock64() - start < 64 * pp.spin_ticks)
+            __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#if defined(__HIP_DEVICE_COMPILE__)
+        persistent_fallback_call((const PersistParams *)__builtin_amdgcn_kernarg_segment_ptr(), fa_s, fu_s,
+                                 fsel_s);
+#endif
+      }
     }
   }
 }
@@ -872,38 +934,52 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : P2_WAVES) void decode_persis
 // bit-identical to an undisturbed launch) and a workgroup barrier where that path has a kernel
 // boundary.  Slow (one CU) and rare; never wrong, never waiting for anybody.
 __device__ int32_t g_fail_sink;   // fail_host stand-in when no pinned word could be allocated
-__global__ __launch_bounds__(256) void persistent_finalize_kernel(PersistParams pp) {
+// the fallback: 256 threads, after every workgroup of the failed grid has left
+__device__ __forceinline__ void persistent_fallback_body(const PersistParams &pp, float (&a_s)[4][8 * 64],
+                                                         float (&u_s)[4][64], int (&sel_s)[4][64]) {
   const StepParams &p = pp.s;
   const int B = p.B, N = p.N, t0 = p.t, max_steps = p.max_steps;
+  const int tid = threadIdx.x;
+  // (every workgroup saved its graph's state before anything else)
+  for (int i = tid; i < B * N; i += 256) p.env.visited[i] = pp.sv_visited[i];
+  for (int b = tid; b < B; b += 256) {
+    p.env.cur[b] = pp.sv_cur[b];
+    p.last[b] = pp.sv_last[b];
+    if (p.kind == VRP_KIND_IRP) p.env.load[b] = pp.sv_load[b];
+    p.io.acc_loss[b] = pp.sv_accl[b];
+    p.io.acc_logp[b] = pp.sv_accp[b];
+  }
+  __threadfence();
+  __syncthreads();
+  for (int t = t0; t < max_steps; ++t) {
+    // batch-wide done (tsp.py:95): every thread reads the flag the step before left in L2
+    if (__hip_atomic_load(&p.io.notdone[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      break;
+    for (int g0 = 0; g0 < B; g0 += 4)
+      step_rt_body<1, 4, false>(p, t, g0 + (tid >> 6), a_s, u_s, sel_s);
+    __threadfence();
+    __syncthreads();
+  }
+  if (tid == 0)
+    __hip_atomic_fetch_add(pp.fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __attribute__((noinline)) void persistent_fallback_call(const PersistParams *pp,
+                                                                   float (*a_s)[8 * 64], float (*u_s)[64],
+                                                                   int (*sel_s)[64]) {
+  persistent_fallback_body(*pp, *reinterpret_cast<float (*)[4][8 * 64]>(a_s),
+                           *reinterpret_cast<float (*)[4][64]>(u_s), *reinterpret_cast<int (*)[4][64]>(sel_s));
+}
+__global__ __launch_bounds__(256) void persistent_finalize_kernel(PersistParams pp) {
+  const StepParams &p = pp.s;
+  const int B = p.B, t0 = p.t, max_steps = p.max_steps;
   const int tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float a_s[4][8 * 64];
   __shared__ __attribute__((aligned(16))) float u_s[4][64];
   __shared__ int sel_s[4][64];
   __shared__ int smax[4];
   if (__hip_atomic_load(pp.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-    // (every workgroup of the grid has run by now -- kernels of a stream do not overlap -- and
-    // saved its graph's state before anything else)
-    for (int i = tid; i < B * N; i += 256) p.env.visited[i] = pp.sv_visited[i];
-    for (int b = tid; b < B; b += 256) {
-      p.env.cur[b] = pp.sv_cur[b];
-      p.last[b] = pp.sv_last[b];
-      if (p.kind == VRP_KIND_IRP) p.env.load[b] = pp.sv_load[b];
-      p.io.acc_loss[b] = pp.sv_accl[b];
-      p.io.acc_logp[b] = pp.sv_accp[b];
-    }
-    __threadfence();
-    __syncthreads();
-    for (int t = t0; t < max_steps; ++t) {
-      // batch-wide done (tsp.py:95): every thread reads the flag the step before left in L2
-      if (__hip_atomic_load(&p.io.notdone[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-        break;
-      for (int g0 = 0; g0 < B; g0 += 4)
-        step_rt_body<1, 4, false>(p, t, g0 + (tid >> 6), a_s, u_s, sel_s);
-      __threadfence();
-      __syncthreads();
-    }
-    if (tid == 0)
-      __hip_atomic_fetch_add(pp.fail_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (every workgroup of the grid has run by now -- kernels of a stream do not overlap)
+    persistent_fallback_body(pp, a_s, u_s, sel_s);
     return;
   }
   if (p.io.notdone[t0 - 1] == 0) return;
@@ -1355,6 +1431,7 @@ static PersistParams make_persist_params(const StepParams &sp, void *workspace) 
   pp.spin_ticks = 2000000;   // 20 ms at 100 MHz
   pp.fail_host = nullptr;
   pp.fold_first = 0;
+  pp.fold_final = 0;
   pp.WqfT = nullptr; pp.KK4 = ws.KK4; pp.SG = ws.SG; pp.base_out = ws.base;
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < VRP_MAX_DEVICES) {
@@ -1409,14 +1486,19 @@ int vrp_launch_persistent_steps(const StepParams &sp, void *workspace, hipStream
   }
   // (the hand-off words and the error flag were cleared by vrp_decode_prologue: one persistent
   // launch per episode)
+  // a four-wave TSP grid finalizes itself (VRP_PERSISTENT_FINALIZE_LAUNCH=1: A/B aid, keeps the launch)
+  static const bool keep_launch = getenv("VRP_PERSISTENT_FINALIZE_LAUNCH") != nullptr;
+  pp.fold_final = (waves == 4 && sp.kind == VRP_KIND_TSP && !keep_launch) ? 1 : 0;
   void *token = nullptr;
   vrp_persistent_serialize_begin(st, &token);
   if (waves == 4) hipLaunchKernelGGL(decode_persistent4_kernel<4>, dim3(sp.B), dim3(256), 0, st, pp);
   else if (waves == 2) hipLaunchKernelGGL(decode_persistent4_kernel<2>, dim3(sp.B), dim3(128), 0, st, pp);
   else hipLaunchKernelGGL(decode_persistent_kernel, dim3(sp.B), dim3(64), 0, st, pp);
   VRP_CHECK_LAUNCH("decode_persistent");
-  hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, pp);
-  VRP_CHECK_LAUNCH("persistent_finalize");
+  if (!pp.fold_final) {
+    hipLaunchKernelGGL(persistent_finalize_kernel, dim3(1), dim3(256), 0, st, pp);
+    VRP_CHECK_LAUNCH("persistent_finalize");
+  }
   vrp_persistent_serialize_end(st, token);
   return 0;
 }
