@@ -240,7 +240,9 @@ const char *vrp_step_kernel_name(int kind, int B, int N, int flags);
  * folded, together with the graph-embedding part, into the last-node score table that every
  * later step reads one row of (the table is built here).  Appended to step 0 by
  * vrp_decode_step unless VRP_STEP_NO_FIRST_ROW is set.  No-op for IRP, whose context has no
- * first-node term (vrp_decode_prologue builds its table). */
+ * first-node term (vrp_decode_prologue builds its table).  (B <= 1024, N <= 63: one launch,
+ * first_base_kernel, from the glimpse keys the prologue kept; vrp_rollout's persistent decode
+ * grid computes the same rows itself and skips this call.) */
 int vrp_decode_first_row(int kind, const void *derived, int B, int N, const float *emb,
                          void *workspace, void *stream);
 

@@ -77,11 +77,11 @@ extern "C" int vrp_rollout_steps_range(int kind, const void *derived,
                          ? vrp_persistent_width(kind, env->B, env->N, max_steps, flags, io,
                                                 (hipStream_t)stream) : 0;
   if (pwaves > 0) {
-    // latency-bound regime: step 0 as its own launch (the first-node fold follows it), every
-    // later step inside ONE persistent launch (decoder_persistent.hip), one, two or four waves
-    // per graph
-    // (two- and four-wave grids compute the first node's part of the score rows themselves:
-    // no first-node GEMM, no score_base launch)
+    // latency-bound regime: step 0 as its own launch, every later step inside ONE persistent
+    // launch (decoder_persistent.hip), one, two or four waves per graph.  Two- and four-wave
+    // grids of small batches compute the first node's part of the score rows themselves (no
+    // first-node GEMM, no score_base launch behind step 0); a four-wave TSP grid also finalizes
+    // itself: four launches per rollout with the encoder and the prologue
     bool fold_first = false;
     if (t_begin == 0) {
       fold_first = vrp_persistent_folds_first(kind, env->B, env->N, pwaves, flags);

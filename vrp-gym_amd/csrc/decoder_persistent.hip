@@ -1,5 +1,6 @@
-// Steps 1 .. T-1 of an episode in ONE launch, for the latency-bound regime (B <= 2048 graphs,
-// N <= 63): one wave per graph keeps the whole per-graph state of the rollout loop
+// Steps 1 .. T-1 of an episode in ONE launch -- and, for batches of up to 1024 graphs, the first
+// chosen node's part of the score rows (persist_first_base) -- for the latency-bound regime
+// (B <= 2048 graphs, N <= 63): one wave per graph keeps the whole per-graph state of the rollout loop
 // (agents/graph_tsp_agent.py:78-88: GraphDecoder.forward agents/graph_decoder.py:51-115 +
 // env.step gym_vrp/envs/tsp.py:60-101) in registers across steps -- coordinates, visited row,
 // demand, load, current/last node, accumulators -- and only streams the step's score row and
@@ -33,7 +34,9 @@
 //     and leaves: a grid that cannot make progress drains in a few tens of milliseconds;
 //   * every graph saves the state it was launched with (visited row, location, load,
 //     accumulators) before it overwrites anything, and persistent_finalize_kernel -- one
-//     workgroup, launched behind the grid in any case -- on `err` puts that state back and
+//     workgroup, launched behind the grid (a four-wave TSP grid does without the launch: the
+//     workgroup that raised `err` first runs the same code once every other one has left, see
+//     the end of decode_persistent4_kernel) -- on `err` puts that state back and
 //     walks the remaining steps itself with the per-step kernel's body (decoder_rt_body.h),
 //     one workgroup barrier per step instead of hand-off words.  The step kernels are
 //     bit-identical (tests/test_gpu_parity.py), the in-kernel noise is counter-based: the
