@@ -497,6 +497,32 @@ HOT_KERNEL_SPILL_BUDGET = {
 HOT_KERNEL_CALL_STACK = {"decode_persistent4_kernel<4>": 640}
 
 
+def test_decoder_workspace_keeps_keys_for_small_batches_only():
+    """DecWs::KK4 (the glimpse keys the small-batch prologue instances leave for
+    persist_first_base, csrc/decoder_ws.h: kk_floats): B x 8 x N x 48 floats for B <= 1024 and
+    N <= 63, nothing beyond, nothing with VRP_NO_KEEP_KEYS (host-side layout only: no GPU)."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import vrpgym_hip as hip; lib = hip.lib();"
+            "print(*[lib.vrp_decoder_workspace_bytes(k, B, N) for k, B, N in "
+            "((0, 1024, 20), (0, 1025, 20), (1, 512, 63), (1, 512, 64))])" % os.path.join(ROOT, "vrp-gym_amd"))
+
+    def sizes(extra):
+        env = {k: v for k, v in os.environ.items() if k != "VRP_NO_KEEP_KEYS"}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, text=True, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return [int(x) for x in r.stdout.split()[-4:]]
+
+    keys, none = sizes({}), sizes({"VRP_NO_KEEP_KEYS": "1"})
+
+    def up(x):
+        return (x + 255) // 256 * 256
+    assert keys[0] - none[0] == up(1024 * 8 * 20 * 48 * 4)      # kept
+    assert keys[1] == none[1]                                    # B = 1025: not kept
+    assert keys[2] - none[2] == up(512 * 8 * 63 * 48 * 4)        # N = 63: kept
+    assert keys[3] == none[3]                                    # N = 64: not kept
+
+
 def test_hot_kernels_do_not_spill():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_resources
